@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE on this container's CPU.
+
+Run only in the build container (the reference tree lives at /root/reference and never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is committed is data only: seeds / small inputs and the reference's outputs as .npz.  The harness
+follows SURVEY.md Appendix A: permissive stubs for third-party modules the path imports but never uses
+arithmetically, and a wrapper that rewrites the reference's hard-coded ``device='cuda'`` factory calls
+(yolo_head_24p.py:176, losses.py:561,566) to CPU.  Reference files are not modified or copied.
+"""
+import importlib
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
+
+from ep24 import synth  # noqa: E402
+
+
+# --------------------------------------------------------------------------- harness
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        full = self.__name__ + "." + name
+        child = sys.modules.get(full)
+        if child is None:
+            child = _Stub(full)
+            child.__path__ = []
+            sys.modules[full] = child
+        return child
+
+    def __call__(self, *a, **k):
+        return self
+
+
+def install_stubs():
+    for name in ["loguru", "cv2", "zmq", "thop", "torchvision", "torchvision.ops", "tensorboard",
+                 "torch.utils.tensorboard", "pycocotools", "pycocotools.coco", "pycocotools.cocoeval",
+                 "pycocotools.mask", "seaborn", "prettytable", "skimage", "skimage.measure"]:
+        if name not in sys.modules:
+            m = _Stub(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    # loguru.logger.catch is used as a decorator
+    lg = sys.modules["loguru"]
+    lg.logger = _Stub("loguru.logger")
+
+
+def cpu_factories():
+    for fname in ("zeros", "arange", "ones", "tensor"):
+        orig = getattr(torch, fname)
+
+        def wrapped(*a, __orig=orig, **k):
+            dev = k.get("device")
+            if isinstance(dev, str) and dev.startswith("cuda"):
+                k["device"] = "cpu"
+            return __orig(*a, **k)
+
+        setattr(torch, fname, wrapped)
+
+
+def load_reference():
+    install_stubs()
+    cpu_factories()
+    sys.path.insert(0, os.path.join(REF, "yolox_24p"))
+    utils = importlib.import_module("utils")
+    models = importlib.import_module("models")
+    return utils, models
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def checksum(t):
+    return float(t.double().sum())
+
+
+# --------------------------------------------------------------------------- G1..G3 circle geometry
+def rows_for_matched(n, seed):
+    """pred [n,26] / target [n,50] rows covering contained / disjoint / lens cases."""
+    g = torch.Generator().manual_seed(seed)
+    lab = synth.make_labels(1, min(n, 50), seed=seed + 1)[0, :min(n, 50), 1:]
+    reps = (n + lab.shape[0] - 1) // lab.shape[0]
+    target = lab.repeat(reps, 1)[:n].clone()
+    pred = torch.empty(n, 26)
+    # centre offsets from 0 to 250 px: small -> containment, large -> disjoint
+    off = torch.rand(n, generator=g) * 250.0
+    off[::7] = 0.0                                   # exactly coincident centres (d == 0)
+    th = torch.rand(n, generator=g) * 6.2831853
+    pred[:, 0] = target[:, 0] + off * torch.cos(th)
+    pred[:, 1] = target[:, 1] + off * torch.sin(th)
+    pred[:, 2:] = torch.exp(torch.randn(n, 24, generator=g) * 0.8 + 3.6)
+    return pred, target
+
+
+def gen_geometry(utils, models):
+    iou = models.IOUloss(reduction="none")
+    # G1: method circle_inter
+    pred, target = rows_for_matched(96, 11)
+    gt_r = torch.sqrt((target[:, 2::2] - target[:, :1]) ** 2 + (target[:, 3::2] - target[:, 1:2]) ** 2)
+    res, dist = iou.circle_inter(target[:, 0], target[:, 1], gt_r, pred[:, 0], pred[:, 1], pred[:, 2:])
+    e_res, e_dist = iou.circle_inter(target[:0, 0], target[:0, 1], gt_r[:0], pred[:0, 0], pred[:0, 1], pred[:0, 2:])
+    save("g1_circle_inter", gt_cx=target[:, 0], gt_cy=target[:, 1], gt_r=gt_r, pd_cx=pred[:, 0], pd_cy=pred[:, 1],
+         pd_r=pred[:, 2:], res_inter=res, dist=dist, empty_res_shape=np.array(e_res.shape),
+         empty_dist_shape=np.array(e_dist.shape))
+
+    # G2: pairwise bboxes_iou
+    raw = synth.make_raw_head(1, seed=21)
+    dec = synth.decode_head(raw)[0]
+    for tag, (G, P) in {"a": (1, 1), "b": (3, 17), "c": (10, 4000), "d": (50, 8400)}.items():
+        a = synth.make_labels(1, G, seed=22 + G)[0, :G, 1:]
+        gsel = torch.Generator().manual_seed(5)
+        idx = torch.randperm(dec.shape[0], generator=gsel)[:P].sort().values
+        b = dec[idx, :26].contiguous()
+        out = utils.bboxes_iou(a, b)
+        if tag == "d":
+            save("g2_pairwise_" + tag, G=G, P=P, label_seed=22 + G, head_seed=21, sel_seed=5,
+                 a_sum=checksum(a), b_sum=checksum(b), out_sub=out[:, ::7], out_sum=checksum(out))
+        else:
+            save("g2_pairwise_" + tag, a=a, b=b, out=out)
+    # error convention (boxes.py:167-168)
+    try:
+        utils.bboxes_iou(torch.zeros(2, 49), torch.zeros(2, 26))
+        raised = False
+    except IndexError:
+        raised = True
+    assert raised
+
+    # G3: matched loss forward + gradient
+    pred, target = rows_for_matched(200, 31)
+    pred.requires_grad_(True)
+    loss24, draw = iou(pred, target)
+    w = torch.linspace(0.5, 1.5, 24)
+    (loss24 * w).sum().backward()
+    e_loss, e_draw = iou(pred[:0], target[:0])
+    save("g3_matched", pred=pred.detach(), target=target, loss24=loss24, w=w, grad=pred.grad,
+         empty_loss=e_loss, empty_draw0_shape=np.array(e_draw[0].shape))
+
+
+# --------------------------------------------------------------------------- G4..G6 assignment + loss
+def gen_assign(utils, models):
+    lf = models.Loss_Function(80)
+    xs, ys, ss = synth.anchor_grid()
+    A = xs.numel()
+    # G4: masks for convex and star polygons; record the margin to the 350-degree threshold
+    for tag, star in (("convex", False), ("star", True)):
+        lab = synth.make_labels(1, 12, seed=41, star=star)[0, :12, 1:]
+        captured = {}
+        orig_rad2deg = torch.rad2deg
+
+        def spy(x, _o=orig_rad2deg):
+            r = _o(x)
+            captured.setdefault("deg", []).append(r.sum(0))
+            return r
+
+        torch.rad2deg = spy
+        try:
+            fg, both = lf.get_in_boxes_info(lab, ss[None], xs[None], ys[None], A)
+        finally:
+            torch.rad2deg = orig_rad2deg
+        deg = torch.stack(captured["deg"])
+        xc = (xs * ss + 0.5 * ss)
+        yc = (ys * ss + 0.5 * ss)
+        in_box = lf.pts_in_poly(lab, xc, yc)
+        save("g4_masks_" + tag, label_seed=41, star=int(star), G=12, fg=fg, in_both=both, in_box=in_box,
+             min_margin=float((deg - 350.0).abs().min()), lab_sum=checksum(lab))
+
+    # G5/G6: full loss, two consecutive calls, batch with an empty image, gradient wrt outputs
+    B = 4
+    counts = [10, 0, 3, 25]
+    labels = synth.make_labels(B, counts, seed=51)
+    raw = synth.make_raw_head(B, seed=52)
+    rec = []
+    orig_assign = lf.get_assignments
+
+    def spy_assign(*a, **k):
+        out = orig_assign(*a, **k)
+        rec.append(out)
+        return out
+
+    lf.get_assignments = spy_assign
+    store = dict(B=B, counts=np.array(counts), label_seed=51, head_seed=52, labels_sum=checksum(labels),
+                 raw_sum=checksum(raw))
+    for call in range(2):
+        outputs = synth.decode_head(raw if call == 0 else raw * 0.98 + 0.01)
+        outputs.requires_grad_(True)
+        rec.clear()
+        tup = lf.forward(synth.outputs_train_tuple(outputs), labels)
+        tup[0].backward()
+        p = "c%d_" % call
+        store[p + "loss"] = tup[0]
+        store[p + "loss_iou_w"] = tup[1]
+        store[p + "loss_obj"] = tup[2]
+        store[p + "loss_cls"] = tup[3]
+        store[p + "loss_l1"] = float(tup[4])
+        store[p + "fg_per_gt"] = float(tup[5])
+        store[p + "draw_cx"] = tup[6][0]
+        store[p + "draw_cy"] = tup[6][1]
+        store[p + "draw_r"] = tup[6][2]
+        store[p + "reg_w"] = tup[6][3]
+        store[p + "obj_w"] = tup[6][4]
+        store[p + "cls_w"] = tup[6][5]
+        g = outputs.grad
+        store[p + "grad_sum"] = checksum(g)
+        store[p + "grad_abs_sum"] = checksum(g.abs())
+        nz = g.abs().sum(-1).reshape(-1).topk(400).indices.sort().values      # rows with the largest gradients
+        store[p + "grad_rows"] = nz
+        store[p + "grad_vals"] = g.reshape(-1, g.shape[-1])[nz]
+        store[p + "grad_obj"] = g[..., 26].reshape(-1)[::5]
+        img = 0
+        for b in range(B):
+            if counts[b] == 0:
+                continue
+            cls_, fgm, pious, minds, nfg = rec[img]
+            img += 1
+            store[p + "img%d_fg" % b] = fgm
+            store[p + "img%d_cls" % b] = cls_
+            store[p + "img%d_pious" % b] = pious
+            store[p + "img%d_gt" % b] = minds
+            store[p + "img%d_nfg" % b] = int(nfg)
+    save("g6_loss", **store)
+
+    # G5: one dense image at G=50 (stress) - assignment only
+    lf2 = models.Loss_Function(80)
+    labels = synth.make_labels(1, 50, seed=61)
+    outputs = synth.decode_head(synth.make_raw_head(1, seed=62))
+    rec2 = []
+    o2 = lf2.get_assignments
+    lf2.get_assignments = lambda *a, **k: (rec2.append(o2(*a, **k)) or rec2[-1])
+    tup = lf2.forward(synth.outputs_train_tuple(outputs), labels)
+    cls_, fgm, pious, minds, nfg = rec2[0]
+    save("g5_assign_g50", label_seed=61, head_seed=62, fg=fgm, cls=cls_, pious=pious, gt=minds, nfg=int(nfg),
+         loss=tup[0], loss_iou_w=tup[1], loss_obj=tup[2], loss_cls=tup[3])
+
+
+# --------------------------------------------------------------------------- G7 model
+def gen_model(utils, models):
+    nb = importlib.import_module("models.network_blocks")
+    torch.manual_seed(0)
+
+    def bn_patch(m):
+        for x in m.modules():
+            if isinstance(x, torch.nn.BatchNorm2d):
+                x.eps, x.momentum = 1e-3, 0.03
+                with torch.no_grad():
+                    x.weight.uniform_(0.5, 1.5)
+                    x.bias.uniform_(-0.3, 0.3)
+
+    def run_block(name, mod, x):
+        bn_patch(mod)
+        mod.train()
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        x = x.clone().requires_grad_(True)
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        y.backward(gy)
+        store = {"x": x.detach(), "y": y, "gy": gy, "gx": x.grad}
+        for k, v in sd.items():
+            store["w:" + k] = v
+        for k, v in mod.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                store["after:" + k] = v
+        for k, p in mod.named_parameters():
+            store["g:" + k] = p.grad
+        save("g7_" + name, **store)
+
+    g = torch.Generator().manual_seed(70)
+    run_block("baseconv3", nb.BaseConv(16, 24, 3, 1), torch.randn(2, 16, 12, 12, generator=g))
+    run_block("baseconv3s2", nb.BaseConv(16, 32, 3, 2), torch.randn(2, 16, 12, 12, generator=g))
+    run_block("baseconv1", nb.BaseConv(16, 8, 1, 1), torch.randn(2, 16, 10, 10, generator=g))
+    run_block("bottleneck", nb.Bottleneck(16, 16, True, 1.0), torch.randn(2, 16, 10, 10, generator=g))
+    run_block("csp", nb.CSPLayer(16, 16, n=2), torch.randn(2, 16, 10, 10, generator=g))
+    run_block("csp_noshort", nb.CSPLayer(32, 16, n=1, shortcut=False), torch.randn(2, 32, 10, 10, generator=g))
+    run_block("spp", nb.SPPBottleneck(16, 16), torch.randn(2, 16, 20, 20, generator=g))
+    run_block("focus", nb.Focus(3, 8, ksize=3), torch.randn(2, 3, 16, 16, generator=g))
+
+    # whole model at width 0.125 / depth 0.33, 64x64 input -> train-mode 5-tuple
+    torch.manual_seed(0)
+    in_ch = [256, 512, 1024]
+    model = models.YOLOX(models.YOLOPAFPN(0.33, 0.125, in_channels=in_ch, act="silu"),
+                         models.YOLOXHead(80, 0.125, in_channels=in_ch, act="silu"))
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    model.head.initialize_biases(1e-2)
+    model.train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(71)) * 255.0
+    xs, ys, st, out, orig = model(x, train=True)
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(72)) * 1e-3
+    out.backward(gy)
+    store = {"x": x, "out": out, "gy": gy, "x_shift0": xs[0], "y_shift1": ys[1], "stride2": st[2],
+             "n_params": sum(p.numel() for p in model.parameters())}
+    for k, v in sd.items():
+        store["w:" + k] = v
+    for k in ("backbone.backbone.stem.conv.conv.weight", "backbone.C3_p3.conv3.conv.weight",
+              "head.reg_preds.1.weight", "head.reg_preds.1.bias", "head.cls_preds.0.bias",
+              "backbone.backbone.dark5.2.m.0.conv2.bn.weight", "head.stems.2.bn.bias"):
+        store["g:" + k] = dict(model.named_parameters())[k].grad
+    store["after:stem_rm"] = model.state_dict()["backbone.backbone.stem.conv.bn.running_mean"]
+    store["after:stem_rv"] = model.state_dict()["backbone.backbone.stem.conv.bn.running_var"]
+    model.eval()
+    with torch.no_grad():
+        store["out_eval"] = model(x, train=False)
+    save("g7_model_tiny", **store)
+
+    # -l: names / shapes / parameter count only
+    torch.manual_seed(0)
+    big = models.YOLOX(models.YOLOPAFPN(1.0, 1.0, in_channels=in_ch), models.YOLOXHead(80, 1.0, in_channels=in_ch))
+    keys = list(big.state_dict().keys())
+    shapes = [tuple(v.shape) for v in big.state_dict().values()]
+    save("g7_model_l_keys", keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
+         n_params=sum(p.numel() for p in big.parameters()))
+
+
+# --------------------------------------------------------------------------- G8 sector warp
+def gen_sector():
+    sys.path.insert(0, REF)
+    np.bool8 = np.bool_
+    demo = importlib.import_module("yolox.demo_featuremap")
+    calls = {}
+
+    def fake_resize(img, dsize, *a, **k):
+        # identity stand-in: inputs are generated at the resize target so cv2's bilinear step is bypassed;
+        # the size the reference asked for is recorded
+        calls["dsize"] = dsize
+        assert img.shape[1] == dsize[0] and img.shape[0] == dsize[1], (img.shape, dsize)
+        return img
+
+    demo.cv2.resize = fake_resize
+    dist = demo.Image_Distortion()
+    store = {}
+    for theta in (30, 60, 90, 180):
+        for (h, w) in ((427, 640), (640, 640), (1280, 1280)):
+            # first call on a dummy to learn target rows T for this (theta, aspect)
+            T = _sector_rows(theta, h, w)
+            rng = np.random.RandomState(theta * 7 + h)
+            # index image: encode (row, col) of the resized source in the three channels exactly
+            rows = np.arange(T, dtype=np.int64)[:, None].repeat(13200, 1)
+            cols = np.arange(13200, dtype=np.int64)[None, :].repeat(T, 0)
+            flat = rows * 13200 + cols + 1                      # 1-based, < 2^24
+            img = np.stack([flat & 255, (flat >> 8) & 255, (flat >> 16) & 255], -1).astype(np.uint8)
+            mask = np.zeros_like(img)
+            r0, r1 = sorted(rng.randint(0, T, 2).tolist())
+            c0, c1 = sorted(rng.randint(0, 13200, 2).tolist())
+            mask[r0:r1 + 1, c0:c1 + 1] = 255
+            # the reference derives T from image.shape -> hand it an image of the ORIGINAL aspect only
+            # through scale_hw; we pass custom_rows to pin T and a [T,13200] source so resize is identity
+            new_img, bbox = dist.sector_distort(img, mask, Theta=theta, custom_rows=T)
+            code = (new_img[..., 0].astype(np.int64) | (new_img[..., 1].astype(np.int64) << 8)
+                    | (new_img[..., 2].astype(np.int64) << 16))
+            fill = (new_img[..., 0] == 114) & (new_img[..., 1] == 114) & (new_img[..., 2] == 114)
+            key = "t%d_%dx%d_" % (theta, h, w)
+            store[key + "T"] = T
+            store[key + "shape"] = np.array(new_img.shape)
+            src = np.ascontiguousarray(np.where(fill, -1, code - 1).astype(np.int32))
+            store[key + "src_sub"] = src[::4, ::4]               # full map is MBs: keep a lattice + CRC
+            store[key + "src_crc"] = zlib.crc32(src.tobytes())
+            store[key + "n_fill"] = int(fill.sum())
+            store[key + "bbox"] = np.array(bbox, dtype=np.int64)
+            store[key + "mask_rect"] = np.array([r0, r1, c0, c1])
+    save("g8_sector", **store)
+
+
+def _sector_rows(theta, h, w):
+    """T = clip(int(arc_len*H/W), 0, 900) computed by calling the reference's own arithmetic path:
+    run sector_distort on a 1-row dummy and read the dsize it requests from cv2.resize."""
+    sys.path.insert(0, REF)
+    demo = importlib.import_module("yolox.demo_featuremap")
+    got = {}
+
+    class Stop(Exception):
+        pass
+
+    def probe(img, dsize, *a, **k):
+        got["dsize"] = dsize
+        raise Stop()
+
+    keep = demo.cv2.resize
+    demo.cv2.resize = probe
+    try:
+        demo.Image_Distortion().sector_distort(np.zeros((h, w, 3), np.uint8), np.zeros((h, w, 3), np.uint8), Theta=theta)
+    except Stop:
+        pass
+    finally:
+        demo.cv2.resize = keep
+    return int(got["dsize"][1])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector"]
+    utils, models = load_reference()
+    if "geometry" in which:
+        gen_geometry(utils, models)
+    if "assign" in which:
+        gen_assign(utils, models)
+    if "model" in which:
+        gen_model(utils, models)
+    if "sector" in which:
+        gen_sector()

@@ -1,0 +1,66 @@
+"""Oracle (CPU restatement) vs golden vectors generated from the reference: circle geometry G1-G3."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from ep24 import synth
+from oracle import geometry
+
+
+def test_g1_lens_area(golden):
+    z = golden("g1_circle_inter")
+    res, dist = geometry.matched_lens(t(z["gt_cx"]), t(z["gt_cy"]), t(z["gt_r"]), t(z["pd_cx"]), t(z["pd_cy"]), t(z["pd_r"]))
+    assert torch.equal(res, t(z["res_inter"]))
+    assert torch.equal(dist, t(z["dist"]))
+    # all three branches are present in the vector
+    gt_r, pd_r, d = t(z["gt_r"]), t(z["pd_r"]), t(z["dist"])
+    contained = (gt_r - pd_r).abs() >= d
+    disjoint = d >= gt_r + pd_r
+    assert contained.any() and disjoint.any() and (~(contained | disjoint)).any()
+    e_res, e_dist = geometry.matched_lens(t(z["gt_cx"])[:0], t(z["gt_cy"])[:0], t(z["gt_r"])[:0],
+                                          t(z["pd_cx"])[:0], t(z["pd_cy"])[:0], t(z["pd_r"])[:0])
+    assert list(e_res.shape) == list(z["empty_res_shape"]) and list(e_dist.shape) == list(z["empty_dist_shape"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g2_pairwise(golden, tag):
+    z = golden("g2_pairwise_" + tag)
+    out = geometry.pairwise(t(z["a"]), t(z["b"]))
+    assert torch.equal(out, t(z["out"]))
+    assert out.min() >= 0 and out.max() <= 1.0 + 1e-6
+
+
+def test_g2_pairwise_full_size(golden):
+    z = golden("g2_pairwise_d")
+    G, P = int(z["G"]), int(z["P"])
+    a = synth.make_labels(1, G, seed=int(z["label_seed"]))[0, :G, 1:]
+    dec = synth.decode_head(synth.make_raw_head(1, seed=int(z["head_seed"])))[0]
+    idx = torch.randperm(dec.shape[0], generator=torch.Generator().manual_seed(int(z["sel_seed"])))[:P].sort().values
+    b = dec[idx, :26].contiguous()
+    assert float(a.double().sum()) == float(z["a_sum"]) and float(b.double().sum()) == float(z["b_sum"])
+    out = geometry.pairwise(a, b)
+    assert torch.equal(out[:, ::7], t(z["out_sub"]))
+    assert float(out.double().sum()) == float(z["out_sum"])
+
+
+def test_pairwise_shape_guard():
+    with pytest.raises(IndexError):
+        geometry.pairwise(torch.zeros(2, 49), torch.zeros(2, 26))
+    with pytest.raises(IndexError):
+        geometry.matched(torch.zeros(2, 25), torch.zeros(2, 50))
+
+
+def test_g3_matched_loss_and_grad(golden):
+    z = golden("g3_matched")
+    pred = t(z["pred"]).clone().requires_grad_(True)
+    loss24, draw = geometry.matched(pred, t(z["target"]))
+    assert torch.equal(loss24.detach(), t(z["loss24"]))
+    (loss24 * t(z["w"])).sum().backward()
+    want = t(z["grad"])
+    # coincident centres (d == 0) give NaN centre gradients in the reference (sqrt'(0)*0); keep that visible
+    assert torch.isnan(want).any() and torch.equal(torch.isnan(pred.grad), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(pred.grad), torch.nan_to_num(want))
+    assert torch.equal(draw[2].detach(), t(z["pred"])[:, 2:])
+    e_loss, e_draw = geometry.matched(pred[:0], t(z["target"])[:0])
+    assert torch.equal(e_loss, t(z["empty_loss"])) and list(e_draw[0].shape) == list(z["empty_draw0_shape"])
