@@ -1,0 +1,261 @@
+// ep24 - SimOTA label assignment for the 24-point head, batched over images with no host round trip.
+//
+// Reference flow per image (yolox_24p/models/losses.py:360-494): candidate masks -> boolean gathers (dynamic
+// shape P) -> [G,P] pairwise/cost matrices -> per-GT python loop of topk -> .tolist()/.item() syncs.
+// Here every stage is a dense kernel over [B, G<=50, A] with the candidate set carried as per-anchor 64-bit
+// GT bitmasks, counts stay on the device and the stages chain on one stream:
+//   candidates (a4+a5) -> cost (a6+a7) -> dynamic_k (a8, one workgroup per (image, gt)) -> resolve (a8).
+// All kernels are elementwise geometry (atan2 / acos / sin / log): no MFMA, HBM/L2 resident, GT rows in LDS.
+#include "geom.h"
+
+namespace {
+
+constexpr int G_MAX = EP24_MAX_GT;
+constexpr int LCOLS = EP24_LABEL_COLS;
+
+// rows with sum > 0 (losses.py:190); valid rows are a prefix (data_augment.py:160-174)
+__device__ int count_gt(const float* lab /*[50][51]*/, float* scratch /*[64]*/) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        float s = 0.f;
+        if (t < G_MAX)
+            for (int c = 0; c < LCOLS; ++c) s += lab[t * LCOLS + c];
+        scratch[t] = (t < G_MAX && s > 0.f) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    int n = 0;
+    for (int i = 0; i < G_MAX; ++i) n += (int)scratch[i];
+    __syncthreads();
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------ a4 + a5
+__global__ __launch_bounds__(256) void candidates_kernel(const float* labels, const float* xs, const float* ys,
+                                                         const float* strides, int* num_gt, unsigned long long* in_box,
+                                                         unsigned long long* in_ctr, int A) {
+    __shared__ float vx[G_MAX][24], vy[G_MAX][24], gcx[G_MAX], gcy[G_MAX], scratch[64];
+    const int b = blockIdx.y;
+    const float* lab = labels + (long)b * G_MAX * LCOLS;
+    const int ng = count_gt(lab, scratch);
+    for (int i = threadIdx.x; i < ng * 24; i += 256) {
+        const int g = i / 24, k = i - g * 24;
+        vx[g][k] = lab[g * LCOLS + 3 + 2 * k];
+        vy[g][k] = lab[g * LCOLS + 4 + 2 * k];
+    }
+    for (int g = threadIdx.x; g < ng; g += 256) { gcx[g] = lab[g * LCOLS + 1]; gcy[g] = lab[g * LCOLS + 2]; }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) num_gt[b] = ng;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const float s = strides[a];
+    const float xc = xs[a] * s + 0.5f * s;             // losses.py:506-516
+    const float yc = ys[a] * s + 0.5f * s;
+    const float rad = 2.5f * s;
+    unsigned long long mb = 0ull, mc = 0ull;
+    for (int g = 0; g < ng; ++g) {
+        // pts_in_poly (losses.py:555-592): unsigned angle of every edge seen from the anchor centre, degrees
+        float deg = 0.f;
+        float sx = vx[g][0] - xc, sy = vy[g][0] - yc;
+        for (int k = 0; k < 24; ++k) {
+            const int k1 = k == 23 ? 0 : k + 1;
+            const float ex = vx[g][k1] - xc, ey = vy[g][k1] - yc;
+            const float cross = sx * ey - ex * sy;
+            const float dot = sx * ex + sy * ey;
+            deg += atan2f(fabsf(cross), dot) * 57.2957795130823208768f;
+            sx = ex; sy = ey;
+        }
+        if (deg >= 350.f) mb |= 1ull << g;
+        // centre square (losses.py:523-543): min of the four deltas strictly positive
+        const float cl = xc - (gcx[g] - rad), cr = (gcx[g] + rad) - xc;
+        const float ct = yc - (gcy[g] - rad), cb = (gcy[g] + rad) - yc;
+        if (fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f) mc |= 1ull << g;
+    }
+    in_box[(long)b * A + a] = mb;
+    in_ctr[(long)b * A + a] = mc;
+}
+
+// ------------------------------------------------------------------------------------------ a6 + a7
+__global__ __launch_bounds__(128) void cost_kernel(const float* outputs, int ncols, const float* labels,
+                                                   const int* num_gt, const unsigned long long* in_box,
+                                                   const unsigned long long* in_ctr, float* pw, float* cost, int A, int C) {
+    __shared__ float gr[G_MAX][24], gcx[G_MAX], gcy[G_MAX];
+    __shared__ float spr[24][128];                                  // this thread's 24 predicted radii, k-major
+    __shared__ int gcls[G_MAX];
+    const int b = blockIdx.y;
+    const int ng = num_gt[b];
+    const float* lab = labels + (long)b * G_MAX * LCOLS;
+    for (int i = threadIdx.x; i < ng * 24; i += 128) {
+        const int g = i / 24, k = i - g * 24;
+        const float dx = lab[g * LCOLS + 3 + 2 * k] - lab[g * LCOLS + 1];
+        const float dy = lab[g * LCOLS + 4 + 2 * k] - lab[g * LCOLS + 2];
+        gr[g][k] = sqrtf(dx * dx + dy * dy);                      // torch.norm over (x,y) (boxes.py:189-197)
+    }
+    for (int g = threadIdx.x; g < ng; g += 128) {
+        gcx[g] = lab[g * LCOLS + 1]; gcy[g] = lab[g * LCOLS + 2]; gcls[g] = (int)lab[g * LCOLS];
+    }
+    __syncthreads();
+    const int a = blockIdx.x * 128 + threadIdx.x;
+    if (a >= A) return;
+    const unsigned long long mb = in_box[(long)b * A + a], mc = in_ctr[(long)b * A + a];
+    if ((mb | mc) == 0ull) return;                                  // not a candidate (fg_mask false)
+    const float* o = outputs + ((long)b * A + a) * ncols;
+    for (int k = 0; k < 24; ++k) spr[k][threadIdx.x] = o[2 + k];
+    const float pcx = o[0], pcy = o[1];
+    const float so = 1.0f / (1.0f + expf(-o[26]));
+    // sum over classes of the "target 0" BCE term: -max(log1p(-p), -100), p = sqrt(sigmoid(cls)*sigmoid(obj))
+    float s0 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + c]))) * so);
+        s0 += -fmaxf(log1pf(-p), -100.f);
+    }
+    for (int g = 0; g < ng; ++g) {
+        const float ddx = gcx[g] - pcx, ddy = gcy[g] - pcy;
+        const float d = sqrtf(ddx * ddx + ddy * ddy);
+        float acc = 0.f;
+        for (int k = 0; k < 24; ++k) acc += 1.0f - ray_giou(gr[g][k], spr[k][threadIdx.x], d);
+        const float v = acc / 24.0f / 2.0f;                        // boxes.py:238-241
+        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + gcls[g]]))) * so);
+        const float cls_cost = s0 - (-fmaxf(log1pf(-p), -100.f)) + (-fmaxf(logf(p), -100.f));
+        const bool both = ((mb & mc) >> g) & 1ull;
+        const float cst = cls_cost + 3.0f * (-logf(v + 1e-8f)) + 100000.0f * (both ? 0.0f : 1.0f);   // losses.py:420-424
+        const long idx = ((long)b * G_MAX + g) * A + a;
+        pw[idx] = v;
+        cost[idx] = cst;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ a8 part 1
+// block-wide arg-best over (value, index): larger value wins when LARGEST, ties -> smaller index
+template <bool LARGEST>
+__device__ void block_best(float& v, int& i, float* sv, int* si) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        const bool take = oi >= 0 && (i < 0 || (LARGEST ? ov > v : ov < v) || (ov == v && oi < i));
+        if (take) { v = ov; i = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = v; si[w] = i; }
+    __syncthreads();
+    v = sv[0]; i = si[0];
+    for (int k = 1; k < 4; ++k) {
+        const bool take = si[k] >= 0 && (i < 0 || (LARGEST ? sv[k] > v : sv[k] < v) || (sv[k] == v && si[k] < i));
+        if (take) { v = sv[k]; i = si[k]; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const float* cost, const int* num_gt,
+                                                        const unsigned long long* in_box, const unsigned long long* in_ctr,
+                                                        unsigned long long* match, int* ks, int A) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.y, g = blockIdx.x;
+    if (g >= num_gt[b]) return;                                     // uniform per block
+    const float* pwr = pw + ((long)b * G_MAX + g) * A;
+    const float* cr = cost + ((long)b * G_MAX + g) * A;
+    const unsigned long long* mb = in_box + (long)b * A;
+    const unsigned long long* mc = in_ctr + (long)b * A;
+    // top-min(10,P) largest pairwise values, summed in descending order (losses.py:452-456)
+    float prev_v = INFINITY; int prev_i = -1;
+    float total = 0.f;
+    for (int r = 0; r < 10; ++r) {
+        float bv = -INFINITY; int bi = -1;
+        for (int a = threadIdx.x; a < A; a += 256) {
+            if ((mb[a] | mc[a]) == 0ull) continue;
+            const float v = pwr[a];
+            const bool after = v < prev_v || (v == prev_v && a > prev_i);
+            if (after && (bi < 0 || v > bv)) { bv = v; bi = a; }     // ascending a: first hit keeps the smaller index
+        }
+        block_best<true>(bv, bi, sv, si);
+        if (bi < 0) break;                                          // fewer than 10 candidates
+        total += bv;
+        prev_v = bv; prev_i = bi;
+    }
+    int k = (int)total;                                             // .int() truncates
+    if (k < 1) k = 1;
+    if (threadIdx.x == 0) ks[b * G_MAX + g] = k;
+    // k cheapest candidates (torch.topk(largest=False)); ties -> lower anchor index
+    prev_v = -INFINITY; prev_i = -1;
+    for (int r = 0; r < k; ++r) {
+        float bv = INFINITY; int bi = -1;
+        for (int a = threadIdx.x; a < A; a += 256) {
+            if ((mb[a] | mc[a]) == 0ull) continue;
+            const float v = cr[a];
+            const bool after = v > prev_v || (v == prev_v && a > prev_i);
+            if (after && (bi < 0 || v < bv)) { bv = v; bi = a; }
+        }
+        block_best<false>(bv, bi, sv, si);
+        if (bi < 0) break;
+        if (threadIdx.x == 0) atomicOr(match + (long)b * A + bi, 1ull << g);
+        prev_v = bv; prev_i = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ a8 part 2
+__global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* match, const float* pw, const float* cost,
+                                                      const int* num_gt, int* matched_gt, float* matched_iou, int A) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const unsigned long long m = match[(long)b * A + a];
+    int g = -1;
+    float v = 0.f;
+    if (m) {
+        if (__popcll(m) == 1) {
+            g = __ffsll((long long)m) - 1;
+        } else {                                                    // losses.py:473-476: argmin over ALL gts
+            const int ng = num_gt[b];
+            float best = INFINITY;
+            for (int q = 0; q < ng; ++q) {
+                const float c = cost[((long)b * G_MAX + q) * A + a];
+                if (c < best) { best = c; g = q; }
+            }
+        }
+        v = pw[((long)b * G_MAX + g) * A + a];
+    }
+    matched_gt[(long)b * A + a] = g;
+    matched_iou[(long)b * A + a] = v;
+}
+
+}  // namespace
+
+extern "C" int ep24_assign_candidates(const float* labels, const float* xs, const float* ys, const float* strides,
+                                      int32_t* num_gt, uint64_t* in_box, uint64_t* in_ctr, int B, int A, void* stream) {
+    EP24_REQUIRE(labels && xs && ys && strides && num_gt && in_box && in_ctr && B > 0 && A > 0, EP24_E_ARG,
+                 "assign_candidates: bad arguments");
+    hipLaunchKernelGGL(candidates_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, labels, xs, ys, strides,
+                       num_gt, (unsigned long long*)in_box, (unsigned long long*)in_ctr, A);
+    EP24_LAUNCH_CHECK("ep24_assign_candidates");
+    return EP24_OK;
+}
+
+extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
+                                const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
+                                int num_classes, void* stream) {
+    EP24_REQUIRE(outputs && labels && num_gt && in_box && in_ctr && pw && cost, EP24_E_ARG, "assign_cost: null pointer");
+    EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "assign_cost: ncols=%d != 27+%d", ncols, num_classes);
+    hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(A, 128), B), dim3(128), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
+                       (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, pw, cost, A, num_classes);
+    EP24_LAUNCH_CHECK("ep24_assign_cost");
+    return EP24_OK;
+}
+
+extern "C" int ep24_dynamic_k(const float* pw, const float* cost, const int32_t* num_gt, const uint64_t* in_box,
+                              const uint64_t* in_ctr, uint64_t* match, int32_t* ks, int B, int A, void* stream) {
+    EP24_REQUIRE(pw && cost && num_gt && in_box && in_ctr && match && ks, EP24_E_ARG, "dynamic_k: null pointer");
+    hipLaunchKernelGGL(dynamic_k_kernel, dim3(G_MAX, B), dim3(256), 0, (hipStream_t)stream, pw, cost, num_gt,
+                       (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, (unsigned long long*)match, ks, A);
+    EP24_LAUNCH_CHECK("ep24_dynamic_k");
+    return EP24_OK;
+}
+
+extern "C" int ep24_assign_resolve(const uint64_t* match, const float* pw, const float* cost, const int32_t* num_gt,
+                                   int32_t* matched_gt, float* matched_iou, int B, int A, void* stream) {
+    EP24_REQUIRE(match && pw && cost && num_gt && matched_gt && matched_iou, EP24_E_ARG, "assign_resolve: null pointer");
+    hipLaunchKernelGGL(resolve_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)match, pw, cost, num_gt, matched_gt, matched_iou, A);
+    EP24_LAUNCH_CHECK("ep24_assign_resolve");
+    return EP24_OK;
+}

@@ -1,0 +1,52 @@
+// ep24 - shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ep24.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define EP24_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------------
+void ep24_set_error(const char* fmt, ...);
+
+#define EP24_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            ep24_set_error(__VA_ARGS__);         \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+// never synchronises the stream: only picks up launch-time errors
+#define EP24_LAUNCH_CHECK(name)                                                        \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            ep24_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return EP24_E_LAUNCH;                                                      \
+        }                                                                              \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+static inline int ep24_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

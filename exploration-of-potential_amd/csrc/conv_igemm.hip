@@ -1,0 +1,313 @@
+// ep24 - bf16 implicit-GEMM convolution on CDNA4 MFMA (forward and input-gradient).
+//
+//   D[m][n] = sum_t sum_k  S[pix(m) + off(t)][k] * Wt[n][slot(t)][k]
+//
+// m runs over a pixel grid [B,GH,GW]; S is an NHWC bf16 tensor with row stride ld_src; taps t carry a
+// spatial offset and a weight slot.  Forward conv, stride-1 dgrad and the four parity classes of a stride-2
+// dgrad are all instances of this one gather-GEMM (host wrappers at the bottom build the tap tables).
+//
+// Tiling: 128 x BN x 64 per workgroup of 4 waves (64-lane), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// Global -> registers -> LDS (register staging, the gather needs per-lane addresses and zero fill);
+// LDS rows are 128 B (64 bf16) with the 16-B chunk index XOR-ed by (row & 7): ds_write_b128 of one row by 8
+// lanes and ds_read_b128 of 16 rows x {chunk c, c+1} by a wave are both bank-conflict free.
+// Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel
+// 4j+t) so every lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+    const bf16* src; long ld_src; int B, SH, SW;
+    int GH, GW, sy, sx;
+    int T; int oy[16]; int ox[16]; int wslot[16];
+    const bf16* wt; int WT; int K; int N;
+    void* dst; long ld_dst; int DH, DW, dsy, dsx, dy0, dx0; long dbs, dp0;   // dst pixel = n*dbs + dp0 + (gy*dsy+dy0)*DW + gx*dsx+dx0
+    int accumulate;
+    const float* bias;
+    float* stats; int stats_replicas;
+    long M;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <int BN, bool OUT_F32>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    constexpr int WN = BN / 64;            // waves along N
+    constexpr int WM = 4 / WN;             // waves along M
+    constexpr int MT = BM / WM / 16;       // 16-row tiles per wave (4 or 2)
+    constexpr int NT = 4;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int B_PIECES = BN * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto lds_a = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES); };
+    auto lds_b = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-thread gather bookkeeping: 4 A rows (tid>>3)+32i, chunk tid&7
+    const int chunk = tid & 7;
+    const int lrow = tid >> 3;
+    int pixbase[4], iy0[4], ix0[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long m = m0 + lrow + 32 * i;
+        rvalid[i] = m < p.M;
+        long mm = rvalid[i] ? m : 0;
+        int n = (int)(mm / (p.GH * p.GW));
+        int rem = (int)(mm - (long)n * (p.GH * p.GW));
+        int gy = rem / p.GW, gx = rem - gy * p.GW;
+        pixbase[i] = n * p.SH * p.SW;
+        iy0[i] = gy * p.sy;
+        ix0[i] = gx * p.sx;
+    }
+    // B rows: weight row n -> LDS row (relabelled inside each 64 span)
+    int brow_g[B_PIECES], brow_l[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        int r = lrow + 32 * i;                       // 0..BN-1 : logical channel inside the tile
+        brow_g[i] = n0 + r;
+        brow_l[i] = (r & ~63) + ((r & 3) << 4) + ((r >> 2) & 15);
+    }
+
+    const int KC = p.K / BK;
+    const int n_iter = p.T * KC;
+    bf16x8 ra[4], rb[B_PIECES];
+
+    auto load_tile = [&](int it) {
+        const int t = it / KC;
+        const int kc = it - t * KC;
+        const int oy = p.oy[t], ox = p.ox[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int iy = iy0[i] + oy, ix = ix0[i] + ox;
+            bool ok = rvalid[i] && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) {
+                const bf16* s = p.src + ((long)(pixbase[i] + iy * p.SW + ix)) * p.ld_src + kc * BK + chunk * 8;
+                v = *reinterpret_cast<const bf16x8*>(s);
+            }
+            ra[i] = v;
+        }
+        const long wtap = (long)p.wslot[t] * p.K + kc * BK + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<bf16x8*>(lds_a(buf) + swz(lrow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            *reinterpret_cast<bf16x8*>(lds_b(buf) + swz(brow_l[i], chunk)) = rb[i];
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;      // row inside a 16-row tile (A: pixel, B: relabelled channel)
+    const int fq = lane >> 4;        // k-chunk inside a 32-deep k-step
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < n_iter;
+        if (more) load_tile(it + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(lds_a(cur) + swz(wm * (MT * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(lds_b(cur) + swz(wn * 64 + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  lane owns channels c0..c0+3 (n-tiles 0..3) of pixels 4*fq + r of every m-tile
+    const int c0 = n0 + wn * 64 + 4 * frow;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
+                           p.dbs == (long)p.GH * p.GW);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
+            if (m >= p.M) continue;
+            long dpix = m;
+            if (!fast_dst) {
+                int n = (int)(m / (p.GH * p.GW));
+                int rem = (int)(m - (long)n * (p.GH * p.GW));
+                int gy = rem / p.GW, gx = rem - gy * p.GW;
+                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[i][j][r] + bias4[j];
+                s1[j] += v[j];
+                s2[j] += v[j] * v[j];
+            }
+            if constexpr (OUT_F32) {
+                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < p.N) d[j] = p.accumulate ? d[j] + v[j] : v[j];
+            } else {
+                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
+                if (c0 + 3 < p.N) {
+                    if (p.accumulate) {
+                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)o[j];
+                    }
+                    bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (bf16)v[j];
+                    *reinterpret_cast<bf16x4*>(d) = w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < p.N) d[j] = (bf16)(p.accumulate ? (float)d[j] + v[j] : v[j]);
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // rows >= M contributed nothing (skipped above); reduce the 4 lane groups that share a channel
+        float* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (fq == 0 && c0 + j < p.N) {
+                atomicAdd(st + c0 + j, a);
+                atomicAdd(st + p.N + c0 + j, b);
+            }
+        }
+    }
+}
+
+int launch(const IgemmArgs& a, bool out_f32, hipStream_t stream) {
+    const bool wide = a.N > 64;
+    dim3 grid(ep24_cdiv(a.M, BM), ep24_cdiv(a.N, wide ? 128 : 64));
+    size_t lds = 2 * (BM * 128 + (wide ? 128 : 64) * 128);
+    if (wide) {
+        if (out_f32) hipLaunchKernelGGL((igemm_kernel<128, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((igemm_kernel<128, false>), grid, dim3(256), lds, stream, a);
+    } else {
+        if (out_f32) hipLaunchKernelGGL((igemm_kernel<64, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((igemm_kernel<64, false>), grid, dim3(256), lds, stream, a);
+    }
+    EP24_LAUNCH_CHECK("ep24_conv_igemm");
+    return EP24_OK;
+}
+
+}  // namespace
+
+extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                                  int64_t y_batch_rows, int64_t y_row0, const float* bias, float* stats,
+                                  int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                  void* stream) {
+    EP24_REQUIRE(x && w && y, EP24_E_ARG, "conv_fwd: null pointer");
+    EP24_REQUIRE(Cin % 64 == 0 && Cin > 0, EP24_E_ARG, "conv_fwd: Cin=%d must be a multiple of 64", Cin);
+    EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
+                 "conv_fwd: k=%d s=%d unsupported", ksize, stride);
+    EP24_REQUIRE(ld_x % 8 == 0 && (y_f32 || ld_y % 4 == 0), EP24_E_ARG, "conv_fwd: ld_x %% 8 / ld_y %% 4 alignment");
+    EP24_REQUIRE(!stats || stats_replicas > 0, EP24_E_ARG, "conv_fwd: stats_replicas");
+    const int pad = (ksize - 1) / 2;
+    const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+    IgemmArgs a{};
+    a.src = (const bf16*)x; a.ld_src = ld_x; a.B = B; a.SH = H; a.SW = W;
+    a.GH = OH; a.GW = OW; a.sy = stride; a.sx = stride;
+    a.T = ksize * ksize;
+    for (int t = 0; t < a.T; ++t) { a.oy[t] = t / ksize - pad; a.ox[t] = t % ksize - pad; a.wslot[t] = t; }
+    a.wt = (const bf16*)w; a.WT = a.T; a.K = Cin; a.N = Cout;
+    a.dst = y; a.ld_dst = ld_y; a.DH = OH; a.DW = OW; a.dsy = a.dsx = 1; a.dy0 = a.dx0 = 0;
+    a.dbs = y_batch_rows > 0 ? y_batch_rows : (long)OH * OW; a.dp0 = y_row0;
+    a.accumulate = 0; a.bias = bias; a.stats = stats; a.stats_replicas = stats ? stats_replicas : 1;
+    a.M = (long)B * OH * OW;
+    return launch(a, y_f32 != 0, (hipStream_t)stream);
+}
+
+extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
+                                    int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                                    void* stream) {
+    EP24_REQUIRE(dy && wt && dx, EP24_E_ARG, "conv_dgrad: null pointer");
+    EP24_REQUIRE(Cout_k % 64 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 64", Cout_k);
+    EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
+                 "conv_dgrad: k=%d s=%d unsupported", ksize, stride);
+    EP24_REQUIRE(ld_dy % 8 == 0 && ld_dx % 4 == 0, EP24_E_ARG, "conv_dgrad: ld alignment");
+    const int pad = (ksize - 1) / 2;
+    const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+    IgemmArgs a{};
+    a.src = (const bf16*)dy; a.ld_src = ld_dy; a.B = B; a.SH = OH; a.SW = OW;
+    a.wt = (const bf16*)wt; a.WT = ksize * ksize; a.K = Cout_k; a.N = Cin;
+    a.dst = dx; a.ld_dst = ld_dx; a.DH = H; a.DW = W; a.dbs = (long)H * W; a.dp0 = 0;
+    a.accumulate = accumulate; a.bias = nullptr; a.stats = nullptr; a.stats_replicas = 1;
+    if (stride == 1) {
+        // dx[y,x] = sum_{kh,kw} dy[y + pad - kh, x + pad - kw] . w[:,kh,kw,:]
+        a.GH = H; a.GW = W; a.sy = a.sx = 1;
+        a.T = ksize * ksize;
+        for (int t = 0; t < a.T; ++t) { a.oy[t] = pad - t / ksize; a.ox[t] = pad - t % ksize; a.wslot[t] = t; }
+        a.dsy = a.dsx = 1; a.dy0 = a.dx0 = 0;
+        a.M = (long)B * H * W;
+        return launch(a, false, (hipStream_t)stream);
+    }
+    // stride 2: input pixels of parity (ph,pw) only see taps with (p + pad - k) even; one launch per class
+    EP24_REQUIRE(H % 2 == 0 && W % 2 == 0, EP24_E_UNSUPPORTED, "conv_dgrad s2: odd spatial size %dx%d", H, W);
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            IgemmArgs c = a;
+            c.GH = H / 2; c.GW = W / 2; c.sy = c.sx = 1;
+            c.dsy = c.dsx = 2; c.dy0 = ph; c.dx0 = pw;
+            c.T = 0;
+            for (int kh = 0; kh < ksize; ++kh)
+                for (int kw = 0; kw < ksize; ++kw) {
+                    if (((ph + pad - kh) & 1) || ((pw + pad - kw) & 1)) continue;
+                    // oh = (2*gy + ph + pad - kh)/2 = gy + (ph + pad - kh)/2  (exact: numerator even)
+                    c.oy[c.T] = (ph + pad - kh) / 2; c.ox[c.T] = (pw + pad - kw) / 2; c.wslot[c.T] = kh * ksize + kw;
+                    ++c.T;
+                }
+            c.M = (long)B * c.GH * c.GW;
+            if (c.T == 0) continue;   // (k=1, odd parity): nothing reaches these pixels; caller zero-fills via accumulate=0 path below
+            int rc = launch(c, false, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return EP24_OK;
+}

@@ -1,0 +1,639 @@
+// ep24 - HBM-bound glue kernels of the conv graph: BN(train)+SiLU forward/backward, stem packing, SPP pools,
+// nearest upsample, head decode, bias sums, SGD.  All are streaming kernels: 16-byte (8 x bf16) accesses per
+// lane, consecutive lanes on consecutive addresses, grid capped and row-strided.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by rows_per_pass
+    int tpr, rpb;      // threads per row, rows per block
+    __device__ RowMap(int C) { tpr = C >> 3; rpb = tpr >= 256 ? 1 : 256 / tpr; }
+};
+
+// ---------------------------------------------------------------------------------------- BN + act forward
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const float* stats, int reps,
+                                                         const float* gamma, const float* beta, float* rmean,
+                                                         float* rvar, long* nbt, float* save, bf16* y, long ld_y,
+                                                         const bf16* res, long ld_res, long M, int C, float eps,
+                                                         float momentum, int act) {
+    const RowMap rm(C);
+    const int tid = threadIdx.x;
+    for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048
+        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
+        if (slot >= rm.rpb) break;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < reps; ++r) {
+                s1 += stats[(long)r * 2 * C + c];
+                s2 += stats[(long)r * 2 * C + C + c];
+            }
+            const float mean = s1 / (float)M;
+            float var = s2 / (float)M - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float invstd = rsqrtf(var + eps);
+            sc[j] = gamma[c] * invstd;
+            sh[j] = beta[c] - mean * sc[j];
+            if (blockIdx.x == 0 && slot == 0) {
+                save[c] = mean;
+                save[C + c] = invstd;
+                if (rmean) {
+                    const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+                    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+                    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+                }
+            }
+        }
+        if (blockIdx.x == 0 && slot == 0 && cg == 0 && nbt) *nbt += 1;
+        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
+            float v[8];
+            load8(z + m * ld_z + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = v[j] * sc[j] + sh[j];
+                v[j] = act ? u * sigmoidf_(u) : u;
+            }
+            if (res) {
+                float r[8];
+                load8(res + m * ld_res + cg * 8, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += r[j];
+            }
+            store8(y + m * ld_y + cg * 8, v);
+        }
+    }
+}
+
+// du = dy * act'(u), u = (z-mean)*invstd*gamma + beta
+__device__ __forceinline__ void du_zhat(const float (&dy)[8], const float (&z)[8], const float* mean, const float* invstd,
+                                        const float* g, const float* b, int act, float (&du)[8], float (&zh)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        zh[j] = (z[j] - mean[j]) * invstd[j];
+        const float u = zh[j] * g[j] + b[j];
+        if (act) {
+            const float s = sigmoidf_(u);
+            du[j] = dy[j] * (s * (1.f + u * (1.f - s)));
+        } else {
+            du[j] = dy[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                                const float* save, const float* gamma,
+                                                                const float* beta, float* dgamma, float* dbeta, long M,
+                                                                int C, int act) {
+    __shared__ float red[2][256][8 + 1];
+    const RowMap rm(C);
+    const int tid = threadIdx.x;
+    for (int cg0 = 0; cg0 < (C >> 3); cg0 += 256) {
+        const int cg = cg0 + tid % rm.tpr;
+        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
+        const bool active = slot < rm.rpb && cg < (C >> 3);
+        float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            float mean[8], inv[8], g[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cg * 8 + j;
+                mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
+            }
+            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
+                float vdy[8], vz[8], du[8], zh[8];
+                load8(dy + m * ld_dy + cg * 8, vdy);
+                load8(z + m * ld_z + cg * 8, vz);
+                du_zhat(vdy, vz, mean, inv, g, b, act, du, zh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sb[j] += du[j]; sg[j] += du[j] * zh[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][tid][j] = sg[j]; red[1][tid][j] = sb[j]; }
+        __syncthreads();
+        // threads of row slot 0 fold the other slots (fixed order) and publish
+        if (active && slot == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = 0.f, b2 = 0.f;
+                for (int s = 0; s < rm.rpb; ++s) { a += red[0][s * rm.tpr + (tid % rm.tpr)][j]; b2 += red[1][s * rm.tpr + (tid % rm.tpr)][j]; }
+                atomicAdd(dgamma + cg * 8 + j, a);
+                atomicAdd(dbeta + cg * 8 + j, b2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                               const float* save, const float* gamma, const float* beta,
+                                                               const float* dgamma, const float* dbeta, bf16* dz,
+                                                               long ld_dz, long M, int C, int act) {
+    const RowMap rm(C);
+    const int tid = threadIdx.x;
+    const float invM = 1.f / (float)M;
+    for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {
+        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
+        if (slot >= rm.rpb) break;
+        float mean[8], inv[8], g[8], b[8], mg[8], mb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
+            mg[j] = dgamma[c] * invM; mb[j] = dbeta[c] * invM;
+        }
+        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
+            float vdy[8], vz[8], du[8], zh[8], o[8];
+            load8(dy + m * ld_dy + cg * 8, vdy);
+            load8(z + m * ld_z + cg * 8, vz);
+            du_zhat(vdy, vz, mean, inv, g, b, act, du, zh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = g[j] * inv[j] * (du[j] - mb[j] - zh[j] * mg[j]);
+            store8(dz + m * ld_dz + cg * 8, o);
+        }
+    }
+}
+
+int row_grid(long M, int C) {
+    int tpr = C >> 3;
+    int rpb = tpr >= 256 ? 1 : 256 / tpr;
+    long blocks = (M + rpb - 1) / rpb;
+    return (int)(blocks < MAX_BLOCKS ? (blocks < 1 ? 1 : blocks) : MAX_BLOCKS);
+}
+
+// ---------------------------------------------------------------------------------------- stem packing
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* rows, int B, int S) {
+    const int F = S >> 1;
+    const long total = (long)B * F * F * 16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i & 15);
+        const long pix = i >> 4;
+        const int n = (int)(pix / (F * F));
+        const int rem = (int)(pix - (long)n * F * F);
+        const int oy = rem / F, ox = rem - oy * F;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = chunk * 8 + j;
+            float v = 0.f;
+            if (col < 108) {
+                const int tap = col / 12, c12 = col - tap * 12;
+                const int patch = c12 / 3, ch = c12 - patch * 3;      // patch order TL, BL, TR, BR
+                const int fy = oy + tap / 3 - 1, fx = ox + tap % 3 - 1;
+                if (fy >= 0 && fy < F && fx >= 0 && fx < F) {
+                    const int y = 2 * fy + (patch & 1), x = 2 * fx + (patch >> 1);
+                    v = img[(((long)n * 3 + ch) * S + y) * S + x];
+                }
+            }
+            o[j] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(rows + pix * 128 + chunk * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- SPP pools
+__global__ __launch_bounds__(256) void spp_fwd_kernel(const bf16* x, long ld_x, bf16* y5, bf16* y9, bf16* y13, long ld_y,
+                                                      uint8_t* idx, int B, int H, int W, int C) {
+    const int cgs = C >> 3;
+    const long total = (long)B * H * W * cgs;
+    const long plane = (long)B * H * W * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / (H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int py = rem / W, px = rem - py * W;
+        float m5[8], m9[8], m13[8];
+        uint8_t i5[8], i9[8], i13[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m5[j] = m9[j] = m13[j] = -INFINITY; i5[j] = i9[j] = i13[j] = 0x88; }
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = py + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = px + dx;
+                if (xx < 0 || xx >= W) continue;
+                float v[8];
+                load8(x + ((long)(n * H + yy) * W + xx) * ld_x + cg * 8, v);
+                const uint8_t code = (uint8_t)(((dy + 8) << 4) | (dx + 8));
+                const bool in9 = dy >= -4 && dy <= 4 && dx >= -4 && dx <= 4;
+                const bool in5 = dy >= -2 && dy <= 2 && dx >= -2 && dx <= 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (v[j] > m13[j] || v[j] != v[j]) { m13[j] = v[j]; i13[j] = code; }
+                    if (in9 && (v[j] > m9[j] || v[j] != v[j])) { m9[j] = v[j]; i9[j] = code; }
+                    if (in5 && (v[j] > m5[j] || v[j] != v[j])) { m5[j] = v[j]; i5[j] = code; }
+                }
+            }
+        }
+        store8(y5 + pix * ld_y + cg * 8, m5);
+        store8(y9 + pix * ld_y + cg * 8, m9);
+        store8(y13 + pix * ld_y + cg * 8, m13);
+        uint8_t* ip = idx + pix * C + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ip[j] = i5[j]; ip[plane + j] = i9[j]; ip[2 * plane + j] = i13[j]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void spp_bwd_kernel(const bf16* dy5, const bf16* dy9, const bf16* dy13, long ld_dy,
+                                                      const uint8_t* idx, bf16* dx, long ld_dx, int accumulate, int B,
+                                                      int H, int W, int C) {
+    const int cgs = C >> 3;
+    const long total = (long)B * H * W * cgs;
+    const long plane = (long)B * H * W * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / (H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int py = rem / W, px = rem - py * W;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // output pixel o = this - (dy,dx) selected this pixel iff its stored offset equals (dy,dx)
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int oy = py - dy;
+            if (oy < 0 || oy >= H) continue;
+            for (int dxo = -6; dxo <= 6; ++dxo) {
+                const int ox = px - dxo;
+                if (ox < 0 || ox >= W) continue;
+                const long op = (long)(n * H + oy) * W + ox;
+                const uint8_t code = (uint8_t)(((dy + 8) << 4) | (dxo + 8));
+                const uint8_t* ip = idx + op * C + cg * 8;
+                float g13[8];
+                load8(dy13 + op * ld_dy + cg * 8, g13);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (ip[2 * plane + j] == code) acc[j] += g13[j];
+                if (dy >= -4 && dy <= 4 && dxo >= -4 && dxo <= 4) {
+                    float g9[8];
+                    load8(dy9 + op * ld_dy + cg * 8, g9);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ip[plane + j] == code) acc[j] += g9[j];
+                }
+                if (dy >= -2 && dy <= 2 && dxo >= -2 && dxo <= 2) {
+                    float g5[8];
+                    load8(dy5 + op * ld_dy + cg * 8, g5);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ip[j] == code) acc[j] += g5[j];
+                }
+            }
+        }
+        bf16* d = dx + pix * ld_dx + cg * 8;
+        if (accumulate) {
+            float o[8];
+            load8(d, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += o[j];
+        }
+        store8(d, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- upsample / copy
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const bf16* x, long ld_x, bf16* y, long ld_y, int B, int H,
+                                                            int W, int C) {
+    const int cgs = C >> 3;
+    const long total = (long)B * 2 * H * 2 * W * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long opix = i / cgs;
+        const int n = (int)(opix / (4 * H * W));
+        const int rem = (int)(opix - (long)n * 4 * H * W);
+        const int oy = rem / (2 * W), ox = rem - oy * 2 * W;
+        const long ip = (long)(n * H + (oy >> 1)) * W + (ox >> 1);
+        *reinterpret_cast<bf16x8*>(y + opix * ld_y + cg * 8) = *reinterpret_cast<const bf16x8*>(x + ip * ld_x + cg * 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const bf16* dy, long ld_dy, bf16* dx, long ld_dx,
+                                                            int accumulate, int B, int H, int W, int C) {
+    const int cgs = C >> 3;
+    const long total = (long)B * H * W * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / (H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int py = rem / W, px = rem - py * W;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float v[8];
+                load8(dy + ((long)(n * 2 * H + 2 * py + a) * 2 * W + 2 * px + b) * ld_dy + cg * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        bf16* d = dx + pix * ld_dx + cg * 8;
+        if (accumulate) {
+            float o[8];
+            load8(d, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += o[j];
+        }
+        store8(d, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_copy_kernel(const bf16* src, long ld_src, bf16* dst, long ld_dst,
+                                                        int accumulate, long M, int C) {
+    const int cgs = C >> 3;
+    const long total = M * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long m = i / cgs;
+        float v[8];
+        load8(src + m * ld_src + cg * 8, v);
+        bf16* d = dst + m * ld_dst + cg * 8;
+        if (accumulate) {
+            float o[8];
+            load8(d, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        store8(d, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- head decode
+__global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int A, int a0, int H, int W, float s,
+                                                         int ncols) {
+    const long total = (long)B * H * W * 26;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % 26);
+        const long cell = i / 26;
+        const int n = (int)(cell / (H * W));
+        const int hw = (int)(cell - (long)n * H * W);
+        float* p = out + ((long)n * A + a0 + hw) * ncols + c;
+        const float t = *p;
+        float v;
+        if (c == 0) v = (t + (float)(hw % W)) * s;
+        else if (c == 1) v = (t + (float)(hw / W)) * s;
+        else v = expf(t) * s;
+        *p = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_bwd_kernel(const float* dout, const float* out, bf16* d_regobj, bf16* d_cls,
+                                                         int B, int A, int a0, int H, int W, float s, int ncols) {
+    // one thread per (cell, 8-column chunk) of the 64 + 128 padded gradient columns
+    const long total = (long)B * H * W * 24;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % 24);
+        const long cell = i / 24;
+        const int n = (int)(cell / (H * W));
+        const int hw = (int)(cell - (long)n * H * W);
+        const long row = ((long)n * A + a0 + hw) * ncols;
+        bf16x8 o;
+        if (chunk < 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = chunk * 8 + j;
+                float g = 0.f;
+                if (c < 2) g = dout[row + c] * s;
+                else if (c < 26) g = dout[row + c] * out[row + c];      // d exp(t)*s / dt = r
+                else if (c == 26) g = dout[row + 26];
+                o[j] = (bf16)g;
+            }
+            *reinterpret_cast<bf16x8*>(d_regobj + cell * 64 + chunk * 8) = o;
+        } else {
+            const int k = chunk - 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = k * 8 + j;
+                o[j] = (bf16)((27 + c < ncols) ? dout[row + 27 + c] : 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(d_cls + cell * 128 + k * 8) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* g, long ld, float* db, long M, int N) {
+    // block = 256 threads = 4 row lanes x 64 columns (N <= 128 handled in two column passes)
+    __shared__ float red[256];
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int c = c0 + (threadIdx.x & 63);
+        float acc = 0.f;
+        if (c < N)
+            for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) acc += (float)g[m * ld + c];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64 && c < N) atomicAdd(db + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------- weights / SGD
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, long ld_w, bf16* wf, bf16* wd, int Cout, int T,
+                                                           int Cin, int Cin_pad, int Cout_pad) {
+    // only real elements are written: padding columns are zeroed once at allocation and never touched
+    const long total = (long)Cout * T * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        const long r = i / Cin;
+        const int t = (int)(r % T);
+        const int co = (int)(r / T);
+        const bf16 v = (bf16)w[(long)co * ld_w + (long)t * Cin + ci];
+        if (wf) wf[((long)co * T + t) * Cin_pad + ci] = v;
+        if (wd) wd[((long)ci * T + t) * Cout_pad + co] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float mom,
+                                                  float gscale, const int* first_flag) {
+    const int first = *first_flag;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+            f32x4 bv = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(buf + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gg = gv[j] * gscale;
+                bv[j] = first ? gg : mom * bv[j] + gg;
+                pv[j] -= lr * (gg + mom * bv[j]);
+            }
+            *reinterpret_cast<f32x4*>(buf + i) = bv;
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+        } else {
+            for (long k = i; k < n; ++k) {
+                const float gg = g[k] * gscale;
+                const float b = first ? gg : mom * buf[k] + gg;
+                buf[k] = b;
+                p[k] -= lr * (gg + mom * b);
+            }
+        }
+    }
+}
+__global__ void clear_flag_kernel(int* f) { *f = 0; }
+
+int cap_grid(long work_items) {
+    long b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+
+}  // namespace
+
+#define S_ (hipStream_t) stream
+
+extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, int reps, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                               float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res, int64_t M, int C,
+                               float eps, float momentum, int act, void* stream) {
+    EP24_REQUIRE(z && stats && gamma && beta && save && y, EP24_E_ARG, "bn_act_fwd: null pointer");
+    EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
+                 "bn_act_fwd: C=%d / strides must be multiples of 8", C);
+    EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)z, ld_z, stats, reps, gamma,
+                       beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
+                       ld_res, M, C, eps, momentum, act);
+    EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int64_t M, int C,
+                                      int act, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
+    EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
+    int grid = row_grid(M, C);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+                       save, gamma, beta, dgamma, dbeta, M, C, act);
+    EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
+    return EP24_OK;
+}
+
+extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                                     const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
+                                     void* dz, int64_t ld_dz, int64_t M, int C, int act, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
+    EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+                       (const bf16*)z, ld_z, save, gamma, beta, dgamma, dbeta, (bf16*)dz, ld_dz, M, C, act);
+    EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
+    return EP24_OK;
+}
+
+extern "C" int ep24_stem_pack(const float* images, void* rows, int B, int S, void* stream) {
+    EP24_REQUIRE(images && rows && S % 2 == 0 && B > 0, EP24_E_ARG, "stem_pack: bad arguments");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(cap_grid((long)B * (S / 2) * (S / 2) * 16)), dim3(256), 0, S_, images,
+                       (bf16*)rows, B, S);
+    EP24_LAUNCH_CHECK("ep24_stem_pack");
+    return EP24_OK;
+}
+
+extern "C" int ep24_spp_fwd(const void* x, int64_t ld_x, void* y5, void* y9, void* y13, int64_t ld_y, uint8_t* idx, int B,
+                            int H, int W, int C, void* stream) {
+    EP24_REQUIRE(x && y5 && y9 && y13 && idx && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0, EP24_E_ARG, "spp_fwd: bad arguments");
+    hipLaunchKernelGGL(spp_fwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)x, ld_x,
+                       (bf16*)y5, (bf16*)y9, (bf16*)y13, ld_y, idx, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_spp_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_spp_bwd(const void* dy5, const void* dy9, const void* dy13, int64_t ld_dy, const uint8_t* idx, void* dx,
+                            int64_t ld_dx, int accumulate, int B, int H, int W, int C, void* stream) {
+    EP24_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0, EP24_E_ARG, "spp_bwd: bad arguments");
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy5,
+                       (const bf16*)dy9, (const bf16*)dy13, ld_dy, idx, (bf16*)dx, ld_dx, accumulate, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_spp_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_upsample2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream) {
+    EP24_REQUIRE(x && y && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0, EP24_E_ARG, "upsample2_fwd: bad arguments");
+    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(cap_grid((long)B * 4 * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)x,
+                       ld_x, (bf16*)y, ld_y, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_upsample2_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_upsample2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W,
+                                  int C, void* stream) {
+    EP24_REQUIRE(dy && dx && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0, EP24_E_ARG, "upsample2_bwd: bad arguments");
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+                       (bf16*)dx, ld_dx, accumulate, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_upsample2_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int accumulate, int64_t M, int C,
+                              void* stream) {
+    EP24_REQUIRE(src && dst && C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, EP24_E_ARG, "rows_copy: bad arguments");
+    hipLaunchKernelGGL(rows_copy_kernel, dim3(cap_grid(M * (C / 8))), dim3(256), 0, S_, (const bf16*)src, ld_src, (bf16*)dst,
+                       ld_dst, accumulate, M, C);
+    EP24_LAUNCH_CHECK("ep24_rows_copy");
+    return EP24_OK;
+}
+
+extern "C" int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream) {
+    EP24_REQUIRE(out && a0 >= 0 && a0 + H * W <= A && ncols >= 27, EP24_E_ARG, "head_decode_fwd: bad arguments");
+    hipLaunchKernelGGL(decode_fwd_kernel, dim3(cap_grid((long)B * H * W * 26)), dim3(256), 0, S_, out, B, A, a0, H, W, stride, ncols);
+    EP24_LAUNCH_CHECK("ep24_head_decode_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
+                                    int H, int W, float stride, int ncols, void* stream) {
+    EP24_REQUIRE(dout && out && d_regobj && d_cls && a0 >= 0 && a0 + H * W <= A && ncols >= 27 && ncols <= 27 + 128, EP24_E_ARG,
+                 "head_decode_bwd: bad arguments");
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3(cap_grid((long)B * H * W * 24)), dim3(256), 0, S_, dout, out, (bf16*)d_regobj,
+                       (bf16*)d_cls, B, A, a0, H, W, stride, ncols);
+    EP24_LAUNCH_CHECK("ep24_head_decode_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_colsum(const void* g, int64_t ld, float* db, int64_t M, int N, void* stream) {
+    EP24_REQUIRE(g && db && N > 0, EP24_E_ARG, "colsum: bad arguments");
+    long blocks = (M + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, S_, (const bf16*)g, ld, db, M, N);
+    EP24_LAUNCH_CHECK("ep24_colsum");
+    return EP24_OK;
+}
+
+extern "C" int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, int Cout, int T, int Cin, int Cin_pad,
+                                 int Cout_pad, void* stream) {
+    EP24_REQUIRE(w && (w_fwd || w_dgrad) && Cin_pad >= Cin && Cout_pad >= Cout, EP24_E_ARG, "pack_weights: bad arguments");
+    long n = (long)Cout * T * Cin;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(cap_grid(n)), dim3(256), 0, S_, w, ld_w, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, T, Cin,
+                       Cin_pad, Cout_pad);
+    EP24_LAUNCH_CHECK("ep24_pack_weights");
+    return EP24_OK;
+}
+
+extern "C" int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float grad_scale,
+                                 int32_t* first_flag, void* stream) {
+    EP24_REQUIRE(p && g && buf && first_flag && n > 0, EP24_E_ARG, "sgd_nesterov: bad arguments");
+    EP24_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) % 16 == 0, EP24_E_ARG, "sgd_nesterov: 16-byte alignment");
+    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p, g, buf, n, lr, momentum, grad_scale, first_flag);
+    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
+    EP24_LAUNCH_CHECK("ep24_sgd_nesterov");
+    return EP24_OK;
+}
+
+extern "C" int ep24_memset_zero(void* p, int64_t bytes, void* stream) {
+    EP24_REQUIRE(p && bytes >= 0, EP24_E_ARG, "memset_zero: bad arguments");
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "memset_zero: %s", hipGetErrorString(e));
+    return EP24_OK;
+}

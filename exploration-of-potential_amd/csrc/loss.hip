@@ -1,0 +1,259 @@
+// ep24 - 24-circle GIoU / objectness / class losses, dynamic task weights and the gradient w.r.t. the decoded
+// head outputs (yolox_24p/models/losses.py:80-157, :283-357), plus the stand-alone forms behind
+// utils.bboxes_iou (yolox_24p/utils/boxes.py:166-243) and IOUloss.forward.
+//
+// Sync-free: loss_terms writes per-workgroup partial sums, loss_finalize folds them in a fixed order
+// (bitwise reproducible), computes num_fg / the 26 task weights / the scalar loss on the device and keeps the
+// "last loss" state there; loss_grad then needs nothing from the host.
+#include "geom.h"
+
+namespace {
+
+constexpr int G_MAX = EP24_MAX_GT;
+constexpr int LCOLS = EP24_LABEL_COLS;
+constexpr int NS = EP24_NUM_SUMS;          // 0..23 iou, 24 obj, 25 cls, 26 num_fg
+
+__device__ __forceinline__ float bce_logits(float x, float y) {
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void loss_terms_kernel(const float* outputs, int ncols, const float* labels,
+                                                         const int* matched_gt, const float* matched_iou, float* partials,
+                                                         int A, int C) {
+    __shared__ float red[4][NS];
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+    if (a < A) {
+        const float* o = outputs + ((long)b * A + a) * ncols;
+        const int g = matched_gt[(long)b * A + a];
+        acc[24] = bce_logits(o[26], g >= 0 ? 1.f : 0.f);
+        if (g >= 0) {
+            const float* lab = labels + ((long)b * G_MAX + g) * LCOLS;
+            const float gcx = lab[1], gcy = lab[2];
+            const float ddx = gcx - o[0], ddy = gcy - o[1];
+            const float d = sqrtf(ddx * ddx + ddy * ddy);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const float vx = lab[3 + 2 * k] - gcx, vy = lab[4 + 2 * k] - gcy;
+                acc[k] = 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), o[2 + k], d);
+            }
+            const int cls = (int)lab[0];
+            const float piou = matched_iou[(long)b * A + a];
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += bce_logits(o[27 + c], c == cls ? piou : 0.f);
+            acc[25] = s;
+            acc[26] = 1.f;
+        }
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        const float v = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) red[w][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        float v = 0.f;
+        if (threadIdx.x < 27) v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        partials[((long)b * gridDim.x + blockIdx.x) * NS + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* partials, int nblocks, const int* num_gt, int B,
+                                                           float* state, float* result) {
+    __shared__ float sums[NS];
+    const int t = threadIdx.x;
+    if (t < NS) {
+        float s = 0.f;
+        for (int i = 0; i < nblocks; ++i) s += partials[(long)i * NS + t];
+        sums[t] = s;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    const float nfg_raw = sums[26];
+    const float nfg = fmaxf(nfg_raw, 1.f);                          // losses.py:280
+    int ngts = 0;
+    for (int b = 0; b < B; ++b) ngts += num_gt[b];
+    float l[26], r[26], e[26];
+    for (int k = 0; k < 26; ++k) l[k] = sums[k] / nfg;              // 0..23 iou, 24 obj, 25 cls
+    for (int k = 0; k < 26; ++k) {
+        r[k] = fminf(fmaxf(l[k] / (state[k] + 1e-8f), 0.f), 2.f);   // losses.py:316-323
+        e[k] = expf(r[k] / 20.0f);
+    }
+    float den = 0.f;
+    for (int k = 0; k < 24; ++k) den += e[k];
+    den = den + e[24] + e[25];
+    float loss = 0.f;
+    for (int k = 0; k < 24; ++k) {
+        const float w = 26.0f * e[k] / den;
+        result[29 + k] = w;
+        result[1 + k] = w * l[k];
+        loss += w * l[k];
+    }
+    const float ow = 26.0f * e[24] / den, cw = 26.0f * e[25] / den;
+    loss = loss + ow * l[24] + cw * l[25] + 0.0f;
+    result[0] = loss;
+    result[25] = l[24];
+    result[26] = l[25];
+    result[27] = nfg;
+    result[28] = (float)ngts;
+    result[53] = ow;
+    result[54] = cw;
+    result[55] = nfg_raw;
+    for (int k = 0; k < 26; ++k) state[k] = l[k];                   // losses.py:343-345
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* outputs, int ncols, const float* labels,
+                                                        const int* matched_gt, const float* matched_iou, const float* result,
+                                                        const float* grad_scale, float* dout, int A, int C) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const float gs = (grad_scale ? *grad_scale : 1.0f) / result[27];
+    const float* o = outputs + ((long)b * A + a) * ncols;
+    float* d_o = dout + ((long)b * A + a) * ncols;
+    const int g = matched_gt[(long)b * A + a];
+    const float so = 1.0f / (1.0f + expf(-o[26]));
+    d_o[26] = result[53] * gs * (so - (g >= 0 ? 1.f : 0.f));
+    if (g < 0) {
+        for (int c = 0; c < 26; ++c) d_o[c] = 0.f;
+        for (int c = 27; c < ncols; ++c) d_o[c] = 0.f;
+        return;
+    }
+    const float* lab = labels + ((long)b * G_MAX + g) * LCOLS;
+    const float gcx = lab[1], gcy = lab[2];
+    const float ddx = gcx - o[0], ddy = gcy - o[1];
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    float gd = 0.f;
+    for (int k = 0; k < 24; ++k) {
+        const float vx = lab[3 + 2 * k] - gcx, vy = lab[4 + 2 * k] - gcy;
+        float g_r, g_d;
+        ray_loss_grad(sqrtf(vx * vx + vy * vy), o[2 + k], d, g_r, g_d);
+        const float w = result[29 + k] * gs;
+        d_o[2 + k] = w * g_r;
+        gd += w * g_d;
+    }
+    // d = sqrt((gx-cx)^2 + (gy-cy)^2): dd/dcx = -(gx-cx)/d.  d == 0 gives NaN, exactly as the reference's autograd
+    d_o[0] = gd * (-ddx / d);
+    d_o[1] = gd * (-ddy / d);
+    const int cls = (int)lab[0];
+    const float piou = matched_iou[(long)b * A + a];
+    const float cw = result[54] * gs;
+    for (int c = 0; c < C; ++c) {
+        const float sc = 1.0f / (1.0f + expf(-o[27 + c]));
+        d_o[27 + c] = cw * (sc - (c == cls ? piou : 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ stand-alone forms
+__global__ __launch_bounds__(256) void pairwise_kernel(const float* gt50, const float* pred26, float* out, int G, int P) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)G * P) return;
+    const int g = (int)(i / P), p = (int)(i - (long)g * P);
+    const float* t = gt50 + (long)g * 50;
+    const float* q = pred26 + (long)p * 26;
+    const float ddx = t[0] - q[0], ddy = t[1] - q[1];
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    float acc = 0.f;
+    for (int k = 0; k < 24; ++k) {
+        const float vx = t[2 + 2 * k] - t[0], vy = t[3 + 2 * k] - t[1];
+        acc += 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), q[2 + k], d);
+    }
+    out[i] = acc / 24.0f / 2.0f;
+}
+
+__global__ __launch_bounds__(256) void matched_fwd_kernel(const float* pred26, const float* target50, float* loss24, int N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * 24) return;
+    const int n = (int)(i / 24), k = (int)(i - (long)n * 24);
+    const float* t = target50 + (long)n * 50;
+    const float* q = pred26 + (long)n * 26;
+    const float ddx = t[0] - q[0], ddy = t[1] - q[1];
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    const float vx = t[2 + 2 * k] - t[0], vy = t[3 + 2 * k] - t[1];
+    loss24[i] = 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), q[2 + k], d);
+}
+
+__global__ __launch_bounds__(256) void matched_bwd_kernel(const float* pred26, const float* target50, const float* dloss24,
+                                                          float* dpred26, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* t = target50 + (long)n * 50;
+    const float* q = pred26 + (long)n * 26;
+    const float ddx = t[0] - q[0], ddy = t[1] - q[1];
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    float gd = 0.f;
+    for (int k = 0; k < 24; ++k) {
+        const float vx = t[2 + 2 * k] - t[0], vy = t[3 + 2 * k] - t[1];
+        float g_r, g_d;
+        ray_loss_grad(sqrtf(vx * vx + vy * vy), q[2 + k], d, g_r, g_d);
+        const float w = dloss24[(long)n * 24 + k];
+        dpred26[(long)n * 26 + 2 + k] = w * g_r;
+        gd += w * g_d;
+    }
+    dpred26[(long)n * 26 + 0] = gd * (-ddx / d);
+    dpred26[(long)n * 26 + 1] = gd * (-ddy / d);
+}
+
+}  // namespace
+
+extern "C" int ep24_loss_blocks(int B, int A) { return B * ep24_cdiv(A, 256); }
+
+extern "C" int ep24_loss_terms(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
+                               const float* matched_iou, float* partials, int B, int A, int num_classes, void* stream) {
+    EP24_REQUIRE(outputs && labels && matched_gt && matched_iou && partials, EP24_E_ARG, "loss_terms: null pointer");
+    EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "loss_terms: ncols=%d != 27+%d", ncols, num_classes);
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
+                       matched_gt, matched_iou, partials, A, num_classes);
+    EP24_LAUNCH_CHECK("ep24_loss_terms");
+    return EP24_OK;
+}
+
+extern "C" int ep24_loss_finalize(const float* partials, int nblocks, const int32_t* num_gt, int B, float* state, float* result,
+                                  void* stream) {
+    EP24_REQUIRE(partials && num_gt && state && result && nblocks > 0, EP24_E_ARG, "loss_finalize: bad arguments");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblocks, num_gt, B, state, result);
+    EP24_LAUNCH_CHECK("ep24_loss_finalize");
+    return EP24_OK;
+}
+
+extern "C" int ep24_loss_grad(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
+                              const float* matched_iou, const float* result, const float* grad_scale, float* dout, int B, int A,
+                              int num_classes, void* stream) {
+    EP24_REQUIRE(outputs && labels && matched_gt && matched_iou && result && dout, EP24_E_ARG, "loss_grad: null pointer");
+    EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "loss_grad: ncols=%d != 27+%d", ncols, num_classes);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
+                       matched_gt, matched_iou, result, grad_scale, dout, A, num_classes);
+    EP24_LAUNCH_CHECK("ep24_loss_grad");
+    return EP24_OK;
+}
+
+extern "C" int ep24_circle_pairwise(const float* gt50, const float* pred26, float* out, int G, int P, void* stream) {
+    if (G == 0 || P == 0) return EP24_OK;       // empty GT / empty candidate set: nothing to write
+    EP24_REQUIRE(gt50 && pred26 && out, EP24_E_ARG, "circle_pairwise: null pointer");
+    hipLaunchKernelGGL(pairwise_kernel, dim3(ep24_cdiv((long)G * P, 256)), dim3(256), 0, (hipStream_t)stream, gt50, pred26, out, G, P);
+    EP24_LAUNCH_CHECK("ep24_circle_pairwise");
+    return EP24_OK;
+}
+
+extern "C" int ep24_circle_matched_fwd(const float* pred26, const float* target50, float* loss24, int N, void* stream) {
+    if (N == 0) return EP24_OK;
+    EP24_REQUIRE(pred26 && target50 && loss24, EP24_E_ARG, "circle_matched_fwd: null pointer");
+    hipLaunchKernelGGL(matched_fwd_kernel, dim3(ep24_cdiv((long)N * 24, 256)), dim3(256), 0, (hipStream_t)stream, pred26, target50,
+                       loss24, N);
+    EP24_LAUNCH_CHECK("ep24_circle_matched_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_circle_matched_bwd(const float* pred26, const float* target50, const float* dloss24, float* dpred26, int N,
+                                       void* stream) {
+    if (N == 0) return EP24_OK;
+    EP24_REQUIRE(pred26 && target50 && dloss24 && dpred26, EP24_E_ARG, "circle_matched_bwd: null pointer");
+    hipLaunchKernelGGL(matched_bwd_kernel, dim3(ep24_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred26, target50, dloss24,
+                       dpred26, N);
+    EP24_LAUNCH_CHECK("ep24_circle_matched_bwd");
+    return EP24_OK;
+}

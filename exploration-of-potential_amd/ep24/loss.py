@@ -1,0 +1,211 @@
+"""Host side of the 24p loss: mirrors ``models.losses.Loss_Function`` / ``IOUloss`` and ``utils.bboxes_iou``
+of the reference (yolox_24p/models/losses.py:14-603, yolox_24p/utils/boxes.py:166-243) on top of the C ABI.
+
+Everything between the head outputs and the scalar loss runs as HIP kernels chained on the current stream;
+nothing is copied to the host (the reference synchronises >= 3+G times per image).  The per-call stateful
+task weights (``last_*`` losses) live in a device buffer.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+MAX_GT = 50
+NCOLS_BASE = 27
+RESULT = 64
+
+
+class LossWorkspace:
+    """Fixed-capacity device buffers for one (B, A, num_classes) problem size."""
+
+    def __init__(self, B, A, num_classes, device):
+        self.B, self.A, self.C = B, A, num_classes
+        z = dict(device=device)
+        self.num_gt = torch.zeros(B, dtype=torch.int32, **z)
+        self.masks = torch.zeros(3, B, A, dtype=torch.int64, **z)         # in_box, in_ctr, match (uint64 bit per GT)
+        self.pw = torch.zeros(B, MAX_GT, A, dtype=torch.float32, **z)
+        self.cost = torch.zeros(B, MAX_GT, A, dtype=torch.float32, **z)
+        self.ks = torch.zeros(B, MAX_GT, dtype=torch.int32, **z)
+        self.matched_gt = torch.full((B, A), -1, dtype=torch.int32, **z)
+        self.matched_iou = torch.zeros(B, A, dtype=torch.float32, **z)
+        self.nblocks = _lib.lib().fn["ep24_loss_blocks"](B, A)
+        self.partials = torch.zeros(self.nblocks, 32, dtype=torch.float32, **z)
+        self.result = torch.zeros(RESULT, dtype=torch.float32, **z)
+        self.dout = torch.zeros(B, A, NCOLS_BASE + num_classes, dtype=torch.float32, **z)
+
+
+def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state):
+    """Kernels a4..a10 forward: fills ws.matched_* and ws.result; updates `state` (device [26])."""
+    B, A, C = ws.B, ws.A, ws.C
+    ncols = NCOLS_BASE + C
+    s = stream_ptr()
+    in_box, in_ctr, match = ws.masks[0], ws.masks[1], ws.masks[2]
+    call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), B, A, s)
+    call("assign_cost", ptr(outputs), ncols, ptr(labels), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ptr(ws.pw),
+         ptr(ws.cost), B, A, C, s)
+    call("memset_zero", ptr(match), match.numel() * 8, s)
+    call("dynamic_k", ptr(ws.pw), ptr(ws.cost), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ptr(match), ptr(ws.ks), B, A, s)
+    call("assign_resolve", ptr(match), ptr(ws.pw), ptr(ws.cost), ptr(ws.num_gt), ptr(ws.matched_gt), ptr(ws.matched_iou),
+         B, A, s)
+    call("loss_terms", ptr(outputs), ncols, ptr(labels), ptr(ws.matched_gt), ptr(ws.matched_iou), ptr(ws.partials),
+         B, A, C, s)
+    call("loss_finalize", ptr(ws.partials), ws.nblocks, ptr(ws.num_gt), B, ptr(state), ptr(ws.result), s)
+
+
+def loss_grad(ws, outputs, labels, grad_scale=None):
+    """d loss / d outputs into ws.dout (fully overwritten)."""
+    call("loss_grad", ptr(outputs), NCOLS_BASE + ws.C, ptr(labels), ptr(ws.matched_gt), ptr(ws.matched_iou),
+         ptr(ws.result), ptr(grad_scale), ptr(ws.dout), ws.B, ws.A, ws.C, stream_ptr())
+    return ws.dout
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, labels, xs, ys, strides, ws, state):
+        assign_and_reduce(ws, outputs, labels, xs, ys, strides, state)
+        ctx.ws = ws
+        ctx.save_for_backward(outputs, labels)
+        return ws.result.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        outputs, labels = ctx.saved_tensors
+        # only element 0 (the weighted total) carries gradient; 1..3 are reported values
+        dout = loss_grad(ctx.ws, outputs, labels, g[0:1].contiguous())
+        return dout, None, None, None, None, None, None
+
+
+def _check_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.Ep24Error("ep24: %s must live on the GPU (no CPU fallback on the product path)" % name)
+
+
+class Loss_Function(nn.Module):
+    """Drop-in for the reference ``Loss_Function(num_classes)`` (yolox_24p/models/losses.py:159-357).
+
+    ``forward(outputs_train, labels)`` takes the head's train-mode 5-tuple and ``labels [B,50,51]`` and returns
+    ``(loss, reg_w*loss_iou[24], loss_obj, loss_cls, loss_l1=0.0, num_fg/num_gts, draw_content)``.
+    Differences, all about avoiding host syncs: position 5 is a 0-dim device tensor (float()-able) instead of
+    a python float, and draw_content[0:3] (matched cx / cy / radii, dynamic length) are only materialised when
+    ``self.draw`` is True.
+    """
+
+    def __init__(self, num_classes):
+        super().__init__()
+        self.num_classes = num_classes
+        self.use_l1 = False
+        self.iou_loss = IOUloss(reduction="none")
+        self.draw = True
+        self._ws = None
+        self._state = None          # device [26]: last_iou_loss[24], last_obj_loss, last_cls_loss (init 1.0)
+        self._grid = None
+
+    # the reference exposes these as attributes that start at 1.0 (losses.py:170-172)
+    @property
+    def last_iou_loss(self):
+        return 1.0 if self._state is None else self._state[:24]
+
+    @property
+    def last_obj_loss(self):
+        return 1.0 if self._state is None else self._state[24]
+
+    @property
+    def last_cls_loss(self):
+        return 1.0 if self._state is None else self._state[25]
+
+    def workspace(self, B, A, device):
+        if self._ws is None or (self._ws.B, self._ws.A) != (B, A):
+            self._ws = LossWorkspace(B, A, self.num_classes, device)
+        if self._state is None:
+            self._state = torch.ones(26, dtype=torch.float32, device=device)
+        return self._ws
+
+    def _anchors(self, x_shifts, y_shifts, strides):
+        key = tuple(t.data_ptr() for t in x_shifts)
+        if self._grid is None or self._grid[0] != key:
+            self._grid = (key, torch.cat(x_shifts, 1)[0].contiguous().float(),
+                          torch.cat(y_shifts, 1)[0].contiguous().float(), torch.cat(strides, 1)[0].contiguous().float())
+        return self._grid[1:]
+
+    def forward(self, outputs_train, labels):
+        _lib.require_gpu()
+        x_shifts, y_shifts, expanded_strides, outputs, _origin = outputs_train
+        _check_cuda(outputs, "outputs")
+        if outputs.shape[2] != NCOLS_BASE + self.num_classes or labels.shape[1:] != (MAX_GT, 51):
+            raise IndexError
+        B, A = outputs.shape[0], outputs.shape[1]
+        ws = self.workspace(B, A, outputs.device)
+        xs, ys, st = self._anchors(x_shifts, y_shifts, expanded_strides)
+        labels = labels.to(device=outputs.device, dtype=torch.float32).contiguous()
+        outputs_c = outputs if outputs.is_contiguous() else outputs.contiguous()
+        res = _LossFn.apply(outputs_c, labels, xs, ys, st, ws, self._state)
+        reg_w, obj_w, cls_w = res[29:53], res[53], res[54]
+        if self.draw:
+            fg = ws.matched_gt.reshape(-1) >= 0
+            rows = outputs_c.detach().reshape(-1, outputs_c.shape[2])[fg]
+            draw = [rows[:, 0], rows[:, 1], rows[:, 2:26]]
+        else:
+            draw = [None, None, None]
+        draw += [reg_w, obj_w, cls_w]
+        return res[0], res[1:25], res[25], res[26], 0.0, res[55] / torch.clamp(res[28], min=1.0), draw
+
+    # --- reference helper kept for API parity (losses.py:360-442): assignment of one image of the last call
+    def assignment_of(self, labels, b):
+        ws = self._ws
+        g = ws.matched_gt[b]
+        fg = g >= 0
+        idx = g[fg].long()
+        return labels[b, :, 0].to(g.device)[idx], fg, ws.matched_iou[b][fg], idx, int(fg.sum())
+
+
+class _MatchedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        out = torch.empty(pred.shape[0], 24, dtype=torch.float32, device=pred.device)
+        call("circle_matched_fwd", ptr(pred), ptr(target), ptr(out), pred.shape[0], stream_ptr())
+        ctx.save_for_backward(pred, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        call("circle_matched_bwd", ptr(pred), ptr(target), ptr(g.contiguous()), ptr(d), pred.shape[0], stream_ptr())
+        return d, None
+
+
+class IOUloss(nn.Module):
+    """Drop-in for the reference ``IOUloss`` (yolox_24p/models/losses.py:14-157): matched rows, returns
+    ``(1 - giou)[N,24]`` and ``[pd_cx, pd_cy, scale_pd]``."""
+
+    def __init__(self, reduction="none"):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, pred, target):
+        if pred.shape[1] != 26 or target.shape[1] != 50:
+            raise IndexError
+        _lib.require_gpu()
+        _check_cuda(pred, "pred")
+        pred = pred.reshape(-1, 26).float()
+        target = target.reshape(-1, 50).float().to(pred.device)
+        if pred.shape[0] == 0 or target.shape[0] == 0:           # placeholder path, losses.py:111-115
+            z = pred.new_zeros(1, 24)
+            return z, [pred.new_zeros(1, 24), pred.new_zeros(1, 24), pred.new_zeros(1, 24)]
+        predc = pred.contiguous()
+        loss24 = _MatchedFn.apply(predc, target.contiguous())
+        return loss24, [predc[:, 0], predc[:, 1], predc[:, 2:]]
+
+
+def bboxes_iou(bboxes_a, bboxes_b, imgs=None):
+    """Drop-in for ``utils.bboxes_iou`` (yolox_24p/utils/boxes.py:166-243): [G,50] x [P,26] -> [G,P]."""
+    if bboxes_b.shape[1] != 26 or bboxes_a.shape[1] != 50:
+        raise IndexError
+    _lib.require_gpu()
+    _check_cuda(bboxes_b, "bboxes_b")
+    a = bboxes_a.reshape(-1, 50).float().contiguous().to(bboxes_b.device)
+    b = bboxes_b.reshape(-1, 26).float().contiguous()
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=b.device)
+    call("circle_pairwise", ptr(a), ptr(b), ptr(out), a.shape[0], b.shape[0], stream_ptr())
+    return out

@@ -1,0 +1,186 @@
+"""Parameter tree of the YOLOX-24p network with the reference's module / state-dict names.
+
+These modules only HOLD parameters and describe the graph; the arithmetic is the HIP plan in
+``ep24.engine`` (NHWC bf16 MFMA convs, fused BN+SiLU, ...), entered through ``YOLOX.forward``.
+Names follow the reference so its checkpoints load unchanged:
+  network_blocks.py:29-210 (BaseConv, Bottleneck, CSPLayer, SPPBottleneck, Focus), darknet.py:95-177
+  (CSPDarknet), yolo_pafpn.py:27-81 (YOLOPAFPN), yolo_head_24p.py:47-141 (YOLOXHead), yolox.py:17-34 (YOLOX).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _no_eager(mod):
+    raise NotImplementedError(
+        "%s holds parameters only; run the network through YOLOX.forward (the HIP plan)" % type(mod).__name__)
+
+
+class BaseConv(nn.Module):
+    """conv (no bias) -> BatchNorm (eps 1e-3, momentum 0.03 as patched by Exp.get_model) -> SiLU."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
+        super().__init__()
+        if groups != 1 or bias or act != "silu":
+            raise NotImplementedError("ep24 hot path: dense conv, no bias, SiLU (the yolox_24p -l configuration)")
+        self.conv = nn.Conv2d(in_channels, out_channels, ksize, stride, (ksize - 1) // 2, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
+        self.act = nn.SiLU(inplace=True)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class Focus(nn.Module):
+    def __init__(self, in_channels, out_channels, ksize=1, stride=1, act="silu"):
+        super().__init__()
+        self.conv = BaseConv(in_channels * 4, out_channels, ksize, stride, act=act)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError("depthwise variants are outside the 24p hot path")
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, 1, act=act)
+        self.conv2 = BaseConv(hidden, out_channels, 3, 1, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class CSPLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, 1, act=act)
+        self.conv2 = BaseConv(in_channels, hidden, 1, 1, act=act)
+        self.conv3 = BaseConv(2 * hidden, out_channels, 1, 1, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class SPPBottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_sizes=(5, 9, 13), activation="silu"):
+        super().__init__()
+        if tuple(kernel_sizes) != (5, 9, 13):
+            raise NotImplementedError("SPP kernel sizes are fixed to (5, 9, 13)")
+        hidden = in_channels // 2
+        self.conv1 = BaseConv(in_channels, hidden, 1, 1, act=activation)
+        self.m = nn.ModuleList([nn.MaxPool2d(k, 1, k // 2) for k in kernel_sizes])
+        self.conv2 = BaseConv(hidden * 4, out_channels, 1, 1, act=activation)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class CSPDarknet(nn.Module):
+    def __init__(self, dep_mul, wid_mul, out_features=("dark3", "dark4", "dark5"), depthwise=False, act="silu"):
+        super().__init__()
+        self.out_features = out_features
+        c = int(wid_mul * 64)
+        d = max(round(dep_mul * 3), 1)
+        self.stem = Focus(3, c, ksize=3, act=act)
+        self.dark2 = nn.Sequential(BaseConv(c, c * 2, 3, 2, act=act), CSPLayer(c * 2, c * 2, n=d, act=act))
+        self.dark3 = nn.Sequential(BaseConv(c * 2, c * 4, 3, 2, act=act), CSPLayer(c * 4, c * 4, n=d * 3, act=act))
+        self.dark4 = nn.Sequential(BaseConv(c * 4, c * 8, 3, 2, act=act), CSPLayer(c * 8, c * 8, n=d * 3, act=act))
+        self.dark5 = nn.Sequential(BaseConv(c * 8, c * 16, 3, 2, act=act), SPPBottleneck(c * 16, c * 16, activation=act),
+                                   CSPLayer(c * 16, c * 16, n=d, shortcut=False, act=act))
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class YOLOPAFPN(nn.Module):
+    def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
+                 depthwise=False, act="silu"):
+        super().__init__()
+        self.backbone = CSPDarknet(depth, width, depthwise=depthwise, act=act)
+        self.in_features = in_features
+        self.in_channels = in_channels
+        c3, c4, c5 = [int(c * width) for c in in_channels]
+        n = round(3 * depth)
+        self.upsample = nn.Upsample(scale_factor=2, mode="nearest")
+        self.lateral_conv0 = BaseConv(c5, c4, 1, 1, act=act)
+        self.C3_p4 = CSPLayer(2 * c4, c4, n, False, act=act)
+        self.reduce_conv1 = BaseConv(c4, c3, 1, 1, act=act)
+        self.C3_p3 = CSPLayer(2 * c3, c3, n, False, act=act)
+        self.bu_conv2 = BaseConv(c3, c3, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c3, c4, n, False, act=act)
+        self.bu_conv1 = BaseConv(c4, c4, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c4, c5, n, False, act=act)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class YOLOXHead(nn.Module):
+    def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act="silu",
+                 depthwise=False):
+        super().__init__()
+        self.n_anchors = 1
+        self.num_classes = num_classes
+        self.decode_in_inference = True
+        self.strides = strides
+        self.use_l1 = False
+        h = int(256 * width)
+        self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
+        self.cls_preds, self.reg_preds, self.obj_preds = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.stems = nn.ModuleList()
+        for c in in_channels:
+            self.stems.append(BaseConv(int(c * width), h, 1, 1, act=act))
+            self.cls_convs.append(nn.Sequential(BaseConv(h, h, 3, 1, act=act), BaseConv(h, h, 3, 1, act=act)))
+            self.reg_convs.append(nn.Sequential(BaseConv(h, h, 3, 1, act=act), BaseConv(h, h, 3, 1, act=act)))
+            self.cls_preds.append(nn.Conv2d(h, self.n_anchors * num_classes, 1, 1, 0))
+            self.reg_preds.append(nn.Conv2d(h, 26, 1, 1, 0))
+            self.obj_preds.append(nn.Conv2d(h, self.n_anchors, 1, 1, 0))
+
+    def initialize_biases(self, prior_prob):
+        """bias = -log((1-p)/p) on the class and objectness predictors (yolo_head_24p.py:132-141)."""
+        v = -math.log((1 - prior_prob) / prior_prob)
+        with torch.no_grad():
+            for conv in list(self.cls_preds) + list(self.obj_preds):
+                conv.bias.fill_(v)
+
+    def forward(self, xin, train=False):
+        _no_eager(self)
+
+
+class YOLOX(nn.Module):
+    """``forward(x, train=True)`` returns the reference's train-mode 5-tuple
+    ``(x_shifts[3], y_shifts[3], expanded_strides[3], outputs[B,A,27+C], origin_preds=[])`` (yolox.py:24-34,
+    yolo_head_24p.py:143-210); ``train=False`` returns decoded predictions with sigmoid scores."""
+
+    def __init__(self, backbone=None, head=None):
+        super().__init__()
+        self.backbone = YOLOPAFPN() if backbone is None else backbone
+        self.head = YOLOXHead(80) if head is None else head
+        self._engines = {}
+
+    def engine(self, batch, size):
+        from .engine import Engine
+        key = (batch, size)
+        if key not in self._engines:
+            # one parameter home (flat buffers) per model; plans for other shapes share it
+            base = next(iter(self._engines.values()), None)
+            self._engines[key] = Engine(self, batch, size, share=base)
+        return self._engines[key]
+
+    def forward(self, x, train=False):
+        _lib.require_gpu()
+        if not x.is_cuda:
+            raise _lib.Ep24Error("ep24: input images must live on the GPU (no CPU fallback on the product path)")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 32:
+            raise IndexError("expected images [B,3,S,S] with S a multiple of 32, got %s" % (tuple(x.shape),))
+        eng = self.engine(x.shape[0], x.shape[2])
+        return eng.run_module_forward(x, train)

@@ -1,0 +1,208 @@
+/* ep24 - C ABI of the MI355X-native YOLOX-24p training path (libep24.so, gfx950 only).
+ *
+ * The reference (IN2-ViAUn/Exploration-of-Potential, /root/reference) has NO native/FFI boundary on this
+ * path: it is plain Python over torch ops.  The drop-in surface is therefore the reference's Python API
+ * (exploration-of-potential_amd/yolox_24p mirrors it) and this C ABI sits one level below it: every entry
+ * point replaces the torch-op sequence of one row of SURVEY.md section 8(a), cited per function as
+ * file:line under /root/reference.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every buffer
+ *   - `stream` is a hipStream_t (passed as void*); nothing here allocates, frees or synchronises
+ *   - activations are NHWC bf16 with an explicit row stride `ld_*` (elements between consecutive pixels),
+ *     so a tensor may be a channel slice of a wider (concat) buffer
+ *   - conv weights are [Cout][KH*KW][Cin] ("KRSC"); fp32 masters, bf16 packed copies
+ *   - return 0 on success, a negative EP24_E_* otherwise; text via ep24_last_error()
+ */
+#ifndef EP24_H
+#define EP24_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EP24_OK 0
+#define EP24_E_ARG (-1)          /* bad shape / alignment / null pointer (reference raises IndexError/assert) */
+#define EP24_E_LAUNCH (-2)       /* HIP launch error */
+#define EP24_E_UNSUPPORTED (-3)
+
+#define EP24_MAX_GT 50           /* max_labels, yolox_24p/datasets/data_augment.py:131 */
+#define EP24_RAYS 24
+#define EP24_LABEL_COLS 51
+#define EP24_NUM_SUMS 32         /* per-step loss accumulators, see ep24_loss_* */
+
+const char* ep24_last_error(void);
+int ep24_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  conv + BN + SiLU blocks  (yolox_24p/models/network_blocks.py:29-54 BaseConv.forward and its autograd)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], w[Cout][k*k][Cin]), pad (k-1)/2, bf16 MFMA implicit GEMM, fp32
+ * accumulate.  y is bf16 (y_f32=0) or fp32 (y_f32=1, + bias) with row stride ld_y.  If `stats` is non-null
+ * the per-channel sum and sum-of-squares of the fp32 results are atomically added into
+ * stats[replica][0][c] / stats[replica][1][c] (replica = block % stats_replicas): the BN batch statistics
+ * (torch.nn.BatchNorm2d training mode, network_blocks.py:47).  Requires Cin % 64 == 0.
+ * Output pixel (n,oh,ow) lands on row n*y_batch_rows + y_row0 + oh*OW + ow of y (y_batch_rows = 0 means
+ * dense OH*OW): lets the head write straight into its slice of the [B,8400,107] tensor. */
+int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                       int64_t y_batch_rows, int64_t y_row0, const float* bias, float* stats, int stats_replicas,
+                       int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 64 == 0 (padded).
+ * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */
+int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
+                         int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, void* stream);
+
+/* dw[co][t][ci] += sum_pixels dy[.,co] * x[.@t,ci]   fp32, row stride ld_dw between co rows (= taps*cin_valid
+ * when dense), only co < cout_valid and ci < cin_valid are written.  Split over pixels with fp32 atomics.
+ * Replaces autograd's conv weight gradient. */
+int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw,
+                         int cout_valid, int cin_valid,
+                         int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad
+ * [Cin][T][Cout_pad] (either may be null).  Only real elements are written; the caller zero-initialises the
+ * padded buffers once. */
+int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, int Cout, int T, int Cin,
+                      int Cin_pad, int Cout_pad, void* stream);
+
+/* y = silu(bn(z)) (+ residual), training-mode BatchNorm with batch statistics taken from `stats`
+ * ([replicas][2][C] sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
+ * save[1][c]=invstd for the backward and updates running_mean / running_var (unbiased) / num_batches_tracked
+ * (momentum, eps: yolox_24p/exp/yolox_base.py:58-62).  act: 1 = SiLU, 0 = identity. */
+int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, int stats_replicas, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                    float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res,
+                    int64_t M, int C, float eps, float momentum, int act, void* stream);
+
+/* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)). */
+int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                           const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                           int64_t M, int C, int act, void* stream);
+/* pass 2: dz = gamma*invstd*(du - dbeta/M - zhat*dgamma/M)  -> bf16 [M,C] (ld_dz). */
+int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                          const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
+                          void* dz, int64_t ld_dz, int64_t M, int C, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1/a2  glue ops of the graph
+ * ------------------------------------------------------------------------------------------------ */
+/* Focus + im2col for the 3x3 stem: images [B,3,S,S] fp32 NCHW -> rows [B*(S/2)^2][128] bf16, columns
+ * (kh,kw,c4) with c4 = TL,BL,TR,BR x 3 channels, 108 real + 20 zero (network_blocks.py:188-210). */
+int ep24_stem_pack(const float* images, void* rows, int B, int S, void* stream);
+
+/* SPP max pools k = 5, 9, 13, stride 1, pad k/2 over x[B,H,W,C] (network_blocks.py:131-143).  Writes the
+ * three pooled maps into y5/y9/y13 (row stride ld_y) and the winning window offset (dy*16+dx biased by 8)
+ * into idx [3][B*H*W][C] uint8 for the backward (first maximum in row-major window order, as ATen). */
+int ep24_spp_fwd(const void* x, int64_t ld_x, void* y5, void* y9, void* y13, int64_t ld_y, uint8_t* idx,
+                 int B, int H, int W, int C, void* stream);
+/* dx (+)= routed gradients of the three pools. */
+int ep24_spp_bwd(const void* dy5, const void* dy9, const void* dy13, int64_t ld_dy, const uint8_t* idx,
+                 void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C, void* stream);
+
+/* nearest x2 upsample into a slice (yolo_pafpn.py:32) and its backward (sum of the 2x2 block). */
+int ep24_upsample2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream);
+int ep24_upsample2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate,
+                       int B, int H, int W, int C, void* stream);
+
+/* hipMemsetAsync(p, 0, bytes) on the stream (step-start clearing of gradient / statistics buffers). */
+int ep24_memset_zero(void* p, int64_t bytes, void* stream);
+
+/* strided row copy / add:  dst[m, 0:C] (=|+=) src[m, 0:C]  (bf16). */
+int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int accumulate, int64_t M, int C,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  head decode (yolox_24p/models/yolo_head_24p.py:212-237)
+ * ------------------------------------------------------------------------------------------------ */
+/* in place on out[B,A,107] fp32 rows of one level (anchor offset a0, HxW cells, stride s):
+ * xy=(t+grid)*s, r=exp(t)*s, obj/cls logits untouched. */
+int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream);
+/* backward through the decode for one level + split into the padded bf16 gradients the prediction convs
+ * consume: d_regobj [B*H*W][64] (26 reg + 1 obj + zeros), d_cls [B*H*W][128] (80 + zeros). */
+int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
+                         int H, int W, float stride, int ncols, void* stream);
+/* bias gradient: db[n] += sum_m g[m][n] for n < N (bf16 rows of stride ld). */
+int ep24_colsum(const void* g, int64_t ld, float* db, int64_t M, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a4-a8  SimOTA assignment, batched over images, no host synchronisation
+ *        (yolox_24p/models/losses.py:360-592, yolox_24p/utils/boxes.py:102-243)
+ * ------------------------------------------------------------------------------------------------ */
+/* a4+a5 (pts_in_poly + get_in_boxes_info, losses.py:497-592).  labels [B,50,51] fp32; xs/ys/strides [A].
+ * Out: num_gt[B] int32 (rows with sum>0, losses.py:190), in_box[B*A], in_ctr[B*A] uint64 bitmasks over GTs. */
+int ep24_assign_candidates(const float* labels, const float* xs, const float* ys, const float* strides,
+                           int32_t* num_gt, uint64_t* in_box, uint64_t* in_ctr, int B, int A, void* stream);
+/* a6+a7 (bboxes_iou + class cost + total cost, boxes.py:166-243, losses.py:396-424) for every candidate
+ * anchor: pw[B,50,A] and cost[B,50,A] fp32 (entries of non-candidate anchors / g >= num_gt are untouched). */
+int ep24_assign_cost(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
+                     const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
+                     int num_classes, void* stream);
+/* a8 part 1 (dynamic_k_matching, losses.py:449-464): per (image, gt) top-10 pw sum -> k, the k cheapest
+ * candidates are OR-ed into match[B*A] (uint64 bit g).  match must be zeroed by the caller; ks[B,50] out. */
+int ep24_dynamic_k(const float* pw, const float* cost, const int32_t* num_gt, const uint64_t* in_box,
+                   const uint64_t* in_ctr, uint64_t* match, int32_t* ks, int B, int A, void* stream);
+/* a8 part 2 (losses.py:471-493): conflicts -> argmin cost, final fg mask, matched gt index (-1 = bg),
+ * matched pairwise value. */
+int ep24_assign_resolve(const uint64_t* match, const float* pw, const float* cost, const int32_t* num_gt,
+                        int32_t* matched_gt, float* matched_iou, int B, int A, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a9+a10  losses and their gradient (yolox_24p/models/losses.py:80-157, :283-357)
+ * ------------------------------------------------------------------------------------------------ */
+/* per-block partial sums of the 24 circle-GIoU terms (matched rows), obj BCE (all anchors), cls BCE
+ * (matched rows), num_fg; partials [nblocks][EP24_NUM_SUMS]; nblocks = ep24_loss_blocks(B, A). */
+int ep24_loss_blocks(int B, int A);
+int ep24_loss_terms(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
+                    const float* matched_iou, float* partials, int B, int A, int num_classes, void* stream);
+/* fixed-order reduction of the partials, dynamic task weights and state update (losses.py:286-345).
+ * state[26] = last_{iou[24],obj,cls} (initialise to 1.0).  result[64]:
+ *   [0] loss  [1..24] reg_w*loss_iou  [25] loss_obj  [26] loss_cls  [27] num_fg (clamped >= 1)
+ *   [28] num_gts  [29..52] reg_w  [53] obj_w  [54] cls_w  [55] num_fg raw */
+int ep24_loss_finalize(const float* partials, int nblocks, const int32_t* num_gt, int B, float* state, float* result,
+                       void* stream);
+/* d loss / d outputs [B,A,ncols] fp32, scaled by *grad_scale (device scalar, may be null = 1). */
+int ep24_loss_grad(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
+                   const float* matched_iou, const float* result, const float* grad_scale, float* dout, int B, int A,
+                   int num_classes, void* stream);
+
+/* stand-alone forms behind utils.bboxes_iou (boxes.py:166-243) and IOUloss.forward (losses.py:80-157) */
+int ep24_circle_pairwise(const float* gt50, const float* pred26, float* out, int G, int P, void* stream);
+int ep24_circle_matched_fwd(const float* pred26, const float* target50, float* loss24, int N, void* stream);
+int ep24_circle_matched_bwd(const float* pred26, const float* target50, const float* dloss24, float* dpred26, int N,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a11  optimizer (yolox_24p/exp/yolox_base.py:120-124: SGD momentum 0.9 nesterov, no decay)
+ * ------------------------------------------------------------------------------------------------ */
+/* flat fp32 p/g/buf of n elements: buf = first ? g : m*buf+g ; p -= lr*(g + m*buf); g is scaled by
+ * grad_scale first (1/world for data parallel means).  `first` is read from *first_flag (device int32),
+ * which is cleared afterwards. */
+int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float grad_scale,
+                      int32_t* first_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a13  fisheye sector warp (yolox/demo_featuremap.py:244-328)
+ * ------------------------------------------------------------------------------------------------ */
+/* The host mirror computes the 1-D tables exactly as the reference does (np.linspace / np.cos / np.sin,
+ * demo_featuremap.py:258-283) and the crop box; the O(13200*T) part runs here.
+ * winner[y*canvas_w+x] = max over (angle a, radius r) pairs landing on canvas pixel (y,x) of a*T+r, i.e. the
+ * LAST writer of the reference's fancy-index scatter (:295-298).  Caller initialises winner to -1.
+ * cos_tab/sin_tab [n_ang] and rho [T] are device float64. */
+int ep24_sector_map(const double* cos_tab, const double* sin_tab, int n_ang, const double* rho, int T, int canvas_w,
+                    int canvas_h, int32_t* winner, void* stream);
+/* Crop [y0:y0+out_h, x0:x0+out_w] of the canvas (:301-306): dst [out_h][out_w][3] uint8 gathered from
+ * src [T][n_ang][3] through the winner map, `fill` where nothing landed (114 image / 0 mask).  If src_index
+ * is non-null the flat source index (row*n_ang+col, -1 = fill) is written too. */
+int ep24_sector_gather(const uint8_t* src, const int32_t* winner, int canvas_w, int y0, int x0, int out_h, int out_w,
+                       int T, int n_ang, uint8_t* dst, int fill, int32_t* src_index, void* stream);
+/* bounding box of the non-zero pixels of channel 0 (:309-326): box = {xmin,ymin,xmax,ymax}; caller initialises
+ * it to {INT_MAX,INT_MAX,-1,-1}. */
+int ep24_mask_bbox(const uint8_t* mask3, int out_h, int out_w, int32_t* box, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EP24_H */

@@ -1,0 +1,192 @@
+"""Oracle: fp32 torch-CPU YOLOX-24p network.  Test infrastructure only.
+
+A compact restatement of the reference graph with the reference's state-dict key names, so golden weights
+load by name:
+  conv-BN-act block / Focus / Bottleneck / CSP / SPP   yolox_24p/models/network_blocks.py:29-210
+  CSPDarknet(dep_mul, wid_mul)                          yolox_24p/models/darknet.py:95-177
+  PAFPN neck                                            yolox_24p/models/yolo_pafpn.py:27-124
+  decoupled 24p head + train-mode decode                yolox_24p/models/yolo_head_24p.py:47-237
+  factory (BN eps 1e-3 / momentum 0.03, prior bias)     yolox_24p/exp/yolox_base.py:55-72
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Unit(nn.Module):
+    """conv (no bias) -> BatchNorm -> SiLU; attribute names conv / bn as in BaseConv."""
+
+    def __init__(self, cin, cout, k, s=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=False)
+        self.bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.03)
+
+    def forward(self, x):
+        return F.silu(self.bn(self.conv(x)))
+
+
+class Stem(nn.Module):
+    """Focus: 2x2 space-to-depth in the order TL, BL, TR, BR, then a conv unit (network_blocks.py:188-210)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = Unit(4 * cin, cout, k)
+
+    def forward(self, x):
+        parts = [x[..., 0::2, 0::2], x[..., 1::2, 0::2], x[..., 0::2, 1::2], x[..., 1::2, 1::2]]
+        return self.conv(torch.cat(parts, 1))
+
+
+class Res(nn.Module):
+    def __init__(self, c, add):
+        super().__init__()
+        self.conv1 = Unit(c, c, 1)
+        self.conv2 = Unit(c, c, 3)
+        self.add = add
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + x if self.add else y
+
+
+class CSP(nn.Module):
+    def __init__(self, cin, cout, n, add=True):
+        super().__init__()
+        h = int(cout * 0.5)
+        self.conv1 = Unit(cin, h, 1)
+        self.conv2 = Unit(cin, h, 1)
+        self.conv3 = Unit(2 * h, cout, 1)
+        self.m = nn.Sequential(*[Res(h, add) for _ in range(n)])
+
+    def forward(self, x):
+        return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), 1))
+
+
+class SPP(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = Unit(cin, cin // 2, 1)
+        self.conv2 = Unit(cin // 2 * 4, cout, 1)
+
+    def forward(self, x):
+        x = self.conv1(x)
+        return self.conv2(torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)], 1))
+
+
+class Backbone(nn.Module):
+    def __init__(self, depth, width):
+        super().__init__()
+        c = int(width * 64)
+        d = max(round(depth * 3), 1)
+        self.stem = Stem(3, c, 3)
+        self.dark2 = nn.Sequential(Unit(c, 2 * c, 3, 2), CSP(2 * c, 2 * c, d))
+        self.dark3 = nn.Sequential(Unit(2 * c, 4 * c, 3, 2), CSP(4 * c, 4 * c, 3 * d))
+        self.dark4 = nn.Sequential(Unit(4 * c, 8 * c, 3, 2), CSP(8 * c, 8 * c, 3 * d))
+        self.dark5 = nn.Sequential(Unit(8 * c, 16 * c, 3, 2), SPP(16 * c, 16 * c), CSP(16 * c, 16 * c, d, add=False))
+
+    def forward(self, x):
+        x = self.dark2(self.stem(x))
+        c3 = self.dark3(x)
+        c4 = self.dark4(c3)
+        return c3, c4, self.dark5(c4)
+
+
+class Neck(nn.Module):
+    def __init__(self, depth, width, in_channels=(256, 512, 1024)):
+        super().__init__()
+        c3, c4, c5 = [int(c * width) for c in in_channels]
+        n = round(3 * depth)
+        self.backbone = Backbone(depth, width)
+        self.lateral_conv0 = Unit(c5, c4, 1)
+        self.C3_p4 = CSP(2 * c4, c4, n, add=False)
+        self.reduce_conv1 = Unit(c4, c3, 1)
+        self.C3_p3 = CSP(2 * c3, c3, n, add=False)
+        self.bu_conv2 = Unit(c3, c3, 3, 2)
+        self.C3_n3 = CSP(2 * c3, c4, n, add=False)
+        self.bu_conv1 = Unit(c4, c4, 3, 2)
+        self.C3_n4 = CSP(2 * c4, c5, n, add=False)
+
+    def forward(self, x):
+        x2, x1, x0 = self.backbone(x)
+        f0 = self.lateral_conv0(x0)
+        p4 = self.C3_p4(torch.cat([F.interpolate(f0, scale_factor=2, mode="nearest"), x1], 1))
+        f1 = self.reduce_conv1(p4)
+        out2 = self.C3_p3(torch.cat([F.interpolate(f1, scale_factor=2, mode="nearest"), x2], 1))
+        out1 = self.C3_n3(torch.cat([self.bu_conv2(out2), f1], 1))
+        out0 = self.C3_n4(torch.cat([self.bu_conv1(out1), f0], 1))
+        return out2, out1, out0
+
+
+class Head(nn.Module):
+    def __init__(self, num_classes, width, in_channels=(256, 512, 1024), strides=(8, 16, 32)):
+        super().__init__()
+        h = int(256 * width)
+        self.num_classes = num_classes
+        self.strides = strides
+        self.stems = nn.ModuleList(Unit(int(c * width), h, 1) for c in in_channels)
+        self.cls_convs = nn.ModuleList(nn.Sequential(Unit(h, h, 3), Unit(h, h, 3)) for _ in in_channels)
+        self.reg_convs = nn.ModuleList(nn.Sequential(Unit(h, h, 3), Unit(h, h, 3)) for _ in in_channels)
+        self.cls_preds = nn.ModuleList(nn.Conv2d(h, num_classes, 1) for _ in in_channels)
+        self.reg_preds = nn.ModuleList(nn.Conv2d(h, 26, 1) for _ in in_channels)
+        self.obj_preds = nn.ModuleList(nn.Conv2d(h, 1, 1) for _ in in_channels)
+        prior = -math.log((1 - 1e-2) / 1e-2)
+        for m in list(self.cls_preds) + list(self.obj_preds):
+            nn.init.constant_(m.bias, prior)
+
+    def forward(self, feats, train=False):
+        outs, xs, ys, ss = [], [], [], []
+        for k, x in enumerate(feats):
+            x = self.stems[k](x)
+            cf = self.cls_convs[k](x)
+            rf = self.reg_convs[k](x)
+            reg, obj, cls = self.reg_preds[k](rf), self.obj_preds[k](rf), self.cls_preds[k](cf)
+            if not train:
+                outs.append(torch.cat([reg, obj.sigmoid(), cls.sigmoid()], 1).flatten(2))
+                continue
+            o = torch.cat([reg, obj, cls], 1)
+            B, C, H, W = o.shape
+            o = o.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            yv, xv = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            grid = torch.stack((xv, yv), 2).reshape(1, -1, 2).to(o.dtype)
+            s = self.strides[k]
+            o = torch.cat([(o[..., :2] + grid) * s, torch.exp(o[..., 2:26]) * s, o[..., 26:]], -1)
+            outs.append(o)
+            xs.append(grid[:, :, 0])
+            ys.append(grid[:, :, 1])
+            ss.append(torch.full((1, H * W), float(s)))
+        if train:
+            return xs, ys, ss, torch.cat(outs, 1), []
+        hw = [(f.shape[-2], f.shape[-1]) for f in feats]
+        o = torch.cat(outs, 2).permute(0, 2, 1)
+        grids, strides = [], []
+        for (H, W), s in zip(hw, self.strides):
+            yv, xv = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            grids.append(torch.stack((xv, yv), 2).reshape(1, -1, 2))
+            strides.append(torch.full((1, H * W, 1), float(s)))
+        grids, strides = torch.cat(grids, 1).to(o.dtype), torch.cat(strides, 1).to(o.dtype)
+        return torch.cat([(o[..., :2] + grids) * strides, torch.exp(o[..., 2:26]) * strides, o[..., 26:]], -1)
+
+
+class Net(nn.Module):
+    def __init__(self, depth=1.0, width=1.0, num_classes=80):
+        super().__init__()
+        self.backbone = Neck(depth, width)
+        self.head = Head(num_classes, width)
+
+    def forward(self, x, train=False):
+        return self.head(self.backbone(x), train)
+
+
+def sgd_nesterov_step(params, bufs, lr, momentum=0.9):
+    """torch.optim.SGD(momentum, nesterov=True, no decay) update (yolox_base.py:120-124):
+    buf = m*buf + g (buf = g on the first step); p -= lr*(g + m*buf)."""
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            g = p.grad
+            if bufs[i] is None:
+                bufs[i] = g.clone()
+            else:
+                bufs[i].mul_(momentum).add_(g)
+            p.add_(g + momentum * bufs[i], alpha=-lr)

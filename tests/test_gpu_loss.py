@@ -1,0 +1,161 @@
+"""GPU parity: HIP loss path (through the C ABI) vs the golden vectors and vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from ep24 import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ep24 import loss
+    return loss
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_pairwise_vs_golden(L, golden, tag):
+    z = golden("g2_pairwise_" + tag)
+    out = L.bboxes_iou(t(z["a"]).to(DEV), t(z["b"]).to(DEV)).cpu()
+    torch.testing.assert_close(out, t(z["out"]), rtol=2e-5, atol=2e-6)
+
+
+def test_pairwise_full_size_vs_golden_and_oracle(L, golden):
+    from oracle import geometry
+    z = golden("g2_pairwise_d")
+    G, P = int(z["G"]), int(z["P"])
+    a = synth.make_labels(1, G, seed=int(z["label_seed"]))[0, :G, 1:]
+    dec = synth.decode_head(synth.make_raw_head(1, seed=int(z["head_seed"])))[0]
+    idx = torch.randperm(dec.shape[0], generator=torch.Generator().manual_seed(int(z["sel_seed"])))[:P].sort().values
+    b = dec[idx, :26].contiguous()
+    out = L.bboxes_iou(a.to(DEV), b.to(DEV)).cpu()
+    torch.testing.assert_close(out[:, ::7], t(z["out_sub"]), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(out, geometry.pairwise(a, b), rtol=2e-5, atol=2e-6)
+    assert abs(float(out.double().sum()) - float(z["out_sum"])) < 1e-5 * float(z["out_sum"])
+
+
+def test_pairwise_edge_cases(L):
+    with pytest.raises(IndexError):
+        L.bboxes_iou(torch.zeros(2, 49, device=DEV), torch.zeros(2, 26, device=DEV))
+    assert L.bboxes_iou(torch.zeros(0, 50, device=DEV), torch.zeros(5, 26, device=DEV)).shape == (0, 5)
+    assert L.bboxes_iou(torch.zeros(3, 50, device=DEV), torch.zeros(0, 26, device=DEV)).shape == (3, 0)
+
+
+def test_matched_loss_and_grad_vs_golden(L, golden):
+    z = golden("g3_matched")
+    pred = t(z["pred"]).to(DEV).requires_grad_(True)
+    iou = L.IOUloss("none")
+    loss24, draw = iou(pred, t(z["target"]).to(DEV))
+    torch.testing.assert_close(loss24.detach().cpu(), t(z["loss24"]), rtol=2e-5, atol=2e-6)
+    (loss24 * t(z["w"]).to(DEV)).sum().backward()
+    got, want = pred.grad.cpu(), t(z["grad"])
+    assert torch.equal(torch.isnan(got), torch.isnan(want))          # d == 0 rows: NaN centre gradient, as the reference
+    torch.testing.assert_close(torch.nan_to_num(got), torch.nan_to_num(want), rtol=2e-3, atol=2e-6)
+    e_loss, e_draw = iou(pred[:0], t(z["target"]).to(DEV)[:0])
+    assert e_loss.shape == (1, 24) and float(e_loss.abs().sum()) == 0.0 and e_draw[0].shape == (1, 24)
+    with pytest.raises(IndexError):
+        iou(torch.zeros(2, 25, device=DEV), torch.zeros(2, 50, device=DEV))
+
+
+@pytest.mark.parametrize("tag", ["convex", "star"])
+def test_candidate_masks_vs_golden(L, golden, tag):
+    from ep24._lib import call, ptr, stream_ptr
+    z = golden("g4_masks_" + tag)
+    G = int(z["G"])
+    labels = synth.make_labels(1, G, seed=int(z["label_seed"]), star=bool(z["star"])).to(DEV)
+    xs, ys, ss = [v.to(DEV) for v in synth.anchor_grid()]
+    A = xs.numel()
+    ws = L.LossWorkspace(1, A, 80, DEV)
+    call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(ss), ptr(ws.num_gt), ptr(ws.masks[0]), ptr(ws.masks[1]),
+         1, A, stream_ptr())
+    assert int(ws.num_gt[0]) == G
+    mb, mc = ws.masks[0, 0].cpu().numpy().astype(np.uint64), ws.masks[1, 0].cpu().numpy().astype(np.uint64)
+    in_box = np.stack([(mb >> np.uint64(g)) & np.uint64(1) for g in range(G)]).astype(bool)
+    in_ctr = np.stack([(mc >> np.uint64(g)) & np.uint64(1) for g in range(G)]).astype(bool)
+    assert np.array_equal(in_box, z["in_box"])
+    fg = (mb | mc) != 0
+    assert np.array_equal(fg, z["fg"])
+    assert np.array_equal((in_box & in_ctr)[:, fg], z["in_both"])
+
+
+def _run_loss(L, lf, outputs, labels):
+    outputs = outputs.to(DEV).requires_grad_(True)
+    tup = lf(synth.outputs_train_tuple(outputs), labels.to(DEV))
+    tup[0].backward()
+    return tup, outputs.grad
+
+
+def test_loss_two_calls_vs_golden(L, golden):
+    z = golden("g6_loss")
+    B = int(z["B"])
+    counts = [int(c) for c in z["counts"]]
+    labels = synth.make_labels(B, counts, seed=int(z["label_seed"]))
+    raw = synth.make_raw_head(B, seed=int(z["head_seed"]))
+    lf = L.Loss_Function(80)
+    for call_i in range(2):
+        p = "c%d_" % call_i
+        outputs = synth.decode_head(raw if call_i == 0 else raw * 0.98 + 0.01)
+        tup, grad = _run_loss(L, lf, outputs, labels)
+        for b in range(B):
+            cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, b)
+            if counts[b] == 0:
+                assert nfg == 0
+                continue
+            # bit-exact assignment indices
+            assert nfg == int(z[p + "img%d_nfg" % b])
+            assert torch.equal(fg.cpu(), t(z[p + "img%d_fg" % b]))
+            assert torch.equal(gt_idx.cpu(), t(z[p + "img%d_gt" % b]))
+            assert torch.equal(cls_m.cpu(), t(z[p + "img%d_cls" % b]))
+            torch.testing.assert_close(ious.cpu(), t(z[p + "img%d_pious" % b]), rtol=2e-5, atol=2e-6)
+        # fp32 loss within 1e-4 relative (north star)
+        for k, v in (("loss", tup[0]), ("loss_iou_w", tup[1]), ("loss_obj", tup[2]), ("loss_cls", tup[3]),
+                     ("reg_w", tup[6][3]), ("obj_w", tup[6][4]), ("cls_w", tup[6][5]), ("draw_cx", tup[6][0]),
+                     ("draw_r", tup[6][2])):
+            torch.testing.assert_close(v.detach().cpu(), t(z[p + k]), rtol=1e-4, atol=1e-6)
+        assert tup[4] == float(z[p + "loss_l1"])
+        assert abs(float(tup[5]) - float(z[p + "fg_per_gt"])) < 1e-6
+        g = grad.cpu()
+        rows = t(z[p + "grad_rows"])
+        torch.testing.assert_close(g.reshape(-1, g.shape[-1])[rows], t(z[p + "grad_vals"]), rtol=2e-3, atol=2e-7)
+        torch.testing.assert_close(g[..., 26].reshape(-1)[::5], t(z[p + "grad_obj"]), rtol=1e-4, atol=1e-9)
+        assert abs(float(g.double().abs().sum()) - float(z[p + "grad_abs_sum"])) < 1e-4 * float(z[p + "grad_abs_sum"])
+
+
+def test_assignment_g50_vs_golden(L, golden):
+    z = golden("g5_assign_g50")
+    labels = synth.make_labels(1, 50, seed=int(z["label_seed"]))
+    outputs = synth.decode_head(synth.make_raw_head(1, seed=int(z["head_seed"])))
+    lf = L.Loss_Function(80)
+    tup, _ = _run_loss(L, lf, outputs, labels)
+    cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, 0)
+    assert nfg == int(z["nfg"])
+    assert torch.equal(fg.cpu(), t(z["fg"])) and torch.equal(gt_idx.cpu(), t(z["gt"])) and torch.equal(cls_m.cpu(), t(z["cls"]))
+    torch.testing.assert_close(tup[0].detach().cpu(), t(z["loss"]), rtol=1e-4, atol=1e-6)
+
+
+def test_full_batch_vs_oracle():
+    """BASELINE config-2 loss sizes (B=20, 8400 anchors, 10 GTs): every image's assignment equals the oracle's."""
+    from ep24 import loss as L
+    from oracle.loss import LossOracle
+    B = 20
+    labels = synth.make_labels(B, 10, seed=101)
+    outputs = synth.decode_head(synth.make_raw_head(B, seed=102))
+    lf = L.Loss_Function(80)
+    tup, grad = _run_loss(L, lf, outputs, labels)
+    ora = LossOracle(80)
+    o_out = outputs.clone().requires_grad_(True)
+    o_tup = ora(synth.outputs_train_tuple(o_out), labels)
+    o_tup[0].backward()
+    for b in range(B):
+        cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, b)
+        o_cls, o_fg, o_ious, o_idx, o_nfg = ora.trace[b]
+        assert nfg == o_nfg and torch.equal(fg.cpu(), o_fg) and torch.equal(gt_idx.cpu(), o_idx)
+    torch.testing.assert_close(tup[0].detach().cpu(), o_tup[0].detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tup[1].detach().cpu(), o_tup[1].detach(), rtol=1e-4, atol=1e-6)
+    g, og = grad.cpu(), o_out.grad
+    assert float((g - og).abs().max()) <= 2e-3 * float(og.abs().max())
+    # gradient is zero exactly where the oracle's is (background anchors, reg/cls columns)
+    assert torch.equal(g[..., :26] != 0, og[..., :26] != 0)
