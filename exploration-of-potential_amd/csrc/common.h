@@ -49,4 +49,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// BatchNorm statistics are accumulated across workgroups as 2^-20 fixed point in int64 atomics: integer
+// addition is associative, so the batch statistics (and with them the whole forward pass) are bitwise
+// reproducible whatever order the workgroups retire in.  |sum| < 2^43 in real units.
+#define EP24_FIX_SCALE 1048576.0f
+__device__ __forceinline__ long long to_fix(float v) { return (long long)__float2ll_rn(v * EP24_FIX_SCALE); }
+__device__ __forceinline__ float from_fix(long long v) { return (float)((double)v * (1.0 / 1048576.0)); }
+
 static inline int ep24_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

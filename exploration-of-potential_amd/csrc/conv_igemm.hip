@@ -24,7 +24,7 @@ struct IgemmArgs {
     void* dst; long ld_dst; int DH, DW, dsy, dsx, dy0, dx0; long dbs, dp0;   // dst pixel = n*dbs + dp0 + (gy*dsy+dy0)*DW + gx*dsx+dx0
     int accumulate;
     const float* bias;
-    float* stats; int stats_replicas;
+    long long* stats; int stats_replicas;
     long M;
 };
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         brow_l[i] = (r & ~63) + ((r & 3) << 4) + ((r >> 2) & 15);
     }
 
-    const int KC = p.K / BK;
+    const int KC = (p.K + BK - 1) / BK;          // K is a multiple of 8; the last 64-chunk may be partial
     const int n_iter = p.T * KC;
     bf16x8 ra[4], rb[B_PIECES];
 
@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         const int t = it / KC;
         const int kc = it - t * KC;
         const int oy = p.oy[t], ox = p.ox[t];
+        const bool kok = kc * BK + chunk * 8 < p.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int iy = iy0[i] + oy, ix = ix0[i] + ox;
-            bool ok = rvalid[i] && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
+            bool ok = kok && rvalid[i] && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ok) {
                 const bf16* s = p.src + ((long)(pixbase[i] + iy * p.SW + ix)) * p.ld_src + kc * BK + chunk * 8;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) {
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
+            if (kok && brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
             rb[i] = v;
         }
     };
@@ -209,15 +210,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
     if (p.stats) {
         // rows >= M contributed nothing (skipped above); reduce the 4 lane groups that share a channel
-        float* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a = s1[j], b = s2[j];
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             if (fq == 0 && c0 + j < p.N) {
-                atomicAdd(st + c0 + j, a);
-                atomicAdd(st + p.N + c0 + j, b);
+                atomicAdd((unsigned long long*)(st + c0 + j), (unsigned long long)to_fix(a));
+                atomicAdd((unsigned long long*)(st + p.N + c0 + j), (unsigned long long)to_fix(b));
             }
         }
     }
@@ -241,11 +242,11 @@ int launch(const IgemmArgs& a, bool out_f32, hipStream_t stream) {
 }  // namespace
 
 extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
-                                  int64_t y_batch_rows, int64_t y_row0, const float* bias, float* stats,
+                                  int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,
                                   int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                                   void* stream) {
     EP24_REQUIRE(x && w && y, EP24_E_ARG, "conv_fwd: null pointer");
-    EP24_REQUIRE(Cin % 64 == 0 && Cin > 0, EP24_E_ARG, "conv_fwd: Cin=%d must be a multiple of 64", Cin);
+    EP24_REQUIRE(Cin % 8 == 0 && Cin > 0, EP24_E_ARG, "conv_fwd: Cin=%d must be a multiple of 8", Cin);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
                  "conv_fwd: k=%d s=%d unsupported", ksize, stride);
     EP24_REQUIRE(ld_x % 8 == 0 && (y_f32 || ld_y % 4 == 0), EP24_E_ARG, "conv_fwd: ld_x %% 8 / ld_y %% 4 alignment");
@@ -260,7 +261,7 @@ extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, vo
     a.wt = (const bf16*)w; a.WT = a.T; a.K = Cin; a.N = Cout;
     a.dst = y; a.ld_dst = ld_y; a.DH = OH; a.DW = OW; a.dsy = a.dsx = 1; a.dy0 = a.dx0 = 0;
     a.dbs = y_batch_rows > 0 ? y_batch_rows : (long)OH * OW; a.dp0 = y_row0;
-    a.accumulate = 0; a.bias = bias; a.stats = stats; a.stats_replicas = stats ? stats_replicas : 1;
+    a.accumulate = 0; a.bias = bias; a.stats = (long long*)stats; a.stats_replicas = stats ? stats_replicas : 1;
     a.M = (long)B * OH * OW;
     return launch(a, y_f32 != 0, (hipStream_t)stream);
 }
@@ -269,7 +270,7 @@ extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* w
                                     int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
                                     void* stream) {
     EP24_REQUIRE(dy && wt && dx, EP24_E_ARG, "conv_dgrad: null pointer");
-    EP24_REQUIRE(Cout_k % 64 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 64", Cout_k);
+    EP24_REQUIRE(Cout_k % 8 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 8", Cout_k);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
                  "conv_dgrad: k=%d s=%d unsupported", ksize, stride);
     EP24_REQUIRE(ld_dy % 8 == 0 && ld_dx % 4 == 0, EP24_E_ARG, "conv_dgrad: ld alignment");

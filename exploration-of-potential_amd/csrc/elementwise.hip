@@ -25,7 +25,7 @@ struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by
 };
 
 // ---------------------------------------------------------------------------------------- BN + act forward
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const float* stats, int reps,
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const long long* stats, int reps,
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, long* nbt, float* save, bf16* y, long ld_y,
                                                          const bf16* res, long ld_res, long M, int C, float eps,
@@ -39,13 +39,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cg * 8 + j;
-            float s1 = 0.f, s2 = 0.f;
+            long long i1 = 0, i2 = 0;
             for (int r = 0; r < reps; ++r) {
-                s1 += stats[(long)r * 2 * C + c];
-                s2 += stats[(long)r * 2 * C + C + c];
+                i1 += stats[(long)r * 2 * C + c];
+                i2 += stats[(long)r * 2 * C + C + c];
             }
-            const float mean = s1 / (float)M;
-            float var = s2 / (float)M - mean * mean;
+            const float mean = from_fix(i1) / (float)M;
+            float var = from_fix(i2) / (float)M - mean * mean;
             var = var < 0.f ? 0.f : var;
             const float invstd = rsqrtf(var + eps);
             sc[j] = gamma[c] * invstd;
@@ -98,8 +98,8 @@ __device__ __forceinline__ void du_zhat(const float (&dy)[8], const float (&z)[8
 
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                 const float* save, const float* gamma,
-                                                                const float* beta, float* dgamma, float* dbeta, long M,
-                                                                int C, int act) {
+                                                                const float* beta, long long* dgamma, long long* dbeta,
+                                                                long M, int C, int act) {
     __shared__ float red[2][256][8 + 1];
     const RowMap rm(C);
     const int tid = threadIdx.x;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
             for (int j = 0; j < 8; ++j) {
                 float a = 0.f, b2 = 0.f;
                 for (int s = 0; s < rm.rpb; ++s) { a += red[0][s * rm.tpr + (tid % rm.tpr)][j]; b2 += red[1][s * rm.tpr + (tid % rm.tpr)][j]; }
-                atomicAdd(dgamma + cg * 8 + j, a);
-                atomicAdd(dbeta + cg * 8 + j, b2);
+                atomicAdd((unsigned long long*)(dgamma + cg * 8 + j), (unsigned long long)to_fix(a));
+                atomicAdd((unsigned long long*)(dbeta + cg * 8 + j), (unsigned long long)to_fix(b2));
             }
         }
         __syncthreads();
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma, const float* beta,
-                                                               const float* dgamma, const float* dbeta, bf16* dz,
-                                                               long ld_dz, long M, int C, int act) {
+                                                               const long long* dgamma, const long long* dbeta, float* ggrad,
+                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C, int act) {
     const RowMap rm(C);
     const int tid = threadIdx.x;
     const float invM = 1.f / (float)M;
@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
         for (int j = 0; j < 8; ++j) {
             const int c = cg * 8 + j;
             mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
-            mg[j] = dgamma[c] * invM; mb[j] = dbeta[c] * invM;
+            const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
+            mg[j] = sg_ * invM; mb[j] = sb_ * invM;
+            if (blockIdx.x == 0 && slot == 0 && ggrad) {      // publish this call's sums into the parameter gradients
+                ggrad[c] += sg_;
+                bgrad[c] += sb_;
+            }
         }
         for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
             float vdy[8], vz[8], du[8], zh[8], o[8];
@@ -178,12 +183,13 @@ int row_grid(long M, int C) {
 }
 
 // ---------------------------------------------------------------------------------------- stem packing
-__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* rows, int B, int S) {
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* rows, int B, int S, int ld) {
     const int F = S >> 1;
-    const long total = (long)B * F * F * 16;
+    const int chunks = ld >> 3;
+    const long total = (long)B * F * F * chunks;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int chunk = (int)(i & 15);
-        const long pix = i >> 4;
+        const int chunk = (int)(i % chunks);
+        const long pix = i / chunks;
         const int n = (int)(pix / (F * F));
         const int rem = (int)(pix - (long)n * F * F);
         const int oy = rem / F, ox = rem - oy * F;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* 
             }
             o[j] = (bf16)v;
         }
-        *reinterpret_cast<bf16x8*>(rows + pix * 128 + chunk * 8) = o;
+        *reinterpret_cast<bf16x8*>(rows + pix * ld + chunk * 8) = o;
     }
 }
 
@@ -394,16 +400,19 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int 
 
 __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* dout, const float* out, bf16* d_regobj, bf16* d_cls,
                                                          int B, int A, int a0, int H, int W, float s, int ncols) {
-    // one thread per (cell, 8-column chunk) of the 64 + 128 padded gradient columns
-    const long total = (long)B * H * W * 24;
+    // one thread per (cell, 8-column chunk): 4 chunks of the 32-wide reg+obj gradient, then ceil(C/8) class chunks
+    const int C = ncols - 27;
+    const int ld_cls = (C + 7) & ~7;
+    const int chunks = 4 + (ld_cls >> 3);
+    const long total = (long)B * H * W * chunks;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int chunk = (int)(i % 24);
-        const long cell = i / 24;
+        const int chunk = (int)(i % chunks);
+        const long cell = i / chunks;
         const int n = (int)(cell / (H * W));
         const int hw = (int)(cell - (long)n * H * W);
         const long row = ((long)n * A + a0 + hw) * ncols;
         bf16x8 o;
-        if (chunk < 8) {
+        if (chunk < 4) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = chunk * 8 + j;
@@ -413,15 +422,15 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* dout, cons
                 else if (c == 26) g = dout[row + 26];
                 o[j] = (bf16)g;
             }
-            *reinterpret_cast<bf16x8*>(d_regobj + cell * 64 + chunk * 8) = o;
+            *reinterpret_cast<bf16x8*>(d_regobj + cell * 32 + chunk * 8) = o;
         } else {
-            const int k = chunk - 8;
+            const int k = chunk - 4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = k * 8 + j;
-                o[j] = (bf16)((27 + c < ncols) ? dout[row + 27 + c] : 0.f);
+                o[j] = (bf16)(c < C ? dout[row + 27 + c] : 0.f);
             }
-            *reinterpret_cast<bf16x8*>(d_cls + cell * 128 + k * 8) = o;
+            *reinterpret_cast<bf16x8*>(d_cls + cell * ld_cls + k * 8) = o;
         }
     }
 }
@@ -494,7 +503,7 @@ int cap_grid(long work_items) {
 
 #define S_ (hipStream_t) stream
 
-extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, int reps, const float* gamma,
+extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int reps, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
                                float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res, int64_t M, int C,
                                float eps, float momentum, int act, void* stream) {
@@ -502,7 +511,7 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, 
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)z, ld_z, stats, reps, gamma,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
@@ -510,33 +519,35 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, 
 }
 
 extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int64_t M, int C,
+                                      const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, int64_t M, int C,
                                       int act, void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
     int grid = row_grid(M, C);
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
-                       save, gamma, beta, dgamma, dbeta, M, C, act);
+                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
 }
 
 extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                                     const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
-                                     void* dz, int64_t ld_dz, int64_t M, int C, int act, void* stream) {
+                                     const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                                     float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                                     void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
-                       (const bf16*)z, ld_z, save, gamma, beta, dgamma, dbeta, (bf16*)dz, ld_dz, M, C, act);
+                       (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
+                       (bf16*)dz, ld_dz, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
     return EP24_OK;
 }
 
-extern "C" int ep24_stem_pack(const float* images, void* rows, int B, int S, void* stream) {
-    EP24_REQUIRE(images && rows && S % 2 == 0 && B > 0, EP24_E_ARG, "stem_pack: bad arguments");
-    hipLaunchKernelGGL(stem_pack_kernel, dim3(cap_grid((long)B * (S / 2) * (S / 2) * 16)), dim3(256), 0, S_, images,
-                       (bf16*)rows, B, S);
+extern "C" int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int S, void* stream) {
+    EP24_REQUIRE(images && rows && S % 2 == 0 && B > 0 && ld >= 108 && ld % 8 == 0, EP24_E_ARG, "stem_pack: bad arguments");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(cap_grid((long)B * (S / 2) * (S / 2) * (ld / 8))), dim3(256), 0, S_, images,
+                       (bf16*)rows, B, S, (int)ld);
     EP24_LAUNCH_CHECK("ep24_stem_pack");
     return EP24_OK;
 }
@@ -594,9 +605,9 @@ extern "C" int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int
 
 extern "C" int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
                                     int H, int W, float stride, int ncols, void* stream) {
-    EP24_REQUIRE(dout && out && d_regobj && d_cls && a0 >= 0 && a0 + H * W <= A && ncols >= 27 && ncols <= 27 + 128, EP24_E_ARG,
+    EP24_REQUIRE(dout && out && d_regobj && d_cls && a0 >= 0 && a0 + H * W <= A && ncols > 27, EP24_E_ARG,
                  "head_decode_bwd: bad arguments");
-    hipLaunchKernelGGL(decode_bwd_kernel, dim3(cap_grid((long)B * H * W * 24)), dim3(256), 0, S_, dout, out, (bf16*)d_regobj,
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3(cap_grid((long)B * H * W * (4 + (ncols - 27 + 7) / 8))), dim3(256), 0, S_, dout, out, (bf16*)d_regobj,
                        (bf16*)d_cls, B, A, a0, H, W, stride, ncols);
     EP24_LAUNCH_CHECK("ep24_head_decode_bwd");
     return EP24_OK;

@@ -1,0 +1,570 @@
+"""Static execution plan of the YOLOX-24p network on one MI355X.
+
+The reference runs ``YOLOX.forward`` / autograd as ~131 cuDNN convs plus hundreds of small aten kernels
+(yolox_24p/models/yolox.py:24-34, yolo_pafpn.py:83-124, darknet.py:165-177, yolo_head_24p.py:143-237).
+Here the module tree is lowered ONCE per (batch, size) into two flat lists of C-ABI launches (forward,
+backward) over pre-allocated NHWC bf16 buffers:
+
+* every conv is the MFMA implicit GEMM (``ep24_conv_fwd_bf16`` / ``_dgrad`` / ``_wgrad``), BN batch statistics
+  are accumulated in the conv epilogue, BN-apply + SiLU (+ residual) is one streaming kernel that writes
+  straight into its consumer's concat slot (torch.cat never materialises);
+* gradients of activations live in mirror buffers; whether a producer overwrites or accumulates is decided
+  statically while the backward list is built, residual adds alias their gradient buffers;
+* all parameters live in ONE flat fp32 buffer (conv weights physically [Cout][kh][kw][Cin], i.e. torch
+  channels_last) with flat gradient / momentum twins, so the optimizer and the RCCL all-reduce are single
+  contiguous passes; ``nn.Parameter`` objects are re-homed as views so state_dict keys and shapes stay the
+  reference's.
+
+The lists contain no host synchronisation, no allocation and no shape-dependent Python, so a training step
+is captured into a hipGraph (``ep24.train.TrainStep``).
+"""
+import torch
+
+from . import _lib, nn as enn
+from ._lib import call, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+STATS_REPLICAS = 8
+STRIDES = (8, 16, 32)
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------ buffers
+class Buf:
+    """Row-major [rows, ld] bf16 buffer with a lazily created gradient twin."""
+
+    def __init__(self, dev, rows, ld):
+        self.rows, self.ld = rows, ld
+        self.t = torch.zeros(rows * ld, dtype=BF16, device=dev)
+        self.g = None
+        self.gwritten = []                       # channel intervals of the gradient already produced
+
+    def grad(self):
+        if self.g is None:
+            self.g = torch.zeros(self.rows * self.ld, dtype=BF16, device=self.t.device)
+        return self.g
+
+
+class Dyn:
+    """Launch argument resolved when the list RUNS (input / incoming-gradient pointers)."""
+
+    def __init__(self, table, key):
+        self.table, self.key = table, key
+
+    def get(self):
+        return self.table[self.key]
+
+
+class Act:
+    """Channel slice [c0, c0+C) of a Buf, viewed as an NHWC tensor [B,H,W,C]."""
+
+    def __init__(self, buf, c0, C, B, H, W):
+        self.buf, self.c0, self.C, self.B, self.H, self.W = buf, c0, C, B, H, W
+        self._alias = None                       # gradient shares storage with this Act's gradient
+        self.needs_grad = True
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    @property
+    def ld(self):
+        return self.buf.ld
+
+    def ptr(self):
+        return self.buf.t.data_ptr() + 2 * self.c0
+
+    def _groot(self):
+        a = self
+        while a._alias is not None:
+            a = a._alias
+        return a
+
+    @property
+    def gld(self):
+        return self._groot().buf.ld
+
+    def gptr(self):
+        r = self._groot()
+        return r.buf.grad().data_ptr() + 2 * r.c0
+
+    def slice(self, c0, C):
+        assert self._alias is None
+        return Act(self.buf, self.c0 + c0, C, self.B, self.H, self.W)
+
+    def alias_grad(self, other):
+        """d(self) shares storage with d(other): used by y = f(x) + x, where dx = dy + f'(...)."""
+        assert self.C == other.C and self._alias is None
+        self._alias = other
+
+    def _interval(self):
+        r = self._groot()
+        return r.buf.gwritten, r.c0, r.c0 + r.C
+
+    def gwrite(self):
+        """Called while the backward list is built: 0 = first producer (overwrite), 1 = accumulate."""
+        w, lo, hi = self._interval()
+        if any(a <= lo and hi <= b for a, b in w):
+            return 1
+        assert not any(not (hi <= a or b <= lo) for a, b in w), "partially written gradient region"
+        w.append((lo, hi))
+        return 0
+
+    def gready(self):
+        w, lo, hi = self._interval()
+        return any(a <= lo and hi <= b for a, b in w)
+
+
+# ------------------------------------------------------------------------------------------------ parameters
+class ConvSeg:
+    def __init__(self, params, cout, taps, cin, need_dgrad=True):
+        self.params, self.cout, self.taps, self.cin, self.need_dgrad = params, cout, taps, cin, need_dgrad
+        self.cin_pad, self.cout_pad = _r8(cin), _r8(cout)
+        self.off = self.wf_off = self.wd_off = None
+
+    @property
+    def numel(self):
+        return self.cout * self.taps * self.cin
+
+
+class VecSeg:
+    def __init__(self, params):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.off = None
+
+
+class ParamHome:
+    """Flat fp32 parameter / gradient / momentum buffers + packed bf16 weight copies for one model."""
+
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.Ep24Error("ep24: move the model to the GPU before running it (model.to('cuda'))")
+        self.dev = dev
+        self.convs, self.vecs, self.order, self.by_param = [], [], [], {}
+        stems = {m.conv for m in model.modules() if isinstance(m, enn.Focus)}
+        for mod in exec_order(model):
+            if isinstance(mod, enn.BaseConv):
+                w = mod.conv.weight
+                k = w.shape[2]
+                if mod in stems:      # Focus stem runs as im2col x [Cout][108]: one "tap" of 108 (kh,kw,c) columns
+                    self._add(ConvSeg([w], w.shape[0], 1, k * k * w.shape[1], need_dgrad=False))
+                else:
+                    self._add(ConvSeg([w], w.shape[0], k * k, w.shape[1]))
+                self._add(VecSeg([mod.bn.weight]))
+                self._add(VecSeg([mod.bn.bias]))
+            elif isinstance(mod, enn.YOLOXHead):
+                for k in range(len(mod.stems)):
+                    rw, ow, cw = mod.reg_preds[k].weight, mod.obj_preds[k].weight, mod.cls_preds[k].weight
+                    # reg(26) and obj(1) predictors read the same feature: one [27][h] GEMM, adjacent in the flat buffer
+                    self._add(ConvSeg([rw, ow], rw.shape[0] + ow.shape[0], 1, rw.shape[1]))
+                    self._add(VecSeg([mod.reg_preds[k].bias, mod.obj_preds[k].bias]))
+                    self._add(ConvSeg([cw], cw.shape[0], 1, cw.shape[1]))
+                    self._add(VecSeg([mod.cls_preds[k].bias]))
+        missing = [n for n, p in model.named_parameters() if p not in self.by_param]
+        if missing:
+            raise _lib.Ep24Error("ep24: parameters outside the supported graph: %s" % missing[:4])
+        n = wf = wd = 0
+        for seg in self.order:                      # execution order: backward completes the buffer from its tail
+            seg.off = n
+            n += (seg.numel + 3) // 4 * 4
+        for seg in self.convs:
+            seg.wf_off, seg.wd_off = wf, wd
+            wf += seg.cout * seg.taps * seg.cin_pad
+            wd += seg.cin * seg.taps * seg.cout_pad if seg.need_dgrad else 0
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.mflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.wf = torch.zeros(max(wf, 8), dtype=BF16, device=dev)
+        self.wd = torch.zeros(max(wd, 8), dtype=BF16, device=dev)
+        self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
+        self.views = {}                                   # param -> (flat view, grad view, momentum view)
+        with torch.no_grad():
+            for seg in self.order:
+                o = seg.off
+                for p in seg.params:
+                    m = p.numel()
+                    vs = []
+                    for base in (self.flat, self.gflat, self.mflat):
+                        v = base[o:o + m]
+                        if p.dim() == 4:                  # physical [Cout][kh][kw][Cin], logical [Cout,Cin,kh,kw]
+                            v = v.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+                        else:
+                            v = v.view(p.shape)
+                        vs.append(v)
+                    vs[0].copy_(p.data)
+                    p.data = vs[0]
+                    p.grad = vs[1]
+                    self.views[p] = tuple(vs)
+                    o += m
+
+    def _add(self, seg):
+        (self.convs if isinstance(seg, ConvSeg) else self.vecs).append(seg)
+        self.order.append(seg)
+        for p in seg.params:
+            self.by_param[p] = seg
+
+    def bind_grads(self):
+        """Undo optimizer.zero_grad(set_to_none=True): .grad must stay the flat view the kernels write."""
+        for p, (_, g, _) in self.views.items():
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def pack(self):
+        """fp32 masters -> bf16 [Cout][T][Cin] (forward) and [Cin][T][Cout_pad] (dgrad) copies."""
+        s = stream_ptr()
+        for seg in self.convs:
+            call("pack_weights", ptr(self.flat, seg.off), seg.taps * seg.cin, ptr(self.wf, seg.wf_off),
+                 ptr(self.wd, seg.wd_off) if seg.need_dgrad else None, seg.cout, seg.taps, seg.cin, seg.cin_pad,
+                 seg.cout_pad, s)
+
+    def zero_grad(self):
+        call("memset_zero", ptr(self.gflat), self.numel * 4, stream_ptr())
+
+    def sgd(self, lr, momentum, grad_scale=1.0):
+        call("sgd_nesterov", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), self.numel, float(lr), float(momentum),
+             float(grad_scale), ptr(self.first_flag), stream_ptr())
+
+
+def exec_order(model):
+    """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
+    any other container (tests build single blocks) falls back to registration order."""
+    if not isinstance(model, enn.YOLOX):
+        yield from model.modules()
+        return
+
+    def csp(m):
+        yield m.conv1
+        yield m.conv2
+        for blk in m.m:
+            yield blk.conv1
+            yield blk.conv2
+        yield m.conv3
+
+    neck, head = model.backbone, model.head
+    bb = neck.backbone
+    yield bb.stem.conv
+    for name in ("dark2", "dark3", "dark4"):
+        seq = getattr(bb, name)
+        yield seq[0]
+        yield from csp(seq[1])
+    yield bb.dark5[0]
+    yield bb.dark5[1].conv1
+    yield bb.dark5[1].conv2
+    yield from csp(bb.dark5[2])
+    yield neck.lateral_conv0
+    yield from csp(neck.C3_p4)
+    yield neck.reduce_conv1
+    yield from csp(neck.C3_p3)
+    yield neck.bu_conv2
+    yield from csp(neck.C3_n3)
+    yield neck.bu_conv1
+    yield from csp(neck.C3_n4)
+    for k in range(len(head.stems)):
+        yield head.stems[k]
+        yield from head.cls_convs[k]
+        yield from head.reg_convs[k]
+    yield head
+
+
+def param_home(model):
+    if getattr(model, "_ep24_home", None) is None:
+        model._ep24_home = ParamHome(model)
+    return model._ep24_home
+
+
+# ------------------------------------------------------------------------------------------------ engine
+class Engine:
+    def __init__(self, model, batch, size):
+        _lib.require_gpu()
+        self.model, self.B, self.S = model, batch, size
+        self.home = param_home(model)
+        self.dev = self.home.dev
+        self.C = getattr(getattr(model, "head", None), "num_classes", 0)
+        self.ncols = 27 + self.C
+        self.fwd, self.bwd = [], []              # launch lists: (abi name, args)
+        self.outputs = None
+        self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
+        self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
+        self._bwd_builders = []
+        self.dyn = {}                            # run-time pointers (input images, incoming gradient)
+        self._stats_specs, self._sum_specs = [], []
+        self.max_dz = 0
+        self._build()
+
+    # ---- small helpers ----------------------------------------------------------------------------
+    def new_act(self, C, H, W, ld=None):
+        return Act(Buf(self.dev, self.B * H * W, ld or C), 0, C, self.B, H, W)
+
+    def _f(self, name, *args):
+        self.fwd.append((name, args))
+
+    def _b(self, name, args, writes=()):
+        self.bwd.append((name, args))
+        self.bwd_writes.append([(seg.off, seg.numel) for seg in writes])
+
+    # ---- graph construction -------------------------------------------------------------------------
+    def _build(self):
+        m, B, S = self.model, self.B, self.S
+        bb, neck, head = m.backbone.backbone, m.backbone, m.head
+        F = S // 2
+        self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
+        # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
+        rows = self.new_act(112, F, F)
+        rows.needs_grad = False
+        self._f("stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
+        x = self.unit(bb.stem.conv, rows, stem=True)
+        c3, c4, c5 = (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels, bb.dark5[0].conv.out_channels)
+        H3, H4, H5 = S // 8, S // 16, S // 32
+        # concat buffers of the neck; producers write straight into their slot (yolo_pafpn.py:100-124)
+        cat_p4 = self.new_act(2 * c4, H4, H4)        # [up(fpn_out0) | dark4]
+        cat_p3 = self.new_act(2 * c3, H3, H3)        # [up(fpn_out1) | dark3]
+        cat_n3 = self.new_act(2 * c3, H4, H4)        # [bu_conv2(pan_out2) | fpn_out1]
+        cat_n4 = self.new_act(2 * c4, H5, H5)        # [bu_conv1(pan_out1) | fpn_out0]
+        x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
+        x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=cat_p3.slice(c3, c3))
+        x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=cat_p4.slice(c4, c4))
+        x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
+        fpn_out0 = self.unit(neck.lateral_conv0, x0, out=cat_n4.slice(c4, c4))
+        self.up2(fpn_out0, cat_p4.slice(0, c4))
+        f_out0 = self.csp(neck.C3_p4, cat_p4)
+        fpn_out1 = self.unit(neck.reduce_conv1, f_out0, out=cat_n3.slice(c3, c3))
+        self.up2(fpn_out1, cat_p3.slice(0, c3))
+        pan_out2 = self.csp(neck.C3_p3, cat_p3)
+        self.unit(neck.bu_conv2, pan_out2, out=cat_n3.slice(0, c3))
+        pan_out1 = self.csp(neck.C3_n3, cat_n3)
+        self.unit(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
+        pan_out0 = self.csp(neck.C3_n4, cat_n4)
+        # head
+        self.A = H3 * H3 + H4 * H4 + H5 * H5
+        self.outputs = torch.zeros(B, self.A, self.ncols, dtype=torch.float32, device=self.dev)
+        a0 = 0
+        self.levels = []
+        for k, feat in enumerate((pan_out2, pan_out1, pan_out0)):
+            self.head_level(head, k, feat, a0)
+            a0 += feat.H * feat.W
+        # anchor tables of the train-mode tuple (yolo_head_24p.py:172-176)
+        self.x_shifts, self.y_shifts, self.exp_strides = [], [], []
+        for (H, W, s) in self.levels:
+            yv, xv = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            self.x_shifts.append(xv.reshape(1, -1).float().to(self.dev))
+            self.y_shifts.append(yv.reshape(1, -1).float().to(self.dev))
+            self.exp_strides.append(torch.full((1, H * W), float(s), device=self.dev))
+        self._finalize()
+
+    def _finalize(self):
+        """Allocate the shared scratch, then build the backward list in reverse op order and resolve pointers."""
+        # scratch shared by all layers (single stream => no overlap in time)
+        self.dz = torch.zeros(max(self.max_dz, 8), dtype=BF16, device=self.dev)
+        self.stats = torch.zeros(max(sum(self._stats_specs), 4), dtype=torch.int64, device=self.dev)
+        self.bnsums = torch.zeros(max(sum(self._sum_specs), 4), dtype=torch.int64, device=self.dev)
+        for b in reversed(self._bwd_builders):
+            b()
+        fw, bw = [], []
+        for lst, out in ((self.fwd, fw), (self.bwd, bw)):
+            for name, args in lst:
+                out.append((name, tuple(a() if callable(a) else a for a in args)))   # Dyn stays for run time
+        self.fwd, self.bwd = fw, bw
+
+    def _stats_slot(self, C):
+        off = sum(self._stats_specs)
+        self._stats_specs.append(STATS_REPLICAS * 2 * C)
+        return lambda: self.stats.data_ptr() + 8 * off
+
+    def _sums_slot(self, C):
+        off = sum(self._sum_specs)
+        self._sum_specs.append(2 * C)
+        return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
+
+    # ---- ops ---------------------------------------------------------------------------------------
+    def unit(self, mod, x, out=None, residual=None, stem=False):
+        """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51)."""
+        home = self.home
+        seg = home.by_param[mod.conv.weight]
+        gam, bet = home.by_param[mod.bn.weight], home.by_param[mod.bn.bias]
+        k = 1 if stem else mod.conv.kernel_size[0]
+        s = 1 if stem else mod.conv.stride[0]
+        cin = x.C                                  # stem: im2col width 112 (108 real columns)
+        assert x.C == seg.cin_pad if stem else x.C == seg.cin, (x.C, seg.cin)
+        cout = seg.cout
+        B, H, W = x.B, x.H, x.W
+        OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+        if out is None:
+            out = self.new_act(cout, OH, OW)
+        assert (out.H, out.W, out.C) == (OH, OW, cout)
+        z = self.new_act(cout, OH, OW)
+        z.needs_grad = False
+        M = B * OH * OW
+        self.max_dz = max(self.max_dz, M * cout)
+        save = torch.zeros(2 * cout, dtype=torch.float32, device=self.dev)
+        stats = self._stats_slot(cout)
+        sum_g, sum_b = self._sums_slot(cout)
+        bn = mod.bn
+        flat, gflat = home.flat, home.gflat
+        wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
+        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s)
+        self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
+                ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld,
+                residual.ptr() if residual is not None else None, residual.ld if residual is not None else 0,
+                M, cout, float(bn.eps), float(bn.momentum), 1)
+        if residual is not None:
+            residual.alias_grad(out)
+        self.unit_acts[mod] = (x, z, out)
+
+        def build_bwd():
+            assert out.gready(), "activation without a gradient producer"
+            dz = lambda: self.dz.data_ptr()
+            self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, 1))
+            self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                         ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
+                                         dz, cout, M, cout, 1), writes=(gam, bet))
+            self._b("conv_wgrad_bf16", (x.ptr(), x.ld, dz, cout, ptr(gflat, seg.off), seg.taps * seg.cin, cout,
+                                        seg.cin, B, H, W, cin, cout, k, s), writes=(seg,))
+            if x.needs_grad:
+                acc = x.gwrite()
+                self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
+                                            seg.cout_pad, k, s))
+
+        self._bwd_builders.append(build_bwd)
+        return out
+
+    def csp(self, mod, x, out=None):
+        """CSPLayer: cat(m(conv1(x)), conv2(x)) -> conv3 (network_blocks.py:179-185)."""
+        h = self.home.by_param[mod.conv1.conv.weight].cout
+        cat = self.new_act(2 * h, x.H, x.W)
+        n = len(mod.m)
+        t = self.unit(mod.conv1, x, out=cat.slice(0, h) if n == 0 else None)
+        self.unit(mod.conv2, x, out=cat.slice(h, h))
+        for i, blk in enumerate(mod.m):
+            last = i == n - 1
+            u = self.unit(blk.conv1, t)
+            t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None)
+        return self.unit(mod.conv3, cat, out=out)
+
+    def spp(self, mod, x):
+        """SPPBottleneck: conv1 -> cat(x, pool5, pool9, pool13) -> conv2 (network_blocks.py:139-144)."""
+        h = self.home.by_param[mod.conv1.conv.weight].cout
+        cat = self.new_act(4 * h, x.H, x.W)
+        t = self.unit(mod.conv1, x, out=cat.slice(0, h))
+        y5, y9, y13 = cat.slice(h, h), cat.slice(2 * h, h), cat.slice(3 * h, h)
+        idx = torch.zeros(3 * t.M * h, dtype=torch.uint8, device=self.dev)
+        self._f("spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h)
+
+        def build_bwd():
+            assert y5.gready() and y9.gready() and y13.gready()
+            acc = t.gwrite()
+            self._b("spp_bwd", (y5.gptr(), y9.gptr(), y13.gptr(), y5.gld, ptr(idx), t.gptr(), t.gld, acc,
+                                t.B, t.H, t.W, h))
+
+        self._bwd_builders.append(build_bwd)
+        return self.unit(mod.conv2, cat)
+
+    def up2(self, x, y):
+        self._f("upsample2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, x.B, x.H, x.W, x.C)
+
+        def build_bwd():
+            assert y.gready()
+            acc = x.gwrite()
+            self._b("upsample2_bwd", (y.gptr(), y.gld, x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
+
+        self._bwd_builders.append(build_bwd)
+
+    def head_level(self, head, k, feat, a0):
+        """stem -> {cls branch -> cls_preds, reg branch -> reg_preds + obj_preds} -> decode (yolo_head_24p.py:150-189)."""
+        home, B, C = self.home, self.B, self.C
+        H, W, s = feat.H, feat.W, float(head.strides[k])
+        self.levels.append((H, W, s))
+        x = self.unit(head.stems[k], feat)
+        cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x))
+        rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x))
+        ro_seg = home.by_param[head.reg_preds[k].weight]
+        ro_b = home.by_param[head.reg_preds[k].bias]
+        cl_seg = home.by_param[head.cls_preds[k].weight]
+        cl_b = home.by_param[head.cls_preds[k].bias]
+        hch = x.C
+        M = B * H * W
+        out = self.outputs
+        flat, gflat = home.flat, home.gflat
+        self._f("conv_fwd_bf16", rf.ptr(), rf.ld, ptr(home.wf, ro_seg.wf_off), ptr(out), self.ncols, 1, self.A, a0,
+                ptr(flat, ro_b.off), None, 1, B, H, W, hch, 27, 1, 1)
+        self._f("conv_fwd_bf16", cf.ptr(), cf.ld, ptr(home.wf, cl_seg.wf_off), ptr(out, 27), self.ncols, 1, self.A, a0,
+                ptr(flat, cl_b.off), None, 1, B, H, W, hch, C, 1, 1)
+        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols)
+        ldc = _r8(C)
+        d_ro = torch.zeros(M * 32, dtype=BF16, device=self.dev)
+        d_cl = torch.zeros(M * ldc, dtype=BF16, device=self.dev)
+
+        def build_bwd():
+            dout = Dyn(self.dyn, "dout")
+            self._b("head_decode_bwd", (dout, ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols))
+            self._b("colsum", (ptr(d_ro), 32, ptr(gflat, ro_b.off), M, 27), writes=(ro_b,))
+            self._b("colsum", (ptr(d_cl), ldc, ptr(gflat, cl_b.off), M, C), writes=(cl_b,))
+            self._b("conv_wgrad_bf16", (rf.ptr(), rf.ld, ptr(d_ro), 32, ptr(gflat, ro_seg.off), hch, 27, hch, B, H, W,
+                                        hch, 32, 1, 1), writes=(ro_seg,))
+            self._b("conv_wgrad_bf16", (cf.ptr(), cf.ld, ptr(d_cl), ldc, ptr(gflat, cl_seg.off), hch, C, hch, B, H, W,
+                                        hch, ldc, 1, 1), writes=(cl_seg,))
+            self._b("conv_dgrad_bf16", (ptr(d_ro), 32, ptr(home.wd, ro_seg.wd_off), rf.gptr(), rf.gld, rf.gwrite(), B, H,
+                                        W, hch, 32, 1, 1))
+            self._b("conv_dgrad_bf16", (ptr(d_cl), ldc, ptr(home.wd, cl_seg.wd_off), cf.gptr(), cf.gld, cf.gwrite(), B, H,
+                                        W, hch, ldc, 1, 1))
+
+        self._bwd_builders.append(build_bwd)
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def _run(self, lst):
+        s = stream_ptr()
+        fn = _lib.lib().fn
+        for name, args in lst:
+            rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
+            if rc != 0:
+                raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
+
+    def zero_step_buffers(self):
+        s = stream_ptr()
+        call("memset_zero", ptr(self.stats), self.stats.numel() * 8, s)
+        call("memset_zero", ptr(self.bnsums), self.bnsums.numel() * 8, s)
+
+    def forward(self, images=None):
+        """Train-mode forward into self.outputs ([B,A,27+C] fp32, decoded)."""
+        if images is not None:
+            self.images.copy_(images)
+        self.zero_step_buffers()
+        self.home.pack()
+        self._run(self.fwd)
+        return self.outputs
+
+    def backward(self, dout):
+        """Accumulates parameter gradients into the flat gradient buffer; dout [B,A,27+C] fp32 contiguous."""
+        self.dyn["dout"] = dout.data_ptr()
+        self._run(self.bwd)
+
+    # ---- nn.Module / autograd entry -----------------------------------------------------------------
+    def run_module_forward(self, x, train):
+        if not train:
+            raise NotImplementedError("eval-mode decode/NMS is the next hot-path row (SURVEY.md 8f N3); "
+                                      "this build implements the training path")
+        out = _NetFn.apply(x, self, *list(self.home.views.keys()))
+        return self.x_shifts, self.y_shifts, self.exp_strides, out, []
+
+
+class _NetFn(torch.autograd.Function):
+    """The whole network as ONE autograd node: forward / backward are the engine's launch lists."""
+
+    @staticmethod
+    def forward(ctx, x, eng, *params):
+        ctx.eng = eng
+        return eng.forward(x.float().contiguous()).clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        eng.home.bind_grads()
+        eng.backward(dout.contiguous())
+        # parameter gradients were accumulated in place into the flat buffer that every p.grad views
+        return (None, None) + (None,) * len(eng.home.views)

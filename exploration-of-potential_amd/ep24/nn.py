@@ -171,9 +171,8 @@ class YOLOX(nn.Module):
         from .engine import Engine
         key = (batch, size)
         if key not in self._engines:
-            # one parameter home (flat buffers) per model; plans for other shapes share it
-            base = next(iter(self._engines.values()), None)
-            self._engines[key] = Engine(self, batch, size, share=base)
+            # one parameter home (flat buffers) per model; plans for other input shapes share it
+            self._engines[key] = Engine(self, batch, size)
         return self._engines[key]
 
     def forward(self, x, train=False):

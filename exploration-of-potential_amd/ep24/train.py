@@ -1,0 +1,151 @@
+"""One training step of the 24p detector as a replayable hipGraph, plus the optimizer mirror.
+
+Reference step body (yolox_24p/train_24p.py:80-111): zero_grad -> model(images, train=True) ->
+Loss_Function.forward -> backward -> SGD.step -> .item() (+53 TensorBoard D2H syncs).  Here the whole body -
+gradient clearing, weight packing, forward list, SimOTA + loss + loss gradient, backward list, (gradient
+all-reduce), fused SGD - is a fixed sequence of launches on static buffers, captured once and replayed;
+the host only copies the next batch into the static input buffers and reads the loss when it wants to.
+"""
+import torch
+
+from . import _lib, loss as eloss
+from .engine import param_home
+
+
+class SGD(torch.optim.Optimizer):
+    """``torch.optim.SGD(params, lr, momentum, nesterov=True)`` semantics (yolox_24p/exp/yolox_base.py:120-124,
+    no weight decay) as ONE fused kernel over the model's flat parameter / gradient / momentum buffers."""
+
+    def __init__(self, params, lr, momentum=0.9, nesterov=True, model=None):
+        if not nesterov or model is None:
+            raise NotImplementedError("ep24.SGD implements the reference's nesterov SGD over an ep24 model")
+        super().__init__(list(params), dict(lr=lr, momentum=momentum, nesterov=True))
+        self.model = model
+
+    def zero_grad(self, set_to_none=False):
+        home = param_home(self.model)
+        home.bind_grads()
+        home.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        g = self.param_groups[0]
+        param_home(self.model).sgd(g["lr"], g["momentum"], grad_scale)
+
+    def state_dict(self):
+        home = param_home(self.model)
+        sd = super().state_dict()
+        # momentum buffers in torch.optim.SGD's layout so reference-style checkpoints round-trip
+        order = [p for grp in self.param_groups for p in grp["params"]]
+        sd["state"] = {i: {"momentum_buffer": home.views[p][2].detach().clone()} for i, p in enumerate(order)}
+        return sd
+
+    def load_state_dict(self, sd):
+        home = param_home(self.model)
+        order = [p for grp in self.param_groups for p in grp["params"]]
+        for i, st in sd.get("state", {}).items():
+            if st.get("momentum_buffer") is not None:
+                home.views[order[int(i)]][2].copy_(st["momentum_buffer"])
+                home.first_flag.zero_()
+        for grp, new in zip(self.param_groups, sd["param_groups"]):
+            grp["lr"], grp["momentum"] = new["lr"], new["momentum"]
+
+
+class TrainStep:
+    """Captured training step.  ``step(images, labels)`` returns the device tensor ``result[64]`` of
+    ``ep24_loss_finalize`` (loss at [0]); nothing synchronises unless the caller reads it.
+
+    ``reducer`` (ep24.dp.GradReducer or None) averages the flat gradient across ranks between backward and
+    SGD; with ``segments > 1`` the backward list is cut into that many graphs so buckets can be all-reduced on
+    the communication stream while the rest of backward still runs.
+    """
+
+    def __init__(self, model, loss_fn, lr, momentum=0.9, batch=None, size=640, reducer=None, use_graph=True):
+        _lib.require_gpu()
+        self.model, self.loss_fn = model, loss_fn
+        self.eng = model.engine(batch, size)
+        self.home = self.eng.home
+        self.lr, self.momentum = lr, momentum
+        self.reducer = reducer
+        eng = self.eng
+        self.ws = loss_fn.workspace(eng.B, eng.A, eng.dev)
+        self.state = loss_fn._state
+        self.xs = torch.cat(eng.x_shifts, 1)[0].contiguous()
+        self.ys = torch.cat(eng.y_shifts, 1)[0].contiguous()
+        self.st = torch.cat(eng.exp_strides, 1)[0].contiguous()
+        self.labels = torch.zeros(eng.B, 50, 51, dtype=torch.float32, device=eng.dev)
+        self.graphs = None
+        self.use_graph = use_graph
+        self.world = 1 if reducer is None else reducer.world
+        if reducer is not None:
+            reducer.attach(self.home, eng)
+
+    # the three phases, each a pure launch sequence on the current stream
+    def _phase_forward(self):
+        eng = self.eng
+        self.home.zero_grad()
+        eng.forward()
+        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state)
+        eloss.loss_grad(self.ws, eng.outputs, self.labels)
+        eng.dyn["dout"] = self.ws.dout.data_ptr()
+
+    def _phase_backward(self, lo, hi):
+        eng = self.eng
+        eng._run(eng.bwd[lo:hi])
+
+    def _phase_update(self):
+        self.home.sgd(self.lr, self.momentum, 1.0 / self.world)
+
+    def _capture(self):
+        eng = self.eng
+        cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
+        # warm-up outside capture (lazy code-object loads); it must not count as a training step, so the
+        # stateful pieces it touches (BN running statistics, the loss's "last loss" weights) are restored
+        keep = [b.clone() for b in self.model.buffers()] + [self.state.clone()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._phase_forward()
+            self._phase_backward(0, len(eng.bwd))
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for b, k in zip(list(self.model.buffers()) + [self.state], keep):
+                b.copy_(k)
+        graphs = []
+        pool = None
+        phases = [self._phase_forward] + [(lambda a=a, b=b: self._phase_backward(a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
+        phases.append(self._phase_update)
+        for ph in phases:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                ph()
+            pool = g.pool()
+            graphs.append(g)
+        self.graphs = graphs
+
+    def step(self, images=None, labels=None):
+        eng = self.eng
+        if images is not None:
+            eng.images.copy_(images, non_blocking=True)
+        if labels is not None:
+            self.labels.copy_(labels, non_blocking=True)
+        if not self.use_graph:
+            self._phase_forward()
+            self._phase_backward(0, len(eng.bwd))
+            if self.reducer is not None:
+                self.reducer.reduce_all()
+            self._phase_update()
+            return self.ws.result
+        if self.graphs is None:
+            self._capture()
+        g = self.graphs
+        g[0].replay()
+        for i in range(1, len(g) - 1):
+            g[i].replay()
+            if self.reducer is not None:
+                self.reducer.bucket_ready(i - 1)
+        if self.reducer is not None:
+            self.reducer.wait()
+        g[-1].replay()
+        return self.ws.result

@@ -41,16 +41,17 @@ int ep24_abi_version(void);
 
 /* y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], w[Cout][k*k][Cin]), pad (k-1)/2, bf16 MFMA implicit GEMM, fp32
  * accumulate.  y is bf16 (y_f32=0) or fp32 (y_f32=1, + bias) with row stride ld_y.  If `stats` is non-null
- * the per-channel sum and sum-of-squares of the fp32 results are atomically added into
- * stats[replica][0][c] / stats[replica][1][c] (replica = block % stats_replicas): the BN batch statistics
- * (torch.nn.BatchNorm2d training mode, network_blocks.py:47).  Requires Cin % 64 == 0.
+ * the per-channel sum and sum-of-squares of the fp32 results are atomically added, as 2^-20 fixed point
+ * int64 (order independent => bitwise reproducible), into stats[replica][0][c] / stats[replica][1][c]
+ * (replica = block % stats_replicas): the BN batch statistics (torch.nn.BatchNorm2d training mode,
+ * network_blocks.py:47).  Requires Cin % 8 == 0.
  * Output pixel (n,oh,ow) lands on row n*y_batch_rows + y_row0 + oh*OW + ow of y (y_batch_rows = 0 means
  * dense OH*OW): lets the head write straight into its slice of the [B,8400,107] tensor. */
 int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
-                       int64_t y_batch_rows, int64_t y_row0, const float* bias, float* stats, int stats_replicas,
+                       int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
-/* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 64 == 0 (padded).
+/* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 8 == 0 (zero padded).
  * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */
 int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
                          int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, void* stream);
@@ -69,29 +70,33 @@ int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, 
                       int Cin_pad, int Cout_pad, void* stream);
 
 /* y = silu(bn(z)) (+ residual), training-mode BatchNorm with batch statistics taken from `stats`
- * ([replicas][2][C] sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
+ * ([replicas][2][C] fixed-point sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
  * save[1][c]=invstd for the backward and updates running_mean / running_var (unbiased) / num_batches_tracked
  * (momentum, eps: yolox_24p/exp/yolox_base.py:58-62).  act: 1 = SiLU, 0 = identity. */
-int ep24_bn_act_fwd(const void* z, int64_t ld_z, const float* stats, int stats_replicas, const float* gamma,
+int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats_replicas, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
                     float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res,
                     int64_t M, int C, float eps, float momentum, int act, void* stream);
 
-/* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)). */
+/* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
+ * 2^-20 fixed-point int64 like the forward statistics. */
 int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                           const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                           const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta,
                            int64_t M, int C, int act, void* stream);
-/* pass 2: dz = gamma*invstd*(du - dbeta/M - zhat*dgamma/M)  -> bf16 [M,C] (ld_dz). */
+/* pass 2: dz = gamma*invstd*(du - dbeta/M - zhat*dgamma/M)  -> bf16 [M,C] (ld_dz).  dgamma/dbeta are this
+ * call's sums (scratch, zeroed by the caller before pass 1); if gamma_grad/beta_grad are non-null they
+ * receive += of those sums (the parameter .grad accumulators). */
 int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                          const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
-                          void* dz, int64_t ld_dz, int64_t M, int C, int act, void* stream);
+                          const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                          float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1/a2  glue ops of the graph
  * ------------------------------------------------------------------------------------------------ */
-/* Focus + im2col for the 3x3 stem: images [B,3,S,S] fp32 NCHW -> rows [B*(S/2)^2][128] bf16, columns
- * (kh,kw,c4) with c4 = TL,BL,TR,BR x 3 channels, 108 real + 20 zero (network_blocks.py:188-210). */
-int ep24_stem_pack(const float* images, void* rows, int B, int S, void* stream);
+/* Focus + im2col for the 3x3 stem: images [B,3,S,S] fp32 NCHW -> rows [B*(S/2)^2][ld] bf16, columns
+ * (kh,kw,c4) with c4 = TL,BL,TR,BR x 3 channels, 108 real + zero padding to ld (network_blocks.py:188-210). */
+int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int S, void* stream);
 
 /* SPP max pools k = 5, 9, 13, stride 1, pad k/2 over x[B,H,W,C] (network_blocks.py:131-143).  Writes the
  * three pooled maps into y5/y9/y13 (row stride ld_y) and the winning window offset (dy*16+dx biased by 8)
@@ -121,7 +126,7 @@ int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, i
  * xy=(t+grid)*s, r=exp(t)*s, obj/cls logits untouched. */
 int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream);
 /* backward through the decode for one level + split into the padded bf16 gradients the prediction convs
- * consume: d_regobj [B*H*W][64] (26 reg + 1 obj + zeros), d_cls [B*H*W][128] (80 + zeros). */
+ * consume: d_regobj [B*H*W][32] (26 reg + 1 obj + zeros), d_cls [B*H*W][round8(C)] (C classes + zeros). */
 int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
                          int H, int W, float stride, int ncols, void* stream);
 /* bias gradient: db[n] += sum_m g[m][n] for n < N (bf16 rows of stride ld). */

@@ -15,8 +15,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+EMULATE_BF16 = False      # tests flip this to mirror the product's storage precision (see Unit.forward)
+
+
+def _q(x):
+    """Round to bf16 and back with a straight-through gradient."""
+    return x + (x.to(torch.bfloat16).float() - x).detach()
+
+
 class Unit(nn.Module):
-    """conv (no bias) -> BatchNorm -> SiLU; attribute names conv / bn as in BaseConv."""
+    """conv (no bias) -> BatchNorm -> SiLU; attribute names conv / bn as in BaseConv.
+
+    With EMULATE_BF16 the same fp32 arithmetic is applied to bf16-rounded operands at the points where the
+    HIP plan stores bf16 (conv inputs, packed weights, raw conv output, activated output) while the batch
+    statistics come from the unrounded conv result, exactly as the MFMA epilogue accumulates them.  This
+    isolates kernel errors from the (expected) bf16 storage error when the two paths are compared."""
 
     def __init__(self, cin, cout, k, s=1):
         super().__init__()
@@ -24,7 +37,21 @@ class Unit(nn.Module):
         self.bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.03)
 
     def forward(self, x):
-        return F.silu(self.bn(self.conv(x)))
+        if not EMULATE_BF16:
+            return F.silu(self.bn(self.conv(x)))
+        z = F.conv2d(_q(x), _q(self.conv.weight), None, self.conv.stride, self.conv.padding)
+        mean = z.mean((0, 2, 3))
+        var = z.var((0, 2, 3), unbiased=False)
+        if self.training:
+            with torch.no_grad():
+                n = z.numel() / z.shape[1]
+                m = self.bn.momentum
+                self.bn.running_mean.mul_(1 - m).add_(m * mean)
+                self.bn.running_var.mul_(1 - m).add_(m * var * n / max(n - 1, 1))
+                self.bn.num_batches_tracked += 1
+        scale = self.bn.weight / torch.sqrt(var + self.bn.eps)
+        u = _q(z) * scale.view(1, -1, 1, 1) + (self.bn.bias - mean * scale).view(1, -1, 1, 1)
+        return _q(F.silu(u))
 
 
 class Stem(nn.Module):
@@ -141,7 +168,11 @@ class Head(nn.Module):
             x = self.stems[k](x)
             cf = self.cls_convs[k](x)
             rf = self.reg_convs[k](x)
-            reg, obj, cls = self.reg_preds[k](rf), self.obj_preds[k](rf), self.cls_preds[k](cf)
+            if EMULATE_BF16:
+                pred = lambda m, f: F.conv2d(_q(f), _q(m.weight), m.bias)
+                reg, obj, cls = pred(self.reg_preds[k], rf), pred(self.obj_preds[k], rf), pred(self.cls_preds[k], cf)
+            else:
+                reg, obj, cls = self.reg_preds[k](rf), self.obj_preds[k](rf), self.cls_preds[k](cf)
             if not train:
                 outs.append(torch.cat([reg, obj.sigmoid(), cls.sigmoid()], 1).flatten(2))
                 continue

@@ -1,0 +1,238 @@
+"""GPU numerics of the conv-graph kernels (through the C ABI) against plain torch fp32 on the same
+bf16-rounded operands.  Tolerances: the kernels accumulate in fp32 and round once to bf16 (2^-8 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _abi():
+    from ep24._lib import call, ptr, stream_ptr
+    return call, ptr, stream_ptr
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def close(got, want, rel=1.2e-2):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rel * ref + 1e-6, "max err %.4g vs ref max %.4g" % (err, ref)
+
+
+CONV_CASES = [  # B, H, Cin, Cout, k, s
+    (2, 20, 64, 64, 3, 1), (3, 16, 128, 128, 3, 1), (2, 16, 64, 128, 3, 2), (2, 10, 256, 256, 1, 1),
+    (2, 12, 16, 24, 3, 1), (1, 24, 8, 16, 3, 2), (5, 9, 72, 200, 3, 1), (2, 8, 512, 64, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,s", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(B, H, Cin, Cout, k, s):
+    call, ptr, sp = _abi()
+    W = H
+    pad = (k - 1) // 2
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, pad)
+    OH, OW = y_ref.shape[2:]
+    gy = rnd(B, Cout, OH, OW, seed=3)
+    y_ref.backward(gy.float())
+
+    xd = nhwc(x).to(DEV)
+    wf = w.permute(0, 2, 3, 1).contiguous().to(DEV)                    # [Cout][kh][kw][Cin]
+    wd = w.permute(1, 2, 3, 0).contiguous().to(DEV)                    # [Cin][kh][kw][Cout]
+    y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
+    R = 4
+    stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
+    call("conv_fwd_bf16", ptr(xd), Cin, ptr(wf), ptr(y), Cout, 0, 0, 0, None, ptr(stats), R, B, H, W, Cin, Cout, k, s, sp())
+    close(y.permute(0, 3, 1, 2), y_ref.detach())
+    st = stats.sum(0).cpu().double().div(2 ** 20).float()               # 2^-20 fixed point
+    yr = y_ref.detach()
+    close(st[0], yr.sum((0, 2, 3)), rel=2e-3)
+    close(st[1], (yr * yr).sum((0, 2, 3)), rel=2e-3)
+
+    gyd = nhwc(gy).to(DEV)
+    dx = torch.full((B, H, W, Cin), 7.0, dtype=BF, device=DEV)          # must be overwritten (accumulate=0)
+    call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, k, s, sp())
+    close(dx.permute(0, 3, 1, 2), xr.grad)
+    base = rnd(B, H, W, Cin, seed=5).to(DEV)
+    dx2 = base.clone()
+    call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx2), Cin, 1, B, H, W, Cin, Cout, k, s, sp())
+    close(dx2.permute(0, 3, 1, 2), xr.grad + base.float().cpu().permute(0, 3, 1, 2))
+
+    dw = torch.zeros(Cout, k * k, Cin, device=DEV)
+    call("conv_wgrad_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(dw), k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, sp())
+    close(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2), wr.grad, rel=5e-3)
+    call("conv_wgrad_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(dw), k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, sp())
+    close(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * wr.grad, rel=5e-3)      # += semantics
+
+
+def test_conv_slices_fp32_out_bias_and_row_mapping():
+    """1x1 predictor form: input is a channel slice of a wider buffer, output fp32 + bias into rows n*A + a0 + hw."""
+    call, ptr, sp = _abi()
+    B, H, W, Cin, N, ld_x, A, a0, ncols, col0 = 3, 5, 5, 64, 27, 96, 40, 7, 107, 0
+    xb = rnd(B * H * W, ld_x, seed=11).to(DEV)
+    w = rnd(N, Cin, seed=12, scale=0.1)
+    bias = torch.linspace(-1, 1, N)
+    out = torch.full((B, A, ncols), -5.0, device=DEV)
+    wd_, bd_ = w.to(DEV), bias.to(DEV)          # keep the device copies alive across the launch
+    call("conv_fwd_bf16", ptr(xb, 16), ld_x, ptr(wd_), ptr(out, col0), ncols, 1, A, a0, ptr(bd_), None, 1,
+         B, H, W, Cin, N, 1, 1, sp())
+    ref = xb.float().cpu()[:, 16:16 + Cin] @ w.float().t() + bias
+    got = out.cpu()[:, a0:a0 + H * W, :N].reshape(-1, N)
+    close(got, ref, rel=2e-3)
+    assert float(out.cpu()[:, :a0].min()) == -5.0 and float(out.cpu()[:, a0 + H * W:].max()) == -5.0
+    assert float(out.cpu()[:, :, N:].max()) == -5.0                      # columns beyond N untouched
+
+
+def test_wgrad_padded_valid_region():
+    call, ptr, sp = _abi()
+    B, H, W, Cin, Cv, Cp = 2, 6, 6, 64, 27, 32
+    x = rnd(B * H * W, Cin, seed=21).to(DEV)
+    dy = torch.zeros(B * H * W, Cp, dtype=BF)
+    dy[:, :Cv] = rnd(B * H * W, Cv, seed=22)
+    dw = torch.zeros(Cv, Cin, device=DEV)
+    dyd = dy.to(DEV)
+    call("conv_wgrad_bf16", ptr(x), Cin, ptr(dyd), Cp, ptr(dw), Cin, Cv, Cin, B, H, W, Cin, Cp, 1, 1, sp())
+    close(dw, dy.float()[:, :Cv].t() @ x.float().cpu(), rel=5e-3)
+
+
+@pytest.mark.parametrize("M,C,res", [(400, 64, False), (1000, 24, True), (130, 512, True), (33, 8, False)])
+def test_bn_silu_fwd_bwd(M, C, res):
+    call, ptr, sp = _abi()
+    z = rnd(M, C, seed=31, scale=2.0)
+    gamma = torch.rand(C) + 0.5
+    beta = torch.rand(C) - 0.5
+    r = rnd(M, C, seed=32) if res else None
+    zr = z.float().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    u = F.batch_norm(zr, rm, rv, g_, b_, True, 0.03, 1e-3)
+    y_ref = F.silu(u) + (r.float() if res else 0)
+    dy = rnd(M, C, seed=33)
+    y_ref.backward(dy.float())
+
+    zd = z.to(DEV)
+    R = 2
+    stats = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+    stats[0, 0] = (z.double().sum(0) * 2 ** 20).round().long().to(DEV)
+    stats[0, 1] = ((z.double() ** 2).sum(0) * 2 ** 20).round().long().to(DEV)
+    save = torch.zeros(2, C, device=DEV)
+    rmd, rvd, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    y = torch.zeros(M, C, dtype=BF, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    rd = r.to(DEV) if res else None
+    call("bn_act_fwd", ptr(zd), C, ptr(stats), R, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), ptr(nbt), ptr(save), ptr(y), C,
+         ptr(rd), C if res else 0, M, C, 1e-3, 0.03, 1, sp())
+    close(y, y_ref.detach())
+    close(rmd, rm, rel=1e-4)
+    close(rvd, rv, rel=1e-4)
+    assert int(nbt) == 1
+    dyd = dy.to(DEV)
+    sums = torch.zeros(2, C, dtype=torch.int64, device=DEV)
+    ggrad, bgrad = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    call("bn_act_bwd_reduce", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), M, C, 1, sp())
+    dz = torch.zeros(M, C, dtype=BF, device=DEV)
+    call("bn_act_bwd_apply", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), ptr(ggrad),
+         ptr(bgrad), ptr(dz), C, M, C, 1, sp())
+    close(dz, zr.grad, rel=2e-2)
+    close(ggrad - 1, g_.grad, rel=5e-3)
+    close(bgrad - 1, b_.grad, rel=5e-3)
+
+
+def test_spp_fwd_bwd():
+    call, ptr, sp = _abi()
+    B, H, W, C = 2, 20, 20, 16
+    x = rnd(B, C, H, W, seed=41)
+    x = (x.float() * 4).round().div(4).to(BF)                            # many exact ties: exercises first-max routing
+    xr = x.float().requires_grad_(True)
+    pools = [F.max_pool2d(xr, k, 1, k // 2) for k in (5, 9, 13)]
+    gys = [rnd(B, C, H, W, seed=42 + i) for i in range(3)]
+    sum((p * g.float()).sum() for p, g in zip(pools, gys)).backward()
+    cat = torch.zeros(B * H * W, 4 * C, dtype=BF, device=DEV)
+    cat[:, :C] = nhwc(x).reshape(-1, C).to(DEV)
+    idx = torch.zeros(3 * B * H * W * C, dtype=torch.uint8, device=DEV)
+    call("spp_fwd", ptr(cat), 4 * C, ptr(cat, C), ptr(cat, 2 * C), ptr(cat, 3 * C), 4 * C, ptr(idx), B, H, W, C, sp())
+    for i, p in enumerate(pools):
+        got = cat[:, (i + 1) * C:(i + 2) * C].reshape(B, H, W, C).permute(0, 3, 1, 2)
+        assert torch.equal(got.float().cpu(), p.detach())
+    dcat = torch.zeros(B * H * W, 4 * C, dtype=BF, device=DEV)
+    for i, g in enumerate(gys):
+        dcat[:, (i + 1) * C:(i + 2) * C] = nhwc(g).reshape(-1, C).to(DEV)
+    call("spp_bwd", ptr(dcat, C), ptr(dcat, 2 * C), ptr(dcat, 3 * C), 4 * C, ptr(idx), ptr(dcat), 4 * C, 0, B, H, W, C, sp())
+    close(dcat[:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2), xr.grad)
+
+
+def test_upsample_stem_decode_sgd():
+    call, ptr, sp = _abi()
+    # nearest x2
+    B, H, W, C = 2, 5, 5, 16
+    x = rnd(B, C, H, W, seed=51)
+    y = torch.zeros(B, 2 * H, 2 * W, C, dtype=BF, device=DEV)
+    xd = nhwc(x).to(DEV)
+    call("upsample2_fwd", ptr(xd), C, ptr(y), C, B, H, W, C, sp())
+    assert torch.equal(y.permute(0, 3, 1, 2).float().cpu(), F.interpolate(x.float(), scale_factor=2, mode="nearest"))
+    gy = rnd(B, 2 * H, 2 * W, C, seed=52).to(DEV)
+    gx = torch.zeros(B, H, W, C, dtype=BF, device=DEV)
+    call("upsample2_bwd", ptr(gy), C, ptr(gx), C, 0, B, H, W, C, sp())
+    ref = gy.float().cpu().reshape(B, H, 2, W, 2, C).sum((2, 4))
+    close(gx, ref)
+    # stem: Focus + 3x3 im2col
+    S = 16
+    img = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(53)) * 255
+    rows = torch.zeros(2 * 8 * 8, 112, dtype=BF, device=DEV)
+    imgd = img.to(DEV)
+    call("stem_pack", ptr(imgd), ptr(rows), 112, 2, S, sp())
+    foc = torch.cat([img[..., 0::2, 0::2], img[..., 1::2, 0::2], img[..., 0::2, 1::2], img[..., 1::2, 1::2]], 1)
+    cols = F.unfold(foc, 3, padding=1).reshape(2, 12, 9, 64).permute(0, 3, 2, 1).reshape(-1, 108)   # (kh,kw) major, c minor
+    assert torch.equal(rows[:, :108].float().cpu(), cols.to(BF).float())
+    assert float(rows[:, 108:].abs().sum()) == 0
+    # decode fwd / bwd of one level
+    Bz, A, a0, Hh, Ww, s, nc = 2, 30, 5, 4, 4, 16.0, 107
+    raw = torch.randn(Bz, A, nc, generator=torch.Generator().manual_seed(54))
+    out = raw.clone().to(DEV)
+    call("head_decode_fwd", ptr(out), Bz, A, a0, Hh, Ww, s, nc, sp())
+    yv, xv = torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij")
+    ref = raw.clone()
+    lvl = ref[:, a0:a0 + 16]
+    lvl[..., 0] = (lvl[..., 0] + xv.reshape(-1)) * s
+    lvl[..., 1] = (lvl[..., 1] + yv.reshape(-1)) * s
+    lvl[..., 2:26] = torch.exp(lvl[..., 2:26]) * s
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    dout = torch.randn(Bz, A, nc, generator=torch.Generator().manual_seed(55)).to(DEV)
+    dro = torch.zeros(Bz * 16, 32, dtype=BF, device=DEV)
+    dcl = torch.zeros(Bz * 16, 80, dtype=BF, device=DEV)
+    call("head_decode_bwd", ptr(dout), ptr(out), ptr(dro), ptr(dcl), Bz, A, a0, Hh, Ww, s, nc, sp())
+    d = dout.cpu()[:, a0:a0 + 16]
+    o = out.cpu()[:, a0:a0 + 16]
+    want = torch.cat([d[..., :2] * s, d[..., 2:26] * o[..., 2:26], d[..., 26:27]], -1).reshape(-1, 27)
+    close(dro[:, :27], want, rel=5e-3)
+    close(dcl, d[..., 27:].reshape(-1, 80), rel=5e-3)
+    assert float(dro[:, 27:].abs().sum()) == 0
+    # SGD nesterov, two steps vs torch.optim.SGD
+    n = 1003
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(56))
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pt], lr=0.01, momentum=0.9, nesterov=True)
+    p, buf, first = torch.zeros(1004, device=DEV), torch.zeros(1004, device=DEV), torch.ones(1, dtype=torch.int32, device=DEV)
+    p[:n] = p0.to(DEV)
+    for step in range(2):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(57 + step))
+        pt.grad = g.clone()
+        opt.step()
+        gd = torch.zeros(1004, device=DEV)
+        gd[:n] = g.to(DEV)
+        call("sgd_nesterov", ptr(p), ptr(gd), ptr(buf), 1004, 0.01, 0.9, 1.0, ptr(first), sp())
+        torch.testing.assert_close(p[:n].cpu(), pt.detach(), rtol=1e-6, atol=1e-7)

@@ -1,0 +1,333 @@
+"""GPU parity of the conv graph plan (ep24.engine) against the reference-generated golden vectors G7 and the
+CPU oracle, plus the captured training step.  bf16 operands / fp32 accumulation vs the fp32 reference: errors
+are judged relative to the tensor's largest magnitude."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from ep24 import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+def cos(got, want):
+    got, want = got.float().cpu().reshape(-1), want.float().cpu().reshape(-1)
+    return float(torch.dot(got, want) / (got.norm() * want.norm() + 1e-20))
+
+
+def make_block(name):
+    from ep24 import nn as enn
+    return {
+        "baseconv3": lambda: enn.BaseConv(16, 24, 3, 1), "baseconv3s2": lambda: enn.BaseConv(16, 32, 3, 2),
+        "baseconv1": lambda: enn.BaseConv(16, 8, 1, 1), "bottleneck": lambda: enn.Bottleneck(16, 16, True, 1.0),
+        "csp": lambda: enn.CSPLayer(16, 16, n=2), "csp_noshort": lambda: enn.CSPLayer(32, 16, n=1, shortcut=False),
+        "spp": lambda: enn.SPPBottleneck(16, 16), "focus": lambda: enn.Focus(3, 8, ksize=3),
+    }[name]()
+
+
+def block_engine(mod, name, x):
+    from ep24.engine import Engine
+
+    class BlockEngine(Engine):
+        def _build(self):
+            B, C, H, W = x.shape
+            if name == "focus":
+                self.images = x.to(self.dev).float().contiguous()
+                rows = self.new_act(112, H // 2, W // 2)
+                rows.needs_grad = False
+                self._f("stem_pack", self.images.data_ptr(), rows.ptr(), 112, B, H)
+                self.xin, out = None, self.unit(mod.conv, rows, stem=True)
+            else:
+                xin = self.new_act(C, H, W)
+                xin.buf.t.copy_(x.permute(0, 2, 3, 1).reshape(-1).to(BF))
+                self.xin = xin
+                if name.startswith("baseconv"):
+                    out = self.unit(mod, xin)
+                elif name == "bottleneck":
+                    out = self.unit(mod.conv2, self.unit(mod.conv1, xin), residual=xin)
+                elif name.startswith("csp"):
+                    out = self.csp(mod, xin)
+                else:
+                    out = self.spp(mod, xin)
+            out.gwrite()                         # the test plays the consumer: it fills d(out)
+            self.out = out
+            self._finalize()
+
+    return BlockEngine(mod, x.shape[0], x.shape[2])
+
+
+@pytest.mark.parametrize("name", ["baseconv3", "baseconv3s2", "baseconv1", "bottleneck", "csp", "csp_noshort", "spp", "focus"])
+def test_block_vs_golden(golden, name):
+    z = golden("g7_" + name)
+    mod = make_block(name)
+    mod.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    mod.to(DEV)
+    x = t(z["x"])
+    eng = block_engine(mod, name, x)
+    eng.forward()
+    o = eng.out
+    y = o.buf.t.view(o.buf.rows, o.buf.ld)[:, o.c0:o.c0 + o.C].reshape(o.B, o.H, o.W, o.C).permute(0, 3, 1, 2)
+    assert rel_err(y, t(z["y"])) < 2.5e-2, rel_err(y, t(z["y"]))
+    gy = t(z["gy"]).permute(0, 2, 3, 1).reshape(-1, o.C).to(DEV).to(BF)
+    o.buf.grad().view(o.buf.rows, o.buf.ld)[:, o.c0:o.c0 + o.C] = gy
+    eng.home.zero_grad()
+    eng.backward(torch.zeros(1, device=DEV))
+    if eng.xin is not None:
+        xi = eng.xin
+        r = xi._groot()                          # a residual input shares its gradient storage with the block output
+        gx = r.buf.grad().view(r.buf.rows, r.buf.ld)[:, r.c0:r.c0 + r.C].reshape(xi.B, xi.H, xi.W, xi.C).permute(0, 3, 1, 2)
+        if name == "spp":
+            # bf16 activations tie where the fp32 reference does not, so max-pool gradients may be routed to a
+            # neighbouring equal maximum (exact routing with ties is checked in test_gpu_conv.test_spp_fwd_bwd)
+            assert cos(gx, t(z["gx"])) > 0.95
+        else:
+            assert rel_err(gx, t(z["gx"])) < 4e-2, rel_err(gx, t(z["gx"]))
+    for k, p in mod.named_parameters():
+        want = t(z["g:" + k])
+        assert p.grad.shape == want.shape
+        if name == "spp" and k.startswith("conv1"):          # upstream of the pools: see the tie note below
+            assert cos(p.grad, want) > 0.95
+            continue
+        assert cos(p.grad, want) > 0.999 and rel_err(p.grad, want) < 5e-2, (k, cos(p.grad, want), rel_err(p.grad, want))
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            assert rel_err(v, t(z["after:" + k])) < 2e-2, k
+        if "num_batches" in k:
+            assert int(v) == int(z["after:" + k])
+
+
+def tiny_model(z=None):
+    from ep24 import nn as enn
+    m = enn.YOLOX(enn.YOLOPAFPN(0.33, 0.125), enn.YOLOXHead(80, 0.125))
+    if z is not None:
+        m.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    return m.to(DEV)
+
+
+def test_tiny_model_forward_backward_vs_golden(golden):
+    """Reference fp32 run of the whole graph (width 0.125, 64x64: the last level normalises over 8 values, so
+    bf16 storage noise is amplified; direction-level agreement is asserted here, tight agreement below)."""
+    z = golden("g7_model_tiny")
+    m = tiny_model(z)
+    assert sum(p.numel() for p in m.parameters()) == int(z["n_params"])
+    x = t(z["x"]).to(DEV)
+    xs, ys, ss, out, extra = m(x, train=True)
+    assert extra == [] and out.shape == (2, 84, 107)
+    assert torch.equal(xs[0].cpu(), t(z["x_shift0"])) and torch.equal(ys[1].cpu(), t(z["y_shift1"])) and torch.equal(ss[2].cpu(), t(z["stride2"]))
+    want = t(z["out"])
+    assert cos(out[..., :2], want[..., :2]) > 0.99 and cos(out[..., 26:], want[..., 26:]) > 0.99
+    assert cos(torch.log(out[..., 2:26]), torch.log(want[..., 2:26])) > 0.9
+    out.backward(t(z["gy"]).to(DEV))
+    params = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith("g:"):
+            g, w = params[k[2:]].grad, t(z[k])
+            assert g.shape == w.shape and torch.isfinite(g).all()
+            if "cls_preds" in k and k.endswith("bias"):
+                assert cos(g, w) > 0.999, (k, cos(g, w))
+    sd = m.state_dict()
+    assert rel_err(sd["backbone.backbone.stem.conv.bn.running_mean"], t(z["after:stem_rm"])) < 2e-2
+    assert rel_err(sd["backbone.backbone.stem.conv.bn.running_var"], t(z["after:stem_rv"])) < 2e-2
+    # state dict keeps the reference's names / logical shapes after the parameters moved into the flat buffer
+    for k in z.files:
+        if k.startswith("w:"):
+            assert tuple(sd[k[2:]].shape) == tuple(z[k].shape)
+
+
+def _paired_models(depth=0.33, width=0.25, seed=3):
+    from oracle import model as om
+    from ep24 import nn as enn
+    torch.manual_seed(seed)
+    ref = om.Net(depth, width)
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
+            torch.nn.init.uniform_(mod.bias, -0.2, 0.2)
+    m = enn.YOLOX(enn.YOLOPAFPN(depth, width), enn.YOLOXHead(80, width))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    return ref, m.to(DEV)
+
+
+def _act(a):
+    return a.buf.t.view(a.buf.rows, a.buf.ld)[:, a.c0:a.c0 + a.C].reshape(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).float().cpu()
+
+
+def test_every_layer_vs_oracle_on_the_plans_own_inputs():
+    """Random-init deep BN nets amplify 1-ulp differences layer by layer (the fp32 and the bf16-storage oracle
+    already differ by ~30 % rms at the head), so whole-net closeness says little.  Instead every conv unit of
+    the plan is checked in isolation: the oracle unit (bf16-storage emulation) is fed the plan's OWN input
+    activation and must reproduce the plan's output to bf16 rounding."""
+    from oracle import model as om
+    ref, m = _paired_models()
+    B, S = 4, 256
+    out = m(synth.make_images(B, S, seed=9).to(DEV), train=True)[3]
+    eng = m.engine(B, S)
+    rmods = dict(ref.named_modules())
+    names = {mod: n for n, mod in m.named_modules()}
+    ref.train()
+    om.EMULATE_BF16 = True
+    worst = 0.0
+    try:
+        with torch.no_grad():
+            for mod, (xin, z, y) in eng.unit_acts.items():
+                n = names[mod]
+                runit = rmods[n]
+                if n.endswith("stem.conv"):
+                    continue                                  # input is the im2col matrix; covered by the focus block test
+                want = runit(_act(xin))
+                got = _act(y)
+                parent = rmods[n.rsplit(".", 1)[0]]
+                if isinstance(parent, om.Res) and n.endswith("conv2") and parent.add:
+                    want = want + _act(eng.unit_acts[dict(m.named_modules())[n.rsplit(".", 1)[0]].conv1][0])
+                e = rel_err(got, want)
+                worst = max(worst, e)
+                assert e < 1.2e-2, (n, e)
+    finally:
+        om.EMULATE_BF16 = False
+    # head: decoded outputs from the plan's own last features
+    assert torch.isfinite(out).all()
+    print("worst per-layer rel err", worst)
+
+
+def test_forward_is_bitwise_reproducible():
+    _, m = _paired_models()
+    x = synth.make_images(2, 128, seed=4).to(DEV)
+    a = m(x, train=True)[3].clone()
+    b = m(x, train=True)[3].clone()
+    assert torch.equal(a, b)
+
+
+def _gact(a):
+    r = a._groot()
+    return r.buf.grad().view(r.buf.rows, r.buf.ld)[:, r.c0:r.c0 + r.C].reshape(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).float().cpu()
+
+
+def test_every_layer_backward_vs_oracle_on_the_plans_own_tensors():
+    """Teacher-forced backward: for every conv unit whose output gradient survives the backward pass untouched,
+    the oracle unit gets the plan's own input activation and the plan's own d(output) and must reproduce the
+    plan's weight / gamma / beta gradients (each of those is written by exactly one layer)."""
+    from oracle import model as om
+    ref, m = _paired_models()
+    B, S = 4, 256
+    gy = torch.randn(B, (S // 8) ** 2 + (S // 16) ** 2 + (S // 32) ** 2, 107, generator=torch.Generator().manual_seed(10)) * 1e-2
+    out = m(synth.make_images(B, S, seed=9).to(DEV), train=True)[3]
+    out.backward(gy.to(DEV))
+    eng = m.engine(B, S)
+    rmods = dict(ref.named_modules())
+    mmods = dict(m.named_modules())
+    names = {mod: n for n, mod in m.named_modules()}
+    ref.train()
+    checked = 0
+    om.EMULATE_BF16 = True
+    try:
+        for mod, (xin, z, y) in eng.unit_acts.items():
+            n = names[mod]
+            parent = rmods[n.rsplit(".", 1)[0]]
+            if n.endswith("stem.conv"):
+                continue
+            if isinstance(parent, om.Res) and parent.add and n.endswith("conv2"):
+                continue                  # d(out) storage is reused for d(block input) later in the pass
+            runit = rmods[n]
+            runit.zero_grad()
+            x = _act(xin)
+            yy = runit(x)
+            yy.backward(_gact(y))
+            for pname, rp in (("conv.weight", runit.conv.weight), ("bn.weight", runit.bn.weight), ("bn.bias", runit.bn.bias)):
+                g = dict(mod.named_parameters())[pname].grad
+                assert cos(g, rp.grad) > 0.9995 and rel_err(g, rp.grad) < 3e-2, (n, pname, cos(g, rp.grad), rel_err(g, rp.grad))
+            checked += 1
+    finally:
+        om.EMULATE_BF16 = False
+    assert checked >= 50, checked
+
+
+def test_model_gradients_are_finite_and_head_directions_match_oracle():
+    from oracle import model as om
+    ref, m = _paired_models()
+    B, S = 4, 256
+    x = synth.make_images(B, S, seed=9)
+    gy = torch.randn(B, (S // 8) ** 2 + (S // 16) ** 2 + (S // 32) ** 2, 107, generator=torch.Generator().manual_seed(10)) * 1e-2
+    om.EMULATE_BF16 = True
+    try:
+        ref.train()
+        o_ref = ref(x, train=True)[3]
+        o_ref.backward(gy)
+    finally:
+        om.EMULATE_BF16 = False
+    out = m(x.to(DEV), train=True)[3]
+    out.backward(gy.to(DEV))
+    rp = dict(ref.named_parameters())
+    cs = {k: cos(p.grad, rp[k].grad) for k, p in m.named_parameters()}
+    # class / objectness biases: column sums of the incoming gradient, independent of the (chaotic) features
+    bias = [v for k, v in cs.items() if ("cls_preds" in k or "obj_preds" in k) and k.endswith("bias")]
+    assert min(bias) > 0.9999, min(bias)
+    assert torch.isfinite(torch.cat([p.grad.reshape(-1) for p in m.parameters()])).all()
+
+
+def test_eager_api_step_matches_captured_step():
+    """Reference-style loop (model -> Loss_Function -> backward -> optimizer.step) vs the hipGraph TrainStep."""
+    from ep24 import loss as eloss, train as etrain
+    torch.manual_seed(0)
+    ma = tiny_model()
+    mb = tiny_model()
+    mb.load_state_dict(ma.state_dict())
+    B, S = 4, 128
+    images = synth.make_images(B, S, seed=1).to(DEV)
+    labels = synth.make_labels(B, [3, 0, 5, 2], size=S, seed=2).to(DEV)
+    # a) eager, through the drop-in API
+    lf_a = eloss.Loss_Function(80)
+    lf_a.draw = False
+    opt = etrain.SGD(ma.parameters(), lr=0.01, momentum=0.9, nesterov=True, model=ma)
+    losses_a = []
+    for _ in range(3):
+        opt.zero_grad()
+        tup = lf_a(ma(images, train=True), labels)
+        tup[0].backward()
+        opt.step()
+        losses_a.append(float(tup[0]))
+    # b) captured
+    lf_b = eloss.Loss_Function(80)
+    ts = etrain.TrainStep(mb, lf_b, lr=0.01, momentum=0.9, batch=B, size=S)
+    losses_b = [float(ts.step(images, labels)[0]) for _ in range(3)]
+    print("eager", losses_a, "captured", losses_b)
+    assert all(np.isfinite(losses_a)) and all(np.isfinite(losses_b))
+    # the forward pass is bitwise reproducible, so the first loss is identical; afterwards the fp32-atomic
+    # weight-gradient sums (order dependent in the last bits) are amplified by the random-init net
+    assert losses_a[0] == losses_b[0]
+    np.testing.assert_allclose(losses_a, losses_b, rtol=5e-2)
+    assert losses_a[0] != losses_a[1]
+    pa = torch.cat([p.detach().reshape(-1) for p in ma.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in mb.parameters()])
+    assert cos(pa, pb) > 0.99
+    # BN statistics advanced exactly 3 times in both (the capture warm-up must not count)
+    assert int(ma.backbone.backbone.stem.conv.bn.num_batches_tracked) == 3
+    assert int(mb.backbone.backbone.stem.conv.bn.num_batches_tracked) == 3
+
+
+def test_loss_of_model_outputs_matches_oracle_assignment():
+    """L2 boundary on real network outputs: feed the HIP model's own outputs to the CPU oracle loss."""
+    from ep24 import loss as eloss
+    from oracle.loss import LossOracle
+    m = tiny_model()
+    B, S = 3, 128
+    images = synth.make_images(B, S, seed=5).to(DEV)
+    labels = synth.make_labels(B, [4, 7, 1], size=S, seed=6)
+    lf = eloss.Loss_Function(80)
+    tup_in = m(images, train=True)
+    tup = lf(tup_in, labels.to(DEV))
+    out_cpu = tup_in[3].detach().cpu()
+    ora = LossOracle(80)
+    o_tup = ora(synth.outputs_train_tuple(out_cpu, size=S), labels)
+    torch.testing.assert_close(tup[0].detach().cpu(), o_tup[0].detach(), rtol=1e-4, atol=1e-6)
+    for b in range(B):
+        cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, b)
+        o = ora.trace[b]
+        assert nfg == o[4] and torch.equal(fg.cpu(), o[1]) and torch.equal(gt_idx.cpu(), o[3])
