@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of YOLOX-l-24p, 640x640, bf16, batch 20 per GPU (BASELINE.json config 2;
+--gpus N shards a global batch of 20*N over N ranks = config 3).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = zero grads -> forward (131 MFMA convs + BN/SiLU) -> SimOTA + 24-circle loss -> backward -> (RCCL gradient
+all-reduce) -> fused SGD, on synthetic images / labels already resident in HBM (SURVEY.md 8d generator).
+Rank 0 prints ONE JSON line with the whole-job images/s, the roofline of the dominant kernel (HIP events around
+each of its launches in an instrumented eager step of the same workload) and, at N=1, a CPU baseline: the
+oracle's fp32 train step timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "exploration-of-potential_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+TRAIN_GFLOP_PER_IMAGE = 466.2       # 3 x 2 x 77.694 GMAC, BASELINE.md section 3
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def conv_flops(args):
+    B, H, W, Cin, Cout, k, s = args[-7:]
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    return 2.0 * B * OH * OW * Cin * Cout * k * k
+
+
+def instrumented_step(ts):
+    """Eager pass over the same launch lists with an event pair round every conv launch."""
+    from ep24 import _lib, loss as eloss
+    eng = ts.eng
+    fn = _lib.lib().fn
+    rec = []
+
+    def run(lst):
+        s = _lib.stream_ptr()
+        for name, args in lst:
+            a = [x.get() if hasattr(x, "get") else x for x in args]
+            timed = name.startswith("conv_")
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = fn["ep24_" + name](*a, s)
+            assert rc == 0, (name, _lib.lib().last_error())
+            if timed:
+                e1.record()
+                rec.append((name, conv_flops(args), e0, e1))
+
+    ts.home.zero_grad()
+    eng.zero_step_buffers()
+    ts.home.pack()
+    run(eng.fwd)
+    eloss.assign_and_reduce(ts.ws, eng.outputs, ts.labels, ts.xs, ts.ys, ts.st, ts.state)
+    eloss.loss_grad(ts.ws, eng.outputs, ts.labels)
+    eng.dyn["dout"] = ts.ws.dout.data_ptr()
+    run(eng.bwd)
+    torch.cuda.synchronize()
+    fam = {}
+    for name, fl, e0, e1 in rec:
+        kern = "wgrad_kernel" if name == "conv_wgrad_bf16" else "igemm_kernel"
+        f = fam.setdefault(kern, dict(flops=0.0, ms=0.0, launches=0))
+        f["flops"] += fl
+        f["ms"] += e0.elapsed_time(e1)
+        f["launches"] += 1
+    return fam
+
+
+def cpu_baseline(steps=2):
+    """Oracle (CPU restatement, fp32) train step of YOLOX-l-24p at B=1, 640x640, 5 GTs on the host cores."""
+    from ep24 import synth
+    from oracle import model as om
+    from oracle.loss import LossOracle
+    torch.manual_seed(0)
+    net = om.Net(1.0, 1.0)
+    net.train()
+    lf = LossOracle(80)
+    params = list(net.parameters())
+    bufs = [None] * len(params)
+    x = synth.make_images(1, 640, seed=1)
+    labels = synth.make_labels(1, 5, seed=2)
+
+    def one():
+        for p in params:
+            p.grad = None
+        tup = lf(net(x, train=True), labels)
+        tup[0].backward()
+        om.sgd_nesterov_step(params, bufs, 0.01)
+        return float(tup[0])
+
+    one()                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return dict(value=round(steps / dt, 4), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle fp32 train step (fwd+SimOTA loss+bwd+SGD), YOLOX-l-24p, B=1, 640x640, 5 GTs, %d steps after 1 warm-up" % steps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=20, help="per-GPU batch (BASELINE config 2: 20)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--gts", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    from ep24 import dp, loss as eloss, nn as enn, synth, train as etrain
+
+    world = a.gpus
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        assert int(os.environ.get("WORLD_SIZE", 1)) == world, "launch with torch.distributed.run --nproc-per-node N"
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)                                     # identical replicas on every rank
+    model = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
+    model.head.initialize_biases(1e-2)
+    model.to(dev)
+    lf = eloss.Loss_Function(80)
+    reducer = dp.GradReducer() if world > 1 else None
+    ts = etrain.TrainStep(model, lf, lr=0.001, momentum=0.9, batch=a.batch, size=a.size, reducer=reducer,
+                          use_graph=not a.no_graph)
+    # this rank's shard of the synthetic global batch (weak scaling: per-GPU work fixed)
+    images = synth.make_images(a.batch, a.size, seed=1 + rank).to(dev)
+    labels = synth.make_labels(a.batch, a.gts, size=a.size, seed=1000 + rank).to(dev)
+    ts.eng.images.copy_(images)
+    ts.labels.copy_(labels)
+
+    for _ in range(a.warmup):
+        ts.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(ts.ws.result[0])
+    ips = world * a.batch * a.steps / dt
+
+    out = None
+    if rank == 0:
+        fam = instrumented_step(ts)
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[dom]
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        out = {
+            "metric": "training images/sec, YOLOX-l 24p 640x640 bf16", "value": round(ips, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "YOLOX-l-24p (CSPDarknet53+PAFPN+24p head) train step, %dx%d, batch %d/GPU, %d GTs/img, "
+                                   "SimOTA + 24-circle GIoU loss, SGD nesterov" % (a.size, a.size, a.batch, a.gts),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": not a.no_graph},
+            "loss": round(loss, 4),
+            "step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE * (a.size / 640.0) ** 2 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
+                         "families": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"], 3),
+                                          "launches": v["launches"]} for k, v in fam.items()}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
