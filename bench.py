@@ -65,6 +65,18 @@ def instrumented_step(ts):
     eng.dyn["dout"] = ts.ws.dout.data_ptr()
     run(eng.bwd)
     torch.cuda.synchronize()
+    if os.environ.get("EP24_LAYER_TABLE"):
+        rows = {}
+        for (name, fl, e0, e1), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].startswith("conv_")]):
+            key = (name,) + tuple(args[-7:])
+            r = rows.setdefault(key, [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += fl
+            r[2] += e0.elapsed_time(e1)
+        with open(os.environ["EP24_LAYER_TABLE"], "w") as fh:
+            fh.write("kernel B H W Cin Cout k s : launches  ms_total  TFLOP/s\n")
+            for key, (n, fl, ms) in sorted(rows.items(), key=lambda kv: -kv[1][2]):
+                fh.write("%-18s %s : %3d %8.3f %8.1f\n" % (key[0], " ".join("%4d" % v for v in key[1:]), n, ms, fl / ms / 1e9))
     fam = {}
     for name, fl, e0, e1 in rec:
         kern = "wgrad_kernel" if name == "conv_wgrad_bf16" else "igemm_kernel"

@@ -7,7 +7,8 @@
 // dgrad are all instances of this one gather-GEMM (host wrappers at the bottom build the tap tables).
 //
 // Tiling: 128 x BN x 64 per workgroup of 4 waves (64-lane), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
-// Global -> registers -> LDS (register staging, the gather needs per-lane addresses and zero fill);
+// Global -> registers -> LDS (register staging, the gather needs per-lane addresses and zero fill), one LDS
+// stage and 4 co-resident workgroups per CU instead of a deep per-workgroup pipeline;
 // LDS rows are 128 B (64 bf16) with the 16-B chunk index XOR-ed by (row & 7): ds_write_b128 of one row by 8
 // lanes and ds_read_b128 of 16 rows x {chunk c, c+1} by a wave are both bank-conflict free.
 // Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel
@@ -25,6 +26,7 @@ struct IgemmArgs {
     int accumulate;
     const float* bias;
     long long* stats; int stats_replicas;
+    int b_resident_max;
     long M;
 };
 
@@ -33,7 +35,7 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, bool PERSIST>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64;            // waves along N
     constexpr int WM = 4 / WN;             // waves along M
@@ -43,33 +45,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     constexpr int B_BYTES = BN * 128;
     constexpr int B_PIECES = BN * 8 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto lds_a = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES); };
-    auto lds_b = [&](int buf) -> char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
+    // ONE LDS stage for A (16 KB) so that up to 4 workgroups share a CU: while one waits at its barriers or for
+    // HBM the others keep the MFMA pipe and the memory system busy; the next tile's global loads are issued
+    // before the MFMAs of the current one and land in registers meanwhile.  The workgroup is persistent over M
+    // tiles (blockIdx.x, stride gridDim.x): the prefetch runs across tile boundaries, BN statistics stay in
+    // registers until the end (one atomic per channel per workgroup) and, when the whole K extent fits in
+    // MAX_RESIDENT stages, the weight tiles are loaded once and stay in LDS.
+    const int KC = (p.K + BK - 1) / BK;          // K is a multiple of 8; the last 64-chunk may be partial
+    const int n_iter = p.T * KC;
+    const bool b_resident = PERSIST && n_iter <= p.b_resident_max;
+    char* const lds_a = smem;
+    char* const lds_b0 = smem + A_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    const int my_tiles = PERSIST ? (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int total = my_tiles * n_iter;
 
-    // ---- per-thread gather bookkeeping: 4 A rows (tid>>3)+32i, chunk tid&7
+    // ---- per-thread gather bookkeeping for the tile being LOADED: 4 A rows (tid>>3)+32i, chunk tid&7
     const int chunk = tid & 7;
     const int lrow = tid >> 3;
     int pixbase[4], iy0[4], ix0[4];
     bool rvalid[4];
+    auto setup_rows = [&](int tile) {
+        const long m0 = (long)tile * BM;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        long m = m0 + lrow + 32 * i;
-        rvalid[i] = m < p.M;
-        long mm = rvalid[i] ? m : 0;
-        int n = (int)(mm / (p.GH * p.GW));
-        int rem = (int)(mm - (long)n * (p.GH * p.GW));
-        int gy = rem / p.GW, gx = rem - gy * p.GW;
-        pixbase[i] = n * p.SH * p.SW;
-        iy0[i] = gy * p.sy;
-        ix0[i] = gx * p.sx;
-    }
+        for (int i = 0; i < 4; ++i) {
+            long m = m0 + lrow + 32 * i;
+            rvalid[i] = m < p.M;
+            long mm = rvalid[i] ? m : 0;
+            int n = (int)(mm / (p.GH * p.GW));
+            int rem = (int)(mm - (long)n * (p.GH * p.GW));
+            int gy = rem / p.GW, gx = rem - gy * p.GW;
+            pixbase[i] = n * p.SH * p.SW;
+            iy0[i] = gy * p.sy;
+            ix0[i] = gx * p.sx;
+        }
+    };
     // B rows: weight row n -> LDS row (relabelled inside each 64 span)
     int brow_g[B_PIECES], brow_l[B_PIECES];
 #pragma unroll
@@ -79,13 +95,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         brow_l[i] = (r & ~63) + ((r & 3) << 4) + ((r >> 2) & 15);
     }
 
-    const int KC = (p.K + BK - 1) / BK;          // K is a multiple of 8; the last 64-chunk may be partial
-    const int n_iter = p.T * KC;
     bf16x8 ra[4], rb[B_PIECES];
+    int ld_it = 0, ld_tile = blockIdx.x;             // (K-step, M tile) of the next load
+    bool ld_first = true;                            // still inside this workgroup's first M tile
 
-    auto load_tile = [&](int it) {
-        const int t = it / KC;
-        const int kc = it - t * KC;
+    auto load_tile = [&]() {
+        if (ld_it == 0) setup_rows(ld_tile);
+        const int t = ld_it / KC;
+        const int kc = ld_it - t * KC;
         const int oy = p.oy[t], ox = p.ox[t];
         const bool kok = kc * BK + chunk * 8 < p.K;
 #pragma unroll
@@ -99,61 +116,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             }
             ra[i] = v;
         }
-        const long wtap = (long)p.wslot[t] * p.K + kc * BK + chunk * 8;
+        if (!b_resident || ld_first) {
+            const long wtap = (long)p.wslot[t] * p.K + kc * BK + chunk * 8;
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kok && brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
-            rb[i] = v;
+            for (int i = 0; i < B_PIECES; ++i) {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kok && brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
+                rb[i] = v;
+            }
         }
     };
-    auto store_tile = [&](int buf) {
+    // the tile held in registers is (st_it, st_first); advance the load cursor after each load
+    int st_it = 0;
+    bool st_first = true;
+    auto advance_load = [&]() {
+        st_it = ld_it; st_first = ld_first;
+        if (++ld_it == n_iter) { ld_it = 0; ld_tile += gridDim.x; ld_first = false; }
+    };
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<bf16x8*>(lds_a(buf) + swz(lrow + 32 * i, chunk)) = ra[i];
+            *reinterpret_cast<bf16x8*>(lds_a + swz(lrow + 32 * i, chunk)) = ra[i];
+        if (!b_resident || st_first) {
+            char* lb = lds_b0 + (b_resident ? st_it * B_BYTES : 0);
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            *reinterpret_cast<bf16x8*>(lds_b(buf) + swz(brow_l[i], chunk)) = rb[i];
+            for (int i = 0; i < B_PIECES; ++i)
+                *reinterpret_cast<bf16x8*>(lb + swz(brow_l[i], chunk)) = rb[i];
+        }
     };
 
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int frow = lane & 15;      // row inside a 16-row tile (A: pixel, B: relabelled channel)
     const int fq = lane >> 4;        // k-chunk inside a 32-deep k-step
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int it = 0; it < n_iter; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < n_iter;
-        if (more) load_tile(it + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[MT], fb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(lds_a(cur) + swz(wm * (MT * 16) + i * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8*>(lds_b(cur) + swz(wn * 64 + j * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue.  lane owns channels c0..c0+3 (n-tiles 0..3) of pixels 4*fq + r of every m-tile
-    const int c0 = n0 + wn * 64 + 4 * frow;
+    const int c0 = n0 + wn * 64 + 4 * frow;      // lane owns channels c0..c0+3 (n-tiles 0..3)
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
@@ -163,77 +158,143 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
                            p.dbs == (long)p.GH * p.GW);
+
+    if (total > 0) { load_tile(); advance_load(); }
+    int j = 0, tile = blockIdx.x;
+    for (int tl = 0; tl < my_tiles; ++tl) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
-            if (m >= p.M) continue;
-            long dpix = m;
-            if (!fast_dst) {
-                int n = (int)(m / (p.GH * p.GW));
-                int rem = (int)(m - (long)n * (p.GH * p.GW));
-                int gy = rem / p.GW, gx = rem - gy * p.GW;
-                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+            for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < n_iter; ++it, ++j) {
+            if (j) __syncthreads();                // every wave is done reading the previous stage
+            store_tile();
+            __syncthreads();
+            if (j + 1 < total) load_tile();        // in flight during the MFMAs below
+            const char* lb = lds_b0 + (b_resident ? it * B_BYTES : 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(lds_a + swz(wm * (MT * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    fb[q] = *reinterpret_cast<const bf16x8*>(lb + swz(wn * 64 + q * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
             }
-            float v[4];
+            if (j + 1 < total) advance_load();
+        }
+
+        // ---- epilogue of this M tile: pixels 4*fq + r of every m-tile, channels c0..c0+3
+        const long m0 = (long)tile * BM;
+        tile += gridDim.x;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc[i][j][r] + bias4[j];
-                s1[j] += v[j];
-                s2[j] += v[j] * v[j];
-            }
-            if constexpr (OUT_F32) {
-                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c0 + j < p.N) d[j] = p.accumulate ? d[j] + v[j] : v[j];
-            } else {
-                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
-                if (c0 + 3 < p.N) {
-                    if (p.accumulate) {
-                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
+                if (m >= p.M) continue;
+                long dpix = m;
+                if (!fast_dst) {
+                    int n = (int)(m / (p.GH * p.GW));
+                    int rem = (int)(m - (long)n * (p.GH * p.GW));
+                    int gy = rem / p.GW, gx = rem - gy * p.GW;
+                    dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+                }
+                float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)o[j];
-                    }
-                    bf16x4 w;
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = acc[i][q][r] + bias4[q];
+                    s1[q] += v[q];
+                    s2[q] += v[q] * v[q];
+                }
+                if constexpr (OUT_F32) {
+                    float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (bf16)v[j];
-                    *reinterpret_cast<bf16x4*>(d) = w;
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
                 } else {
+                    bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
+                    if (c0 + 3 < p.N) {
+                        if (p.accumulate) {
+                            bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c0 + j < p.N) d[j] = (bf16)(p.accumulate ? (float)d[j] + v[j] : v[j]);
+                            for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                        }
+                        bf16x4 w;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                        *reinterpret_cast<bf16x4*>(d) = w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                    }
                 }
             }
         }
     }
+
     if (p.stats) {
-        // rows >= M contributed nothing (skipped above); reduce the 4 lane groups that share a channel
-        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        // per-channel sums of this workgroup: fold the 4 lane groups of a wave, then the WM waves that share
+        // the channel range through LDS, then ONE fixed-point atomic per channel (coalesced, 512 B per wave)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = s1[j], b = s2[j];
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (fq == 0 && c0 + j < p.N) {
-                atomicAdd((unsigned long long*)(st + c0 + j), (unsigned long long)to_fix(a));
-                atomicAdd((unsigned long long*)(st + p.N + c0 + j), (unsigned long long)to_fix(b));
+            if (fq == 0) {
+                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
+                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
             }
+        }
+        __syncthreads();
+        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;      // channel inside the tile
+            const int wcol = c >> 6;                            // wave column owning it
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
 }
 
-int launch(const IgemmArgs& a, bool out_f32, hipStream_t stream) {
+template <int BN, bool F32>
+void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
+    if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((igemm_kernel<BN, F32, false>), grid, dim3(256), lds, stream, a);
+}
+
+int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     const bool wide = a.N > 64;
-    dim3 grid(ep24_cdiv(a.M, BM), ep24_cdiv(a.N, wide ? 128 : 64));
-    size_t lds = 2 * (BM * 128 + (wide ? 128 : 64) * 128);
+    const int gy = ep24_cdiv(a.N, wide ? 128 : 64);
+    const int tiles_m = ep24_cdiv(a.M, BM);
+    // Large-M layers (memory bound, thousands of M tiles) run persistent workgroups: ~4 per CU, each walking
+    // several M tiles; MFMA-bound layers with few tiles keep the lean one-tile-per-workgroup kernel.
+    const bool persist = (long)tiles_m * gy > 2048;
+    int gx = persist ? 1024 / gy : tiles_m;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, gy);
+    const int n_iter = a.T * ((a.K + BK - 1) / BK);
+    // keep the weight tiles resident in LDS when the whole reduction fits in two stages
+    a.b_resident_max = (persist && n_iter <= 2) ? 2 : 0;
+    const int b_stages = a.b_resident_max ? n_iter : 1;
+    size_t lds = BM * 128 + (size_t)b_stages * (wide ? 128 : 64) * 128;
     if (wide) {
-        if (out_f32) hipLaunchKernelGGL((igemm_kernel<128, true>), grid, dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((igemm_kernel<128, false>), grid, dim3(256), lds, stream, a);
+        if (out_f32) launch_variant<128, true>(a, persist, grid, lds, stream);
+        else launch_variant<128, false>(a, persist, grid, lds, stream);
     } else {
-        if (out_f32) hipLaunchKernelGGL((igemm_kernel<64, true>), grid, dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((igemm_kernel<64, false>), grid, dim3(256), lds, stream, a);
+        if (out_f32) launch_variant<64, true>(a, persist, grid, lds, stream);
+        else launch_variant<64, false>(a, persist, grid, lds, stream);
     }
     EP24_LAUNCH_CHECK("ep24_conv_igemm");
     return EP24_OK;

@@ -41,8 +41,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row_lo, int cb, 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int TILE_BYTES = 64 * 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto lds_y = [&](int buf) -> char* { return smem + buf * 2 * TILE_BYTES; };
-    auto lds_x = [&](int buf) -> char* { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+    auto lds_y = [&](int) -> char* { return smem; };                    // one stage: 32 KB, 4 workgroups per CU
+    auto lds_x = [&](int) -> char* { return smem + TILE_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -97,14 +97,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int q = (lane & 15) >> 2;      // row inside the 4-row transposed block this lane addresses
     const int pp4 = lane & 3;            // 4-channel sub-slot this lane addresses
 
-    if (n_iter > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
+    if (n_iter > 0) load_tile(0);
     for (int it = 0; it < n_iter; ++it) {
-        const int cur = it & 1;
+        const int cur = 0;
         const bool more = it + 1 < n_iter;
+        if (it) __syncthreads();
+        store_tile(0);
+        __syncthreads();
         if (more) load_tile(it + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -120,8 +119,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
     }
 
     // D[row = co][col = ci]: row = 4*fq + r, col = lane & 15
@@ -168,7 +165,7 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     a.chunk = ((steps + splits - 1) / splits) * 64;
     splits = (a.M + a.chunk - 1) / a.chunk;
     dim3 grid(tiles, (unsigned)splits);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 4 * 64 * 256, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 2 * 64 * 256, (hipStream_t)stream, a);
     EP24_LAUNCH_CHECK("ep24_conv_wgrad");
     return EP24_OK;
 }

@@ -25,57 +25,70 @@ struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by
 };
 
 // ---------------------------------------------------------------------------------------- BN + act forward
+// Prologue: the block folds the fixed-point statistics into per-channel scale / shift in LDS (one channel per
+// thread, 2*reps loads).  Body: flat grid-stride over 16-byte chunks, consecutive lanes on consecutive
+// addresses whatever C is, 2 chunks in flight per lane.
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const long long* stats, int reps,
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, long* nbt, float* save, bf16* y, long ld_y,
                                                          const bf16* res, long ld_res, long M, int C, float eps,
                                                          float momentum, int act) {
-    const RowMap rm(C);
-    const int tid = threadIdx.x;
-    for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048
-        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
-        if (slot >= rm.rpb) break;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            long long i1 = 0, i2 = 0;
-            for (int r = 0; r < reps; ++r) {
-                i1 += stats[(long)r * 2 * C + c];
-                i2 += stats[(long)r * 2 * C + C + c];
-            }
-            const float mean = from_fix(i1) / (float)M;
-            float var = from_fix(i2) / (float)M - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            const float invstd = rsqrtf(var + eps);
-            sc[j] = gamma[c] * invstd;
-            sh[j] = beta[c] - mean * sc[j];
-            if (blockIdx.x == 0 && slot == 0) {
-                save[c] = mean;
-                save[C + c] = invstd;
-                if (rmean) {
-                    const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
-                    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-                    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
-                }
+    extern __shared__ float lds[];
+    float* sc = lds;
+    float* sh = lds + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        long long i1 = 0, i2 = 0;
+        for (int r = 0; r < reps; ++r) {
+            i1 += stats[(long)r * 2 * C + c];
+            i2 += stats[(long)r * 2 * C + C + c];
+        }
+        const float mean = from_fix(i1) / (float)M;
+        float var = from_fix(i2) / (float)M - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float invstd = rsqrtf(var + eps);
+        const float s_ = gamma[c] * invstd;
+        sc[c] = s_;
+        sh[c] = beta[c] - mean * s_;
+        if (blockIdx.x == 0) {
+            save[c] = mean;
+            save[C + c] = invstd;
+            if (rmean) {
+                const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
             }
         }
-        if (blockIdx.x == 0 && slot == 0 && cg == 0 && nbt) *nbt += 1;
-        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
-            float v[8];
-            load8(z + m * ld_z + cg * 8, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    __syncthreads();
+    const int cgs = C >> 3;
+    const long total = M * cgs;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += 2 * stride) {
+        const long i2 = i + stride;
+        const bool two = i2 < total;
+        const long m0 = i / cgs, m1 = two ? i2 / cgs : 0;
+        const int g0 = (int)(i - m0 * cgs), g1 = two ? (int)(i2 - m1 * cgs) : 0;
+        float v0[8], v1[8], r0[8], r1[8];
+        load8(z + m0 * ld_z + g0 * 8, v0);
+        if (two) load8(z + m1 * ld_z + g1 * 8, v1);
+        if (res) {
+            load8(res + m0 * ld_res + g0 * 8, r0);
+            if (two) load8(res + m1 * ld_res + g1 * 8, r1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = v0[j] * sc[g0 * 8 + j] + sh[g0 * 8 + j];
+            v0[j] = (act ? u * sigmoidf_(u) : u) + (res ? r0[j] : 0.f);
+        }
+        store8(y + m0 * ld_y + g0 * 8, v0);
+        if (two) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float u = v[j] * sc[j] + sh[j];
-                v[j] = act ? u * sigmoidf_(u) : u;
+                const float u = v1[j] * sc[g1 * 8 + j] + sh[g1 * 8 + j];
+                v1[j] = (act ? u * sigmoidf_(u) : u) + (res ? r1[j] : 0.f);
             }
-            if (res) {
-                float r[8];
-                load8(res + m * ld_res + cg * 8, r);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += r[j];
-            }
-            store8(y + m * ld_y + cg * 8, v);
+            store8(y + m1 * ld_y + g1 * 8, v1);
         }
     }
 }
@@ -96,11 +109,15 @@ __device__ __forceinline__ void du_zhat(const float (&dy)[8], const float (&z)[8
     }
 }
 
+// Column sums over rows: every thread keeps one 8-channel group for the whole kernel (register accumulators),
+// the row slots of a block are folded through LDS in a fixed order and the block's totals leave as coalesced
+// fixed-point atomics (lane l -> channel l: 512 contiguous bytes per wave instruction).
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                 const float* save, const float* gamma,
                                                                 const float* beta, long long* dgamma, long long* dbeta,
                                                                 long M, int C, int act) {
     __shared__ float red[2][256][8 + 1];
+    __shared__ float fin[2][2048];
     const RowMap rm(C);
     const int tid = threadIdx.x;
     for (int cg0 = 0; cg0 < (C >> 3); cg0 += 256) {
@@ -115,27 +132,44 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
                 const int c = cg * 8 + j;
                 mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
             }
-            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
-                float vdy[8], vz[8], du[8], zh[8];
+            const long step = (long)gridDim.x * rm.rpb;
+            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += 2 * step) {
+                const long m2 = m + step;
+                const bool two = m2 < M;
+                float vdy[8], vz[8], du[8], zh[8], wdy[8], wz[8];
                 load8(dy + m * ld_dy + cg * 8, vdy);
                 load8(z + m * ld_z + cg * 8, vz);
+                if (two) {
+                    load8(dy + m2 * ld_dy + cg * 8, wdy);
+                    load8(z + m2 * ld_z + cg * 8, wz);
+                }
                 du_zhat(vdy, vz, mean, inv, g, b, act, du, zh);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sb[j] += du[j]; sg[j] += du[j] * zh[j]; }
+                if (two) {
+                    du_zhat(wdy, wz, mean, inv, g, b, act, du, zh);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { sb[j] += du[j]; sg[j] += du[j] * zh[j]; }
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[0][tid][j] = sg[j]; red[1][tid][j] = sb[j]; }
         __syncthreads();
-        // threads of row slot 0 fold the other slots (fixed order) and publish
         if (active && slot == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float a = 0.f, b2 = 0.f;
-                for (int s = 0; s < rm.rpb; ++s) { a += red[0][s * rm.tpr + (tid % rm.tpr)][j]; b2 += red[1][s * rm.tpr + (tid % rm.tpr)][j]; }
-                atomicAdd((unsigned long long*)(dgamma + cg * 8 + j), (unsigned long long)to_fix(a));
-                atomicAdd((unsigned long long*)(dbeta + cg * 8 + j), (unsigned long long)to_fix(b2));
+                for (int s = 0; s < rm.rpb; ++s) { a += red[0][s * rm.tpr + tid][j]; b2 += red[1][s * rm.tpr + tid][j]; }
+                fin[0][(cg - cg0) * 8 + j] = a;
+                fin[1][(cg - cg0) * 8 + j] = b2;
             }
+        }
+        __syncthreads();
+        const int nch = min(2048, C - cg0 * 8);
+        for (int c = tid; c < nch; c += 256) {
+            atomicAdd((unsigned long long*)(dgamma + cg0 * 8 + c), (unsigned long long)to_fix(fin[0][c]));
+            atomicAdd((unsigned long long*)(dbeta + cg0 * 8 + c), (unsigned long long)to_fix(fin[1][c]));
         }
         __syncthreads();
     }
@@ -145,41 +179,49 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
                                                                const float* save, const float* gamma, const float* beta,
                                                                const long long* dgamma, const long long* dbeta, float* ggrad,
                                                                float* bgrad, bf16* dz, long ld_dz, long M, int C, int act) {
-    const RowMap rm(C);
-    const int tid = threadIdx.x;
+    extern __shared__ float lds[];
+    float* k_mean = lds;             // per channel: mean, invstd, gamma, beta, dgamma/M, dbeta/M
+    float* k_inv = lds + C;
+    float* k_g = lds + 2 * C;
+    float* k_b = lds + 3 * C;
+    float* k_mg = lds + 4 * C;
+    float* k_mb = lds + 5 * C;
     const float invM = 1.f / (float)M;
-    for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {
-        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
-        if (slot >= rm.rpb) break;
-        float mean[8], inv[8], g[8], b[8], mg[8], mb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
-            const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
-            mg[j] = sg_ * invM; mb[j] = sb_ * invM;
-            if (blockIdx.x == 0 && slot == 0 && ggrad) {      // publish this call's sums into the parameter gradients
-                ggrad[c] += sg_;
-                bgrad[c] += sb_;
-            }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
+        k_mean[c] = save[c]; k_inv[c] = save[C + c]; k_g[c] = gamma[c]; k_b[c] = beta[c];
+        k_mg[c] = sg_ * invM; k_mb[c] = sb_ * invM;
+        if (blockIdx.x == 0 && ggrad) {          // publish this call's sums into the parameter gradients
+            ggrad[c] += sg_;
+            bgrad[c] += sb_;
         }
-        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += (long)gridDim.x * rm.rpb) {
-            float vdy[8], vz[8], du[8], zh[8], o[8];
-            load8(dy + m * ld_dy + cg * 8, vdy);
-            load8(z + m * ld_z + cg * 8, vz);
-            du_zhat(vdy, vz, mean, inv, g, b, act, du, zh);
+    }
+    __syncthreads();
+    const int cgs = C >> 3;
+    const long total = M * cgs;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long m = i / cgs;
+        const int cg = (int)(i - m * cgs);
+        float vdy[8], vz[8], du[8], zh[8], o[8];
+        load8(dy + m * ld_dy + cg * 8, vdy);
+        load8(z + m * ld_z + cg * 8, vz);
+        du_zhat(vdy, vz, k_mean + cg * 8, k_inv + cg * 8, k_g + cg * 8, k_b + cg * 8, act, du, zh);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = g[j] * inv[j] * (du[j] - mb[j] - zh[j] * mg[j]);
-            store8(dz + m * ld_dz + cg * 8, o);
-        }
+        for (int j = 0; j < 8; ++j) o[j] = k_g[cg * 8 + j] * k_inv[cg * 8 + j] * (du[j] - k_mb[cg * 8 + j] - zh[j] * k_mg[cg * 8 + j]);
+        store8(dz + m * ld_dz + cg * 8, o);
     }
 }
 
-int row_grid(long M, int C) {
+int flat_grid(long M, int C, int per_thread) {       // flat 16-byte chunks, `per_thread` chunks per lane
+    long blocks = (M * (C >> 3) + 256L * per_thread - 1) / (256L * per_thread);
+    return (int)(blocks < 1 ? 1 : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks));
+}
+int reduce_grid(long M, int C) {                       // >= 16 rows per thread, at most one block per CU
     int tpr = C >> 3;
     int rpb = tpr >= 256 ? 1 : 256 / tpr;
-    long blocks = (M + rpb - 1) / rpb;
-    return (int)(blocks < MAX_BLOCKS ? (blocks < 1 ? 1 : blocks) : MAX_BLOCKS);
+    long blocks = (M + (long)rpb * 16 - 1) / ((long)rpb * 16);
+    return (int)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks));
 }
 
 // ---------------------------------------------------------------------------------------- stem packing
@@ -511,7 +553,7 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(M, C, 4)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
@@ -523,9 +565,7 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
                                       int act, void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
-    int grid = row_grid(M, C);
-    if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(reduce_grid(M, C)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
@@ -537,7 +577,8 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
                                      void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+    EP24_REQUIRE(C <= 6144, EP24_E_UNSUPPORTED, "bn_act_bwd_apply: C=%d exceeds the LDS constant table", C);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(flat_grid(M, C, 2)), dim3(256), 6 * C * sizeof(float), S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
                        (bf16*)dz, ld_dz, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
