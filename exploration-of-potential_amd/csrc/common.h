@@ -56,4 +56,21 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ long long to_fix(float v) { return (long long)__float2ll_rn(v * EP24_FIX_SCALE); }
 __device__ __forceinline__ float from_fix(long long v) { return (float)((double)v * (1.0 / 1048576.0)); }
 
+// exact x / d for 0 <= x < 2^31 with one mulhi + shift (divisor known at launch time)
+struct FastDiv {
+    unsigned mul, shr, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, d};
+    if (d != 1) {
+        unsigned lg = 0;
+        while ((1ull << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+__device__ __forceinline__ int fdiv(int x, const FastDiv& f) { return f.d == 1 ? x : (int)(__umulhi((unsigned)x, f.mul) >> f.shr); }
+
 static inline int ep24_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
