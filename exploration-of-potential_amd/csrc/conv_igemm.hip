@@ -27,6 +27,8 @@ struct IgemmArgs {
     const float* bias;
     long long* stats; int stats_replicas;
     int b_resident_max;
+    int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
+    unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernel
     long M;
 };
 
@@ -268,10 +270,210 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
+// staging, no ds_write: the VGPR->LDS store path moves only ~79 B/clk/CU and capped the register-staged
+// kernel).  The DMA writes LDS linearly (wave base + lane*16), so the XOR swizzle is applied to the per-lane
+// SOURCE address: LDS unit U = row*8 + pchunk is fetched from (row, pchunk ^ (row & 7)); padding taps and the
+// M / N / K tails use an out-of-range buffer offset, for which the DMA writes zeros.  Two LDS stages, one barrier per K-step: the DMA of tile t+1 is
+// in flight while tile t feeds the MFMAs.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN, bool OUT_F32>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
+    constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM * 8 / 64 / 4;             // DMA instructions per wave for the A tile (4)
+    constexpr int B_INSTR = BN * 8 / 64 / 4;             // 4 or 2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run
+    // of tiles (N fastest): the N tiles of one M tile and neighbouring M tiles share their operands in one L2
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = tile_id / tiles_n;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = (tile_id - tile_m * tiles_n) * BN;
+    const int KC = (p.K + BK - 1) / BK;
+    const int n_iter = p.T * KC;
+
+    // Addressing is hoisted out of the K loop: per lane a 32-bit byte offset per row (tap (0,0), chunk folded in)
+    // and a bit mask of the taps that fall inside the image; per K-step the address is rowoff + (scalar tap /
+    // chunk offset).  Loads go through buffer descriptors: an out-of-range voffset makes the DMA write zeros, which
+    // is how padding taps, the M / N tails and the K tail are filled.
+    const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+    constexpr int OOB = 0x7FFFFFF0;
+    int rowoff[A_INSTR];
+    unsigned vmask[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const long m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
+        const bool rv = m < p.M;
+        const long mm = rv ? m : 0;
+        const int n = (int)(mm / (p.GH * p.GW));
+        const int rem = (int)(mm - (long)n * (p.GH * p.GW));
+        const int gy = rem / p.GW, gx = rem - gy * p.GW;
+        const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+        rowoff[i] = (int)((((long)n * p.SH * p.SW + (long)iy0 * p.SW + ix0) * p.ld_src + lchunk * 8) * 2);
+        unsigned mk = 0;
+        for (int t = 0; t < p.T; ++t) {
+            const int iy = iy0 + p.oy[t], ix = ix0 + p.ox[t];
+            if (rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
+        }
+        vmask[i] = mk;
+    }
+    int wvoff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int q = (wave * B_INSTR + i) * 8 + (lane >> 3);
+        const int r = (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
+        wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : OOB;
+    }
+    const int kmax = (p.K - lchunk * 8 + BK - 1) / BK;       // chunks kc < kmax hold real channels for this lane
+
+    int is_t = 0, is_kc = 0;                                 // (tap, channel chunk) of the next tile to issue
+    auto issue = [&](int buf) {
+        // channel-chunk outer, tap inner: the 9 taps of a chunk re-read the same ~27 KB window (L1 / L2 hits)
+        const int t = is_t, kc = is_kc;
+        if (++is_t == p.T) { is_t = 0; ++is_kc; }
+        const bool kok = kc < kmax;
+        const int a_s = p.toff[t] + kc * (BK * 2);
+        const int b_s = (p.wslot[t] * p.K + kc * BK) * 2;
+        char* stage = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int vo = (kok && ((vmask[i] >> t) & 1u)) ? rowoff[i] + a_s : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int vo = kok ? wvoff[i] + b_s : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+
+    issue(0);
+    for (int it = 0; it < n_iter; ++it) {
+        __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
+        if (it + 1 < n_iter) issue((it + 1) & 1);
+        const char* la = smem + (it & 1) * STAGE;
+        const char* lb = la + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(la + swz(wm * (MT * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                fb[q] = *reinterpret_cast<const bf16x8*>(lb + swz(wn * 64 + q * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (same as the register-staged kernel)
+    const int c0 = n0 + wn * 64 + 4 * frow;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
+                           p.dbs == (long)p.GH * p.GW);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
+            if (m >= p.M) continue;
+            long dpix = m;
+            if (!fast_dst) {
+                int n = (int)(m / (p.GH * p.GW));
+                int rem = (int)(m - (long)n * (p.GH * p.GW));
+                int gy = rem / p.GW, gx = rem - gy * p.GW;
+                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+            }
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = acc[i][q][r] + bias4[q];
+                s1[q] += v[q];
+                s2[q] += v[q] * v[q];
+            }
+            if constexpr (OUT_F32) {
+                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
+            } else {
+                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
+                if (c0 + 3 < p.N) {
+                    if (p.accumulate) {
+                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                    }
+                    bf16x4 w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                    *reinterpret_cast<bf16x4*>(d) = w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (fq == 0) {
+                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
+                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+            }
+        }
+        __syncthreads();
+        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            const int wcol = c >> 6;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+        }
+    }
+}
+
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
     if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((igemm_kernel<BN, F32, false>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
 }
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
@@ -284,6 +486,9 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     int gx = persist ? 1024 / gy : tiles_m;
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
+    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
+    a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
+    a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     const int n_iter = a.T * ((a.K + BK - 1) / BK);
     // keep the weight tiles resident in LDS when the whole reduction fits in two stages
     a.b_resident_max = (persist && n_iter <= 2) ? 2 : 0;

@@ -93,25 +93,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
     }
 }
 
-// du = dy * act'(u), u = (z-mean)*invstd*gamma + beta
-__device__ __forceinline__ void du_zhat(const float (&dy)[8], const float (&z)[8], const float* mean, const float* invstd,
-                                        const float* g, const float* b, int act, float (&du)[8], float (&zh)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        zh[j] = (z[j] - mean[j]) * invstd[j];
-        const float u = zh[j] * g[j] + b[j];
-        if (act) {
-            const float s = sigmoidf_(u);
-            du[j] = dy[j] * (s * (1.f + u * (1.f - s)));
-        } else {
-            du[j] = dy[j];
-        }
-    }
+// Backward of y = act(bn(z)) written per channel with precomputed constants:
+//   u  = z*sc + sh                 (sc = gamma*invstd, sh = beta - mean*sc)
+//   du = dy * act'(u)
+//   zhat = z*invstd - mean*invstd
+//   dz = k1*du - k2 - k3*z         (k1 = gamma*invstd, k3 = k1*invstd*mean(du*zhat), k2 = k1*(mean(du) - mean*invstd*mean(du*zhat)))
+// Every thread owns one 8-channel group for the whole kernel (constants in registers) and walks rows with
+// several 16-byte loads in flight.
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (!act) return 1.f;
+    const float s = sigmoidf_(u);
+    return s * (1.f + u * (1.f - s));
 }
 
-// Column sums over rows: every thread keeps one 8-channel group for the whole kernel (register accumulators),
-// the row slots of a block are folded through LDS in a fixed order and the block's totals leave as coalesced
-// fixed-point atomics (lane l -> channel l: 512 contiguous bytes per wave instruction).
+template <int UNROLL>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                 const float* save, const float* gamma,
                                                                 const float* beta, long long* dgamma, long long* dbeta,
@@ -126,30 +121,34 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
         const bool active = slot < rm.rpb && cg < (C >> 3);
         float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (active) {
-            float mean[8], inv[8], g[8], b[8];
+            float sc[8], sh[8], iv[8], mi[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = cg * 8 + j;
-                mean[j] = save[c]; inv[j] = save[C + c]; g[j] = gamma[c]; b[j] = beta[c];
+                const float mean = save[c], inv = save[C + c];
+                sc[j] = gamma[c] * inv; sh[j] = beta[c] - mean * sc[j]; iv[j] = inv; mi[j] = mean * inv;
             }
             const long step = (long)gridDim.x * rm.rpb;
-            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += 2 * step) {
-                const long m2 = m + step;
-                const bool two = m2 < M;
-                float vdy[8], vz[8], du[8], zh[8], wdy[8], wz[8];
-                load8(dy + m * ld_dy + cg * 8, vdy);
-                load8(z + m * ld_z + cg * 8, vz);
-                if (two) {
-                    load8(dy + m2 * ld_dy + cg * 8, wdy);
-                    load8(z + m2 * ld_z + cg * 8, wz);
+            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += UNROLL * step) {
+                bf16x8 vdy[UNROLL], vz[UNROLL];
+#pragma unroll
+                for (int k = 0; k < UNROLL; ++k) {
+                    const long mm = m + k * step;
+                    if (mm < M) {
+                        vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
+                        vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
+                    }
                 }
-                du_zhat(vdy, vz, mean, inv, g, b, act, du, zh);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { sb[j] += du[j]; sg[j] += du[j] * zh[j]; }
-                if (two) {
-                    du_zhat(wdy, wz, mean, inv, g, b, act, du, zh);
+                for (int k = 0; k < UNROLL; ++k) {
+                    if (m + k * step >= M) break;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { sb[j] += du[j]; sg[j] += du[j] * zh[j]; }
+                    for (int j = 0; j < 8; ++j) {
+                        const float zz = (float)vz[k][j];
+                        const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
+                        sb[j] += du;
+                        sg[j] += du * (zz * iv[j] - mi[j]);
+                    }
                 }
             }
         }
@@ -175,41 +174,57 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
     }
 }
 
+template <int UNROLL>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma, const float* beta,
                                                                const long long* dgamma, const long long* dbeta, float* ggrad,
                                                                float* bgrad, bf16* dz, long ld_dz, long M, int C, int act) {
-    extern __shared__ float lds[];
-    float* k_mean = lds;             // per channel: mean, invstd, gamma, beta, dgamma/M, dbeta/M
-    float* k_inv = lds + C;
-    float* k_g = lds + 2 * C;
-    float* k_b = lds + 3 * C;
-    float* k_mg = lds + 4 * C;
-    float* k_mb = lds + 5 * C;
+    const RowMap rm(C);
+    const int tid = threadIdx.x;
     const float invM = 1.f / (float)M;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
-        k_mean[c] = save[c]; k_inv[c] = save[C + c]; k_g[c] = gamma[c]; k_b[c] = beta[c];
-        k_mg[c] = sg_ * invM; k_mb[c] = sb_ * invM;
-        if (blockIdx.x == 0 && ggrad) {          // publish this call's sums into the parameter gradients
-            ggrad[c] += sg_;
-            bgrad[c] += sb_;
-        }
-    }
-    __syncthreads();
-    const int cgs = C >> 3;
-    const long total = M * cgs;
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const long m = i / cgs;
-        const int cg = (int)(i - m * cgs);
-        float vdy[8], vz[8], du[8], zh[8], o[8];
-        load8(dy + m * ld_dy + cg * 8, vdy);
-        load8(z + m * ld_z + cg * 8, vz);
-        du_zhat(vdy, vz, k_mean + cg * 8, k_inv + cg * 8, k_g + cg * 8, k_b + cg * 8, act, du, zh);
+    for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048
+        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
+        if (slot >= rm.rpb) break;
+        float sc[8], sh[8], k1[8], k2[8], k3[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = k_g[cg * 8 + j] * k_inv[cg * 8 + j] * (du[j] - k_mb[cg * 8 + j] - zh[j] * k_mg[cg * 8 + j]);
-        store8(dz + m * ld_dz + cg * 8, o);
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            const float mean = save[c], inv = save[C + c], g = gamma[c];
+            const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
+            sc[j] = g * inv; sh[j] = beta[c] - mean * sc[j];
+            k1[j] = g * inv;
+            k3[j] = k1[j] * inv * (sg_ * invM);
+            k2[j] = k1[j] * (sb_ * invM) - k3[j] * mean;
+            if (blockIdx.x == 0 && slot == 0 && ggrad) {      // publish this call's sums into the parameter gradients
+                ggrad[c] += sg_;
+                bgrad[c] += sb_;
+            }
+        }
+        const long step = (long)gridDim.x * rm.rpb;
+        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += UNROLL * step) {
+            bf16x8 vdy[UNROLL], vz[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const long mm = m + k * step;
+                if (mm < M) {
+                    vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
+                    vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const long mm = m + k * step;
+                if (mm >= M) break;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float zz = (float)vz[k][j];
+                    const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
+                    o[j] = (bf16)(k1[j] * du - k2[j] - k3[j] * zz);
+                }
+                *reinterpret_cast<bf16x8*>(dz + mm * ld_dz + cg * 8) = o;
+            }
+        }
     }
 }
 
@@ -217,11 +232,11 @@ int flat_grid(long M, int C, int per_thread) {       // flat 16-byte chunks, `pe
     long blocks = (M * (C >> 3) + 256L * per_thread - 1) / (256L * per_thread);
     return (int)(blocks < 1 ? 1 : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks));
 }
-int reduce_grid(long M, int C) {                       // >= 16 rows per thread, at most one block per CU
+int rows_grid(long M, int C, int rows_per_thread, int max_blocks) {   // fixed channel group per thread, strided rows
     int tpr = C >> 3;
     int rpb = tpr >= 256 ? 1 : 256 / tpr;
-    long blocks = (M + (long)rpb * 16 - 1) / ((long)rpb * 16);
-    return (int)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks));
+    long blocks = (M + (long)rpb * rows_per_thread - 1) / ((long)rpb * rows_per_thread);
+    return (int)(blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks));
 }
 
 // ---------------------------------------------------------------------------------------- stem packing
@@ -565,7 +580,7 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
                                       int act, void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(reduce_grid(M, C)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<4>, dim3(rows_grid(M, C, 16, 512)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
@@ -577,8 +592,7 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
                                      void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
-    EP24_REQUIRE(C <= 6144, EP24_E_UNSUPPORTED, "bn_act_bwd_apply: C=%d exceeds the LDS constant table", C);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(flat_grid(M, C, 2)), dim3(256), 6 * C * sizeof(float), S_, (const bf16*)dy, ld_dy,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(rows_grid(M, C, 8, 2048)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
                        (bf16*)dz, ld_dz, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
