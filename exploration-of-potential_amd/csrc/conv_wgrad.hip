@@ -11,6 +11,7 @@
 // banks; 16-B staging writes stay whole because the permutation moves 32-B units.
 // Workgroup = 128 co x 128 ci of one tap, 4 waves (2x2 of 64x64), 64 pixels per K-step; pixels are split
 // over blockIdx.y and combined with fp32 atomics (device scope, one 64-B segment per 16 lanes).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -23,6 +24,9 @@ struct WgradArgs {
     long chunk;      // pixels per split (multiple of 64)
     int tiles_ci, tiles_co, T;
     FastDiv d_plane, d_ow;      // pixel -> (n, oh, ow)
+    unsigned x_bytes, dy_bytes; // extents for the buffer descriptors
+    int dbg_skip_epilogue;      // tools/conv_probe.py experiments only
+    int dbg_splits;
 };
 
 // Row keys of the 32-byte-block XOR permutation.  256-B rows (128 channels): one row per bank row, the 8 rows a
@@ -48,16 +52,22 @@ template <int TW> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, in
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 // TCO x TCI output tile of one tap per workgroup (128 or 64 each), 4 waves as 2x2.
+// Staging is LDS-DMA (buffer_load ... lds, 16 B per lane): no VGPR round trip and no ds_write - the VGPR->LDS
+// store path (~79 B/clk/CU) was the busiest pipe of the register-staged version.  The DMA writes LDS linearly, so
+// the 32-B-block permutation is applied to the per-lane SOURCE channel; rows past the pixel range, padding taps
+// and channel tails use an out-of-range buffer offset (the DMA then writes zeros).  Two stages, one barrier per
+// 64-pixel step.
 template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
-    constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2;
+    constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2, STAGE = Y_BYTES + X_BYTES;
     constexpr int FM = TCO / 32, FN = TCI / 32;          // 16x16 fragments per wave along co / ci
     constexpr int YCH = TCO / 8, XCH = TCI / 8;          // 16-B chunks per tile row
-    constexpr int YP = YCH / 4, XP = XCH / 4;            // pieces per thread
+    constexpr int YI = 64 * YCH / 256, XI = 64 * XCH / 256;   // DMA instructions per wave (4 or 2)
+    constexpr int OOB = 0x7FFFFFF0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const lds_y = smem;                            // one stage: <= 32 KB, 4 workgroups per CU
-    char* const lds_x = smem + Y_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -70,41 +80,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const long p_end = min(p.M, p_begin + p.chunk);
     const int n_iter = (int)((p_end - p_begin + 63) / 64);      // uniform over the workgroup
 
-    const int yc = tid % YCH, yr = tid / YCH;            // dY pieces: rows yr + (256/YCH) i
-    const int xc = tid % XCH, xr = tid / XCH;
-    const bool y_col_ok = co0 + yc * 8 < p.Cout;
-    const bool x_col_ok = ci0 + xc * 8 < p.Cin;
-    bf16x8 ry[YP], rx[XP];
+    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+    // lane -> (tile row, logical 16-B chunk) of DMA instruction j: LDS unit U = (wave*NI + j)*64 + lane
+    int y_row[YI], y_off[YI];
+#pragma unroll
+    for (int j = 0; j < YI; ++j) {
+        const int U = (wave * YI + j) * 64 + lane;
+        const int r = U / YCH, pc = U % YCH;
+        const int c = ((((pc >> 1) ^ rkey<TCO>(r)) << 1) | (pc & 1));
+        y_row[j] = r;
+        y_off[j] = co0 + c * 8 < p.Cout ? (int)((((p_begin + r) * p.ld_dy) + co0 + c * 8) * 2) : OOB;
+    }
+    int x_row[XI], x_col[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int U = (wave * XI + j) * 64 + lane;
+        const int r = U / XCH, pc = U % XCH;
+        const int c = ((((pc >> 1) ^ rkey<TCI>(r)) << 1) | (pc & 1));
+        x_row[j] = r;
+        x_col[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : -1;
+    }
+    const int y_step = (int)(64 * p.ld_dy * 2);
 
-    auto load_tile = [&](int it) {
+    auto issue = [&](int it, int buf) {
+        char* stage = smem + buf * STAGE;
         const long base = p_begin + (long)it * 64;
 #pragma unroll
-        for (int i = 0; i < YP; ++i) {
-            const long pp = base + yr + (256 / YCH) * i;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (pp < p_end && y_col_ok) v = *reinterpret_cast<const bf16x8*>(p.dy + pp * p.ld_dy + co0 + yc * 8);
-            ry[i] = v;
+        for (int j = 0; j < YI; ++j) {
+            const bool ok = base + y_row[j] < p_end && y_off[j] != OOB;
+            const int vo = ok ? y_off[j] + it * y_step : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lptr_t)(stage + (wave * YI + j) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const long pp = base + xr + (256 / XCH) * i;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (pp < p_end && x_col_ok) {
+        for (int j = 0; j < XI; ++j) {
+            const long pp = base + x_row[j];
+            int vo = OOB;
+            if (pp < p_end && x_col[j] >= 0) {
                 const int n = fdiv((int)pp, p.d_plane);
                 const int rem = (int)pp - n * (p.OH * p.OW);
                 const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
                 const int iy = oh * p.stride + kh - p.pad, ix = ow * p.stride + kw - p.pad;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = *reinterpret_cast<const bf16x8*>(p.x + ((long)(n * p.H + iy) * p.W + ix) * p.ld_x + ci0 + xc * 8);
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) vo = (int)((((long)(n * p.H + iy) * p.W + ix) * p.ld_x) * 2) + x_col[j];
             }
-            rx[i] = v;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(stage + Y_BYTES + (wave * XI + j) * 1024), 16, vo, 0, 0, 0);
         }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < YP; ++i) *reinterpret_cast<bf16x8*>(lds_y + wr_off<TCO>(yr + (256 / YCH) * i, yc)) = ry[i];
-#pragma unroll
-        for (int i = 0; i < XP; ++i) *reinterpret_cast<bf16x8*>(lds_x + wr_off<TCI>(xr + (256 / XCH) * i, xc)) = rx[i];
     };
 
     f32x4 acc[FM][FN];
@@ -117,12 +137,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int q = (lane & 15) >> 2;      // row inside the 4-row transposed block this lane addresses
     const int pp4 = lane & 3;            // 4-channel sub-slot this lane addresses
 
-    if (n_iter > 0) load_tile(0);
+    if (n_iter > 0) issue(0, 0);
     for (int it = 0; it < n_iter; ++it) {
-        if (it) __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (it + 1 < n_iter) load_tile(it + 1);
+        __syncthreads();                 // vmcnt(0) + barrier: step `it` landed, the other stage is free
+        if (it + 1 < n_iter) issue(it + 1, (it + 1) & 1);
+        const char* lds_y = smem + (it & 1) * STAGE;
+        const char* lds_x = lds_y + Y_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int row_lo = ks * 32 + fq * 8 + q;
@@ -141,33 +161,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     // D[row = co][col = ci]: row = 4*fq + r, col = lane & 15
     const int fr = lane & 15;
+    if (p.dbg_skip_epilogue) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // Epilogue: the accumulators go through LDS so that every atomic wave-instruction adds 64 CONSECUTIVE floats of
+    // one dW row (256 contiguous bytes - the shape the memory-side atomic units take at full rate) instead of
+    // four 64-byte pieces in four rows.
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);            // [TCO][TCI] fp32 <= 64 KB = the two staging stages
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wm * (TCO / 2) + i * 16 + 4 * fq + r;
-            if (co >= p.cout_valid) continue;
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int ci = ci0 + wn * (TCI / 2) + j * 16 + fr;
-                if (ci < p.cin_valid) atomicAdd(p.dw + (long)co * p.ld_dw + (long)tap * p.cin_valid + ci, acc[i][j][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                tile[(wm * (TCO / 2) + i * 16 + 4 * fq + r) * TCI + wn * (TCI / 2) + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    for (int row = wave; row < TCO; row += 4) {
+        const int co = co0 + row;
+        if (co >= p.cout_valid) break;
+        float* d = p.dw + (long)co * p.ld_dw + (long)tap * p.cin_valid + ci0;
+#pragma unroll
+        for (int h = 0; h < TCI / 64; ++h) {
+            const int c = h * 64 + lane;
+            if (ci0 + c < p.cin_valid) atomicAdd(d + c, tile[row * TCI + c]);
         }
+    }
 }
 
 template <int TCO, int TCI>
 void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
     const int tiles = a.tiles_ci * a.tiles_co * a.T;
-    // ~3-4 workgroups per CU, at least 8 K-steps (512 pixels) per split so the fp32 atomic epilogue amortises
+    // ~2 workgroups per CU and at least 8 K-steps (512 pixels) per split: the fp32 atomic epilogue moves
+    // splits x |dW| bytes at the ~1.3 TB/s memory-side atomic rate and was a third of the kernel at 25 splits
     long steps = (a.M + 63) / 64;
-    long splits = (896 + tiles - 1) / tiles;
+    long splits = (512 + tiles - 1) / tiles;
     if (splits > steps / 8) splits = steps / 8;
+    if (a.dbg_splits > 0) splits = a.dbg_splits;
     if (splits < 1) splits = 1;
     a.chunk = ((steps + splits - 1) / splits) * 64;
     splits = (a.M + a.chunk - 1) / a.chunk;
     dim3 grid(tiles, (unsigned)splits);
-    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 64 * (TCO + TCI) * 2, stream, a);
+    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2, stream, a);
 }
 
 }  // namespace
@@ -190,7 +230,13 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     a.T = ksize * ksize;
     EP24_REQUIRE(a.M < (1L << 31), EP24_E_UNSUPPORTED, "conv_wgrad: more than 2^31 output pixels");
     a.d_plane = make_fastdiv((unsigned)(a.OH * a.OW)); a.d_ow = make_fastdiv((unsigned)a.OW);
-    const bool co64 = Cout <= 64, ci64 = Cin <= 64;
+    a.x_bytes = (unsigned)((((long)B * H * W - 1) * ld_x + Cin) * 2);
+    a.dy_bytes = (unsigned)(((a.M - 1) * ld_dy + Cout) * 2);
+    { const char* e = getenv("EP24_DBG_WGRAD_SKIP_EPI"); a.dbg_skip_epilogue = e && e[0] == '1';
+      const char* f = getenv("EP24_DBG_WGRAD_SPLITS"); a.dbg_splits = f ? atoi(f) : 0; }
+    // 1x1 layers are tall-skinny (huge pixel count, small dW): 64x64 tiles quarter the atomic traffic per workgroup
+    bool co64 = Cout <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256), ci64 = Cin <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256);
+    if (const char* g = getenv("EP24_DBG_WGRAD_TILE")) { co64 = g[0] == '6'; ci64 = g[1] == '6'; }
     if (co64 && ci64) launch_wgrad<64, 64>(a, (hipStream_t)stream);
     else if (co64) launch_wgrad<64, 128>(a, (hipStream_t)stream);
     else if (ci64) launch_wgrad<128, 64>(a, (hipStream_t)stream);
