@@ -42,8 +42,10 @@ __global__ __launch_bounds__(256) void sector_gather_kernel(const uint8_t* src, 
         if (key >= 0) {
             const int a = key / T, r = key - a * T;
             flat = (T - 1 - r) * n_ang + (n_ang - 1 - a);         // img_resize[ptx[:, ::-1], pty[::-1, :]]
-            const uint8_t* s = src + (long)flat * 3;
-            c0 = s[0]; c1 = s[1]; c2 = s[2];
+            if (dst) {                                            // index-only calls pass no source image
+                const uint8_t* s = src + (long)flat * 3;
+                c0 = s[0]; c1 = s[1]; c2 = s[2];
+            }
         }
         if (dst) { dst[i * 3 + 0] = c0; dst[i * 3 + 1] = c1; dst[i * 3 + 2] = c2; }
         if (src_index) src_index[i] = flat;
@@ -98,5 +100,54 @@ extern "C" int ep24_mask_bbox(const uint8_t* mask3, int out_h, int out_w, int32_
     EP24_REQUIRE(mask3 && box && out_h > 0 && out_w > 0, EP24_E_ARG, "mask_bbox: bad arguments");
     hipLaunchKernelGGL(mask_bbox_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, mask3, out_h, out_w, box);
     EP24_LAUNCH_CHECK("ep24_mask_bbox");
+    return EP24_OK;
+}
+
+// ------------------------------------------------------------------------------------------ bilinear resize
+// uint8 bilinear resize with OpenCV's INTER_LINEAR fixed-point arithmetic (the reference calls
+// cv2.resize(image, (13200, T)), demo_featuremap.py:285): 11-bit horizontal/vertical coefficients
+// (saturate_cast<short>(w * 2048), round to nearest even), pixel-centre mapping f = (d + 0.5) * scale - 0.5 with
+// border clamping, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  cv2 is not installed in
+// this image, so this step is checked against a numpy restatement of the same published arithmetic only.
+namespace {
+__device__ __forceinline__ void lin_coef(int d, float scale, int ssize, int& s0, int& s1, int& a0, int& a1) {
+    float f = (float)((d + 0.5) * (double)scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    s0 = s;
+    s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+    a0 = (int)rintf((1.f - f) * 2048.f);
+    a1 = (int)rintf(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw,
+                                                               float scale_x, float scale_y) {
+    const long total = (long)dh * dw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int dy = (int)(i / dw), dx = (int)(i - (long)dy * dw);
+        int x0, x1, ax0, ax1, y0, y1, by0, by1;
+        lin_coef(dx, scale_x, sw, x0, x1, ax0, ax1);
+        lin_coef(dy, scale_y, sh, y0, y1, by0, by1);
+        const uint8_t* r0 = src + (long)y0 * sw * 3;
+        const uint8_t* r1 = src + (long)y1 * sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[x0 * 3 + c] * ax0 + r0[x1 * 3 + c] * ax1;
+            const int h1 = r1[x0 * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
+            const int v = (((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            dst[i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream) {
+    EP24_REQUIRE(src && dst && sh > 0 && sw > 0 && dh > 0 && dw > 0, EP24_E_ARG, "resize_linear_u8: bad arguments");
+    long blocks = ((long)dh * dw + 255) / 256;
+    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, src,
+                       sh, sw, dst, dh, dw, (float)((double)sw / dw), (float)((double)sh / dh));
+    EP24_LAUNCH_CHECK("ep24_resize_linear_u8");
     return EP24_OK;
 }

@@ -1,0 +1,103 @@
+"""Fisheye sector warp on the GPU: mirror of ``Image_Distortion.sector_distort`` (yolox/demo_featuremap.py:238-328).
+
+Host side (this file) computes what is 1-D and cheap exactly as the reference does with numpy - the angle / radius
+tables, the target row count T from the arc length, the crop box - and caches, per (Theta, T), the device-resident
+winner map built by ``ep24_sector_map``.  Per image only ``ep24_resize_linear_u8`` + ``ep24_sector_gather`` (+
+``ep24_mask_bbox``) run.  Inputs may be numpy HWC uint8 arrays (drop-in: results come back as numpy) or CUDA tensors.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+CANVAS = 1000
+N_ANG = 165 * 80
+MAX_ROWS = CANVAS - 100
+
+
+def _tables(theta_deg, h, w, custom_rows):
+    assert (theta_deg >= 15) and (theta_deg <= 180), "Theta is not in range 15°-180°!"
+    canvas_w = int(CANVAS * np.sin(theta_deg / 2 * np.pi / 180) * 2)
+    start = (180 - theta_deg) / 2
+    ang = np.linspace(start, start + theta_deg, N_ANG, True) * np.pi / 180
+    c, s = np.cos(ang), np.sin(ang)
+    if custom_rows is None:
+        ends = (c * CANVAS).astype(np.int16) + (s * CANVAS).astype(np.int16) * 1j
+        T = int(np.clip(int(np.unique(ends).shape[0] * (h / w)), 0, MAX_ROWS))
+    else:
+        assert custom_rows <= MAX_ROWS, "Custom row should be limited in 900!"
+        T = int(custom_rows)
+    rho = np.linspace(CANVAS - T, CANVAS, T)
+    return canvas_w, c, s, rho, T
+
+
+def _crop_box(canvas_w, c, s, rho):
+    """min / max of the destination coordinates over all (angle, radius) pairs from the 1-D tables: rho > 0, so
+    rho*cos and rho*sin are monotone in each factor and truncation / clipping preserve order."""
+    def dest_x(v):
+        return int(np.clip(np.int16(v) + canvas_w / 2 - 1, 0, canvas_w).astype(np.int16))
+
+    def dest_y(v):
+        return int(np.clip((CANVAS - np.int16(v)) - 1, 0, CANVAS))
+
+    cmax, cmin, smax, smin = c.max(), c.min(), s.max(), s.min()
+    rmax, rmin = rho.max(), rho.min()
+    vx_max = cmax * (rmax if cmax >= 0 else rmin)
+    vx_min = cmin * (rmax if cmin <= 0 else rmin)
+    vy_max = smax * (rmax if smax >= 0 else rmin)
+    vy_min = smin * (rmax if smin <= 0 else rmin)
+    return dest_y(vy_max), dest_y(vy_min), dest_x(vx_min), dest_x(vx_max)       # y0, y1, x0, x1
+
+
+class Image_Distortion:
+    def __init__(self, device="cuda:0"):
+        self.draw_temp_size = CANVAS
+        self.sector_length = MAX_ROWS
+        self.draw_resolution = 80
+        self.device = torch.device(device)
+        self._maps = {}
+
+    def _map(self, theta_deg, h, w, custom_rows):
+        canvas_w, c, s, rho, T = _tables(theta_deg, h, w, custom_rows)
+        key = (float(theta_deg), T)
+        if key not in self._maps:
+            dev = self.device
+            winner = torch.full((CANVAS * canvas_w,), -1, dtype=torch.int32, device=dev)
+            ct, st, rt = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (c, s, rho))
+            call("sector_map", ptr(ct), ptr(st), N_ANG, ptr(rt), T, canvas_w, CANVAS, ptr(winner), stream_ptr())
+            torch.cuda.current_stream().synchronize()        # ct/st/rt may be freed after this point (one-time build)
+            self._maps[key] = (winner, canvas_w, _crop_box(canvas_w, c, s, rho), T)
+        return self._maps[key]
+
+    def source_index(self, theta_deg, h, w, custom_rows=None):
+        """[out_h, out_w] int32 flat index into the resized image (-1 = fill): the scatter's winners."""
+        winner, cw, (y0, y1, x0, x1), T = self._map(theta_deg, h, w, custom_rows)
+        out = torch.empty((y1 - y0, x1 - x0), dtype=torch.int32, device=self.device)
+        call("sector_gather", None, ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, None, 0, ptr(out), stream_ptr())
+        return out
+
+    def _warp(self, img, winner, cw, box, T, fill):
+        y0, y1, x0, x1 = box
+        h, w = img.shape[0], img.shape[1]
+        resized = torch.empty((T, N_ANG, 3), dtype=torch.uint8, device=self.device)
+        call("resize_linear_u8", ptr(img), h, w, ptr(resized), T, N_ANG, stream_ptr())
+        out = torch.empty((y1 - y0, x1 - x0, 3), dtype=torch.uint8, device=self.device)
+        call("sector_gather", ptr(resized), ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, ptr(out), fill, None, stream_ptr())
+        return out
+
+    def sector_distort(self, image, mask, Theta=60, custom_rows=None):
+        _lib.require_gpu()
+        as_numpy = isinstance(image, np.ndarray)
+        img = torch.as_tensor(image).to(self.device).contiguous()
+        msk = torch.as_tensor(mask).to(self.device).contiguous()
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise IndexError("expected HWC uint8 images")
+        winner, cw, box, T = self._map(Theta, img.shape[0], img.shape[1], custom_rows)
+        new_image = self._warp(img, winner, cw, box, T, 114)
+        new_mask = self._warp(msk, winner, cw, box, T, 0)
+        bb = torch.tensor([2 ** 31 - 1, 2 ** 31 - 1, -1, -1], dtype=torch.int32, device=self.device)
+        call("mask_bbox", ptr(new_mask), new_mask.shape[0], new_mask.shape[1], ptr(bb), stream_ptr())
+        xmin, ymin, xmax, ymax = bb.tolist()
+        new_bbox = [xmin, ymin, xmax - xmin, ymax - ymin] if xmax >= 0 else []
+        return (new_image.cpu().numpy() if as_numpy else new_image), new_bbox

@@ -1,0 +1,29 @@
+"""Synthetic stand-in for ``COCO24PDataset`` + ``TrainTransform`` (datasets/coco24p.py, data_augment.py:131-174):
+items are ``(image [3,S,S] fp32 0..255, labels [50,51], img_info, img_id)`` exactly as the trainer unpacks them
+(train_24p.py:83).  The real loader (cv2 / pycocotools, CPU workers, hard-coded dataset paths) is outside the hot path."""
+import _path  # noqa: F401
+import torch
+from ep24 import synth
+
+
+class SyntheticDataset(torch.utils.data.Dataset):
+    def __init__(self, length=64, size=640, num_gt=10, num_classes=80, seed=0):
+        self.length, self.size, self.num_gt, self.num_classes, self.seed = length, size, num_gt, num_classes, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        img = synth.make_images(1, self.size, seed=self.seed * 100003 + idx)[0]
+        lab = synth.make_labels(1, self.num_gt, size=self.size, seed=self.seed * 100003 + 7919 + idx, num_classes=self.num_classes)[0]
+        return img, lab, (self.size, self.size), idx
+
+
+COCO24PDataset = SyntheticDataset        # name the reference's Exp imports (exp/yolox_base.py:76)
+
+
+class TrainTransform:
+    """Placeholder with the reference's constructor signature; synthetic items are already in network layout."""
+
+    def __init__(self, max_labels=50, flip_prob=0.5, hsv_prob=1.0):
+        self.max_labels = max_labels

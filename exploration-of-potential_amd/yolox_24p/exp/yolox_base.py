@@ -1,0 +1,85 @@
+"""``Exp``: model / data / optimizer factory of the 24p detector (reference exp/yolox_base.py:11-137) on top of the
+MI355X-native path: ``get_model`` builds the ep24 parameter tree (HIP plan behind ``YOLOX.forward``),
+``get_optimizer`` the fused nesterov SGD, ``get_data_loader`` a synthetic source with the reference's label layout
+(the reference's COCO24P loader reads hard-coded /home/gaoyu/... paths, coco24p.py:19-20, and is out of scope)."""
+import _path  # noqa: F401
+import torch.nn as nn
+
+from .base_exp import BaseExp
+
+
+class Exp(BaseExp):
+    def __init__(self):
+        super().__init__()
+        # model
+        self.num_classes = 80
+        self.depth = 1.00
+        self.width = 1.00
+        self.act = "silu"
+        # data
+        self.data_num_workers = 8
+        self.input_size = (640, 640)
+        self.multiscale_range = 5
+        self.train_ann = "instances_train2017.json"
+        self.val_ann = "instances_val2017.json"
+        self.synthetic_len = 64          # images per synthetic epoch
+        self.synthetic_gts = 10
+        # training
+        self.warmup_epochs = 5
+        self.max_epoch = 300
+        self.L1_epoch = 100
+        self.warmup_lr = 0
+        self.basic_lr_per_img = 0.01 / 64.0
+        self.scheduler = "yoloxwarmcos"
+        self.no_aug_epochs = 100
+        self.min_lr_ratio = 0.05
+        self.ema = True
+        self.weight_decay = 5e-4
+        self.momentum = 0.9
+        self.print_interval = 10
+        self.eval_interval = 10
+        self.exp_name = "yolox_24p"
+        # testing
+        self.test_size = (640, 640)
+        self.test_conf = 0.01
+        self.nmsthre = 0.65
+
+    def get_model(self):
+        from models import YOLOX, YOLOPAFPN, YOLOXHead
+        if getattr(self, "model", None) is None:
+            in_channels = [256, 512, 1024]
+            backbone = YOLOPAFPN(self.depth, self.width, in_channels=in_channels, act=self.act)
+            head = YOLOXHead(self.num_classes, self.width, in_channels=in_channels, act=self.act)
+            self.model = YOLOX(backbone, head)
+        for m in self.model.modules():                    # init_yolo, yolox_base.py:58-62
+            if isinstance(m, nn.BatchNorm2d):
+                m.eps = 1e-3
+                m.momentum = 0.03
+        self.model.head.initialize_biases(1e-2)
+        return self.model
+
+    def get_data_loader(self, batch_size):
+        from datasets import SyntheticDataset
+        import torch
+        self.dataset = SyntheticDataset(self.synthetic_len, self.input_size[0], self.synthetic_gts, self.num_classes)
+        return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True)
+
+    def preprocess(self, inputs, targets, tsize):
+        scale_y = tsize[0] / self.input_size[0]
+        scale_x = tsize[1] / self.input_size[1]
+        if scale_x != 1 or scale_y != 1:
+            inputs = nn.functional.interpolate(inputs, size=tsize, mode="bilinear", align_corners=False)
+            targets[..., 1::2] = targets[..., 1::2] * scale_x
+            targets[..., 2::2] = targets[..., 2::2] * scale_y
+        return inputs, targets
+
+    def get_optimizer(self, lr):
+        """Takes the learning rate (not the batch size), like the 24p trainer (yolox_base.py:120-124)."""
+        from ep24.train import SGD
+        self.optimizer = SGD(self.model.parameters(), lr=lr, momentum=self.momentum, nesterov=True, model=self.model)
+        return self.optimizer
+
+    def get_lr_scheduler(self, lr, iters_per_epoch, **kwargs):
+        from utils import LRScheduler
+        return LRScheduler(self.scheduler, lr, iters_per_epoch, self.max_epoch, warmup_epochs=self.warmup_epochs,
+                           warmup_lr_start=self.warmup_lr, no_aug_epochs=self.no_aug_epochs, min_lr_ratio=self.min_lr_ratio)

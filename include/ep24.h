@@ -207,6 +207,10 @@ int ep24_sector_gather(const uint8_t* src, const int32_t* winner, int canvas_w, 
  * it to {INT_MAX,INT_MAX,-1,-1}. */
 int ep24_mask_bbox(const uint8_t* mask3, int out_h, int out_w, int32_t* box, void* stream);
 
+/* uint8 HWC bilinear resize with OpenCV's INTER_LINEAR fixed-point arithmetic (cv2.resize(image, (13200, T)),
+ * demo_featuremap.py:285).  src [sh][sw][3] -> dst [dh][dw][3]. */
+int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
