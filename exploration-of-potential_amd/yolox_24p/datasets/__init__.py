@@ -9,14 +9,18 @@ from ep24 import synth
 class SyntheticDataset(torch.utils.data.Dataset):
     def __init__(self, length=64, size=640, num_gt=10, num_classes=80, seed=0):
         self.length, self.size, self.num_gt, self.num_classes, self.seed = length, size, num_gt, num_classes, seed
+        self._cache = {}
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, idx):
+        if idx in self._cache:
+            return self._cache[idx]
         img = synth.make_images(1, self.size, seed=self.seed * 100003 + idx)[0]
         lab = synth.make_labels(1, self.num_gt, size=self.size, seed=self.seed * 100003 + 7919 + idx, num_classes=self.num_classes)[0]
-        return img, lab, (self.size, self.size), idx
+        self._cache[idx] = (img, lab, (self.size, self.size), idx)
+        return self._cache[idx]
 
 
 COCO24PDataset = SyntheticDataset        # name the reference's Exp imports (exp/yolox_base.py:76)
