@@ -13,7 +13,15 @@
 // lanes and ds_read_b128 of 16 rows x {chunk c, c+1} by a wave are both bank-conflict free.
 // Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel
 // 4j+t) so every lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
+#include <stdlib.h>
 #include "common.h"
+
+// Ablation switches used by tools/conv_probe.py experiments are compiled in only with -DEP24_ABLATE.
+#ifdef EP24_ABLATE
+#define DBG(p, bit) ((p).dbg_mode & (bit))
+#else
+#define DBG(p, bit) 0
+#endif
 
 namespace {
 
@@ -29,6 +37,9 @@ struct IgemmArgs {
     int b_resident_max;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernel
+    FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
+    int dbg_same_addr;              // tools/conv_probe.py experiment: every lane fetches the same few lines
+    int dbg_mode;                   // ablations: 1 no MFMA, 2 no DMA, 4 no barrier/wait, 8 no LDS fragment reads
     long M;
 };
 
@@ -270,6 +281,102 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 }
 
+// Shared epilogue of the DMA kernels: bias, BN statistics, bf16 / fp32 stores, fixed-point statistic atomics.
+template <int BN, bool OUT_F32, int MT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
+    constexpr int WN = BN / 64, WM = 4 / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    if (DBG(p, 64)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(acc[i][q]));
+        return;
+    }
+    const int c0 = n0 + wn * 64 + 4 * frow;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
+                           p.dbs == (long)p.GH * p.GW);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
+            if (m >= p.M) continue;
+            long dpix = m;
+            if (!fast_dst) {
+                int n = fdiv((int)m, p.d_plane);
+                int rem = (int)m - n * (p.GH * p.GW);
+                int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
+                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+            }
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = acc[i][q][r] + bias4[q];
+                s1[q] += v[q];
+                s2[q] += v[q] * v[q];
+            }
+            if (DBG(p, 16)) continue;
+            if constexpr (OUT_F32) {
+                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
+            } else {
+                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
+                if (c0 + 3 < p.N) {
+                    if (p.accumulate) {
+                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                    }
+                    bf16x4 w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                    *reinterpret_cast<bf16x4*>(d) = w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                }
+            }
+        }
+    }
+    if (p.stats && !DBG(p, 32)) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (fq == 0) {
+                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
+                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+            }
+        }
+        __syncthreads();
+        long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            const int wcol = c >> 6;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
 // staging, no ds_write: the VGPR->LDS store path moves only ~79 B/clk/CU and capped the register-staged
@@ -315,16 +422,17 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     for (int i = 0; i < A_INSTR; ++i) {
         const long m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
         const bool rv = m < p.M;
-        const long mm = rv ? m : 0;
-        const int n = (int)(mm / (p.GH * p.GW));
-        const int rem = (int)(mm - (long)n * (p.GH * p.GW));
-        const int gy = rem / p.GW, gx = rem - gy * p.GW;
+        const int mm = rv ? (int)m : 0;
+        const int n = fdiv(mm, p.d_plane);
+        const int rem = mm - n * (p.GH * p.GW);
+        const int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
         const int iy0 = gy * p.sy, ix0 = gx * p.sx;
         rowoff[i] = (int)((((long)n * p.SH * p.SW + (long)iy0 * p.SW + ix0) * p.ld_src + lchunk * 8) * 2);
         unsigned mk = 0;
-        for (int t = 0; t < p.T; ++t) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {         // static trip count: the tap tables arrive with the kernel arguments
             const int iy = iy0 + p.oy[t], ix = ix0 + p.ox[t];
-            if (rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
+            if (t < p.T && rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
         }
         vmask[i] = mk;
     }
@@ -388,92 +496,195 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         }
     }
 
-    // ---- epilogue (same as the register-staged kernel)
-    const int c0 = n0 + wn * 64 + 4 * frow;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    igemm_epilogue<BN, OUT_F32, MT>(p, acc, m0, n0, tile_m, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ring variant: BK = 32 stages (A 8 KB + B 8/4 KB), RING stages per workgroup, DMA runs RING-1 stages ahead and is
+// retired with COUNTED s_waitcnt vmcnt(N) + a raw s_barrier (a __syncthreads() would drain every DMA in flight).
+// With one stage of lookahead every K-step waited a full L2/HBM round trip (~2-4 k cycles against 512 cycles of
+// MFMA); here three stages are in flight per workgroup and two workgroups share a CU.
+// LDS rows are 64 B: unit (row, chunk c) sits at 16-B slot ((row>>2)&3) ^ PERM[c] of its row, which makes the
+// ds_read_b128 fragment reads (16 rows x chunks {c, c+1} per lane group) conflict free; the DMA applies the inverse
+// on the source side.
+#define EP24_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int BN, bool OUT_F32, int RING>
+__global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
+    constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
+    constexpr int RK = 32;
+    if (DBG(p, 128)) return;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024 / 4;          // 2 DMA instructions per wave
+    constexpr int B_INSTR = B_BYTES / 1024 / 4;          // 2 (BN=128) or 1 (BN=64)
+    constexpr int GROUP = A_INSTR + B_INSTR;             // vmcnt units per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = tile_id / tiles_n;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = (tile_id - tile_m * tiles_n) * BN;
+    const int KC = (p.K + RK - 1) / RK;
+    const int n_iter = p.T * KC;
+
+    // lane -> LDS unit U = (wave*NI + i)*64 + lane: row = U>>2, physical slot = U&3, logical chunk = PINV[slot ^ rh]
+    const int rh = (lane >> 4) & 3;                       // ((row >> 2) & 3) with row = 16*k + (lane >> 2)
+    const int pslot = lane & 3;
+    const int lchunk = (0x1320 >> (4 * (pslot ^ rh))) & 3;   // PINV = {0,2,3,1}
+    const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+    constexpr int OOB = 0x7FFFFFF0;
+    int rowoff[A_INSTR];
+    unsigned vmask[A_INSTR];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
+    for (int i = 0; i < A_INSTR; ++i) {
+        const long m = m0 + (wave * A_INSTR + i) * 16 + (lane >> 2);
+        const bool rv = m < p.M;
+        const int mm = rv ? (int)m : 0;
+        const int n = fdiv(mm, p.d_plane);
+        const int rem = mm - n * (p.GH * p.GW);
+        const int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
+        const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+        rowoff[i] = (int)((((long)n * p.SH * p.SW + (long)iy0 * p.SW + ix0) * p.ld_src + lchunk * 8) * 2);
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {         // static trip count: the tap tables arrive with the kernel arguments
+            const int iy = iy0 + p.oy[t], ix = ix0 + p.ox[t];
+            if (t < p.T && rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
+        }
+        vmask[i] = mk;
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
-                           p.dbs == (long)p.GH * p.GW);
+    int wvoff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int q = (wave * B_INSTR + i) * 16 + (lane >> 2);
+        const int r = (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
+        wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : 0x40000000;
+    }
+    const int kmax = (p.K - lchunk * 8 + RK - 1) / RK;
+    if (p.dbg_same_addr) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) rowoff[i] = (lane & 7) * 16 + 4096;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) wvoff[i] = (lane & 7) * 16;
+    }
+
+    // per-tap scalars live in a small LDS table and are fetched one stage ahead (a dynamic kernarg index would be
+    // an s_load + full lgkmcnt wait inside every K step)
+    int* tap_tab = reinterpret_cast<int*>(smem + RING * STAGE);        // [0..15] source byte offset, [16..31] weight slot
+    if (tid < 16) { tap_tab[tid] = p.toff[tid]; tap_tab[16 + tid] = p.wslot[tid] * p.K * 2; }
+    __syncthreads();
+    int is_t = 0, is_kc = 0, is_stage = 0;
+    int pf_a = tap_tab[0], pf_b = tap_tab[16];
+    auto issue = [&]() {
+        const int t = is_t, kc = is_kc;
+        if (++is_t == p.T) { is_t = 0; ++is_kc; }
+        const int a_s = pf_a + kc * (RK * 2);
+        const int b_s = pf_b + kc * (RK * 2);
+        pf_a = tap_tab[is_t];                              // for the next call
+        pf_b = tap_tab[16 + is_t];
+        char* stage = smem + is_stage * STAGE;
+        if (++is_stage == RING) is_stage = 0;
+        // branch-free validity: an invalid lane adds 2^30 to its offset (beyond every buffer => the DMA writes zeros).
+        // The value is made opaque so the compiler cannot turn the select into two exec-masked copies of the load,
+        // which would break the counted vmcnt bookkeeping below.
+        int kbad = kc < kmax ? 0 : 0x40000000;
+        asm volatile("" : "+v"(kbad));
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            int bad = ((vmask[i] >> t) & 1u) ? 0 : 0x40000000;
+            asm volatile("" : "+v"(bad));
+            const int vo = (rowoff[i] + a_s) + (bad | kbad);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int vo = (wvoff[i] + b_s) + kbad;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    // fragment address inside a stage: row*64 + ((row>>2)&3 ^ PERM[fq])*16, PERM = {0,3,1,2}
+    const int pfq = (0x2130 >> (4 * fq)) & 3;
+    int a_off[MT], b_off[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int row = wm * (MT * 16) + i * 16 + frow;
+        a_off[i] = row * 64 + ((((row >> 2) & 3) ^ pfq) << 4);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
-            if (m >= p.M) continue;
-            long dpix = m;
-            if (!fast_dst) {
-                int n = (int)(m / (p.GH * p.GW));
-                int rem = (int)(m - (long)n * (p.GH * p.GW));
-                int gy = rem / p.GW, gx = rem - gy * p.GW;
-                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
-            }
-            float v[4];
+    for (int q = 0; q < NT; ++q) {
+        const int row = wn * 64 + q * 16 + frow;
+        b_off[q] = A_BYTES + row * 64 + ((((row >> 2) & 3) ^ pfq) << 4);
+    }
+
+    if (DBG(p, 256)) { asm volatile("" ::"v"(rowoff[0] + wvoff[0] + (int)vmask[0] + a_off[0] + b_off[0])); return; }
+    const int pre = n_iter < RING - 1 ? n_iter : RING - 1;
+    for (int s_ = 0; s_ < pre; ++s_) issue();
+    int issued = pre, cs = 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const int ahead = issued - it - 1;               // stages issued after the one needed now (0..RING-2)
+        if (!DBG(p, 4)) {
+        if (ahead >= 2) { if constexpr (GROUP == 4) EP24_WAIT_VMCNT(8); else EP24_WAIT_VMCNT(6); }
+        else if (ahead == 1) { if constexpr (GROUP == 4) EP24_WAIT_VMCNT(4); else EP24_WAIT_VMCNT(3); }
+        else EP24_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                     // stage `it` landed for every wave; stage it-1 is free
+        }
+        if (issued < n_iter) { if (!DBG(p, 2)) issue(); ++issued; }
+        const char* st = smem + cs * STAGE;
+        if (++cs == RING) cs = 0;
+        bf16x8 fa[MT], fb[NT];
+        if (!DBG(p, 8)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[q] = acc[i][q][r] + bias4[q];
-                s1[q] += v[q];
-                s2[q] += v[q] * v[q];
-            }
-            if constexpr (OUT_F32) {
-                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
-            } else {
-                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
-                if (c0 + 3 < p.N) {
-                    if (p.accumulate) {
-                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+        for (int q = 0; q < NT; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(st + b_off[q]);
+        } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
-                    }
-                    bf16x4 w;
+        for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(fa[i]));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
-                    *reinterpret_cast<bf16x4*>(d) = w;
-                } else {
+        for (int q = 0; q < NT; ++q) asm volatile("" : "=v"(fb[q]));
+        }
+        if (!DBG(p, 1)) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                }
-            }
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
+        } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int q = 0; q < NT; ++q) asm volatile("" ::"v"(fb[q]));
         }
     }
-    if (p.stats) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a = s1[q], b = s2[q];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (fq == 0) {
-                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
-            }
-        }
-        __syncthreads();
-        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
-        for (int i = tid; i < 2 * BN; i += 256) {
-            const int which = i / BN, c = i - which * BN;
-            const int wcol = c >> 6;
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
-        }
-    }
+    igemm_epilogue<BN, OUT_F32, MT>(p, acc, m0, n0, tile_m, smem);
 }
 
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
     if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
+    else if (!getenv("EP24_IGEMM_RING")) hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
+    else {
+        // experimental: BK=32 ring with counted vmcnt (EP24_IGEMM_RING=2|3|4 stages); measured within +-10 % of the
+        // two-stage BK=64 kernel on the 3x3 layers, which stays the default
+        const int ring = atoi(getenv("EP24_IGEMM_RING"));
+        const dim3 g1(grid.x * grid.y);
+        const size_t st = BM * 64 + BN * 64;
+        if (ring == 2) hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 2>), g1, dim3(256), 2 * st + 128, stream, a);
+        else if (ring == 3) hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 3>), g1, dim3(256), 3 * st + 128, stream, a);
+        else hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 4>), g1, dim3(256), 4 * st + 128, stream, a);
+    }
 }
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
@@ -486,7 +697,10 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     int gx = persist ? 1024 / gy : tiles_m;
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
-    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
+    a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
+    a.dbg_same_addr = getenv("EP24_DBG_SAME_ADDR") != nullptr;
+    a.dbg_mode = getenv("EP24_DBG_MODE") ? atoi(getenv("EP24_DBG_MODE")) : 0;
+    for (int t = 0; t < a.T; ++t) a.toff[t] = a.dbg_same_addr ? 0 : (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     const int n_iter = a.T * ((a.K + BK - 1) / BK);

@@ -30,11 +30,24 @@ def main():
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    # capture the launches in a hipGraph so that the host launch path does not bound short kernels
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         run()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            run()
+    g.replay()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / iters
     fl = 2.0 * B * OH * OH * Cin * Cout * k * k
     print("%s B%d H%d Cin%d Cout%d k%d s%d: %.1f us  %.1f TFLOP/s" % (kind, B, H, Cin, Cout, k, s, dt * 1e6, fl / dt / 1e12))
 
