@@ -146,6 +146,10 @@ __device__ void block_best(float& v, int& i, float* sv, int* si) {
     __syncthreads();
 }
 
+// One workgroup per (image, gt).  The candidate values of the row are cached in registers (PER = ceil(A/256)
+// per thread, 33 at 640x640) so the 10 + k selection rounds never go back to memory; larger anchor counts
+// (PER > 40, e.g. 1280x1280) take the re-reading path.
+template <int PER>
 __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const float* cost, const int* num_gt,
                                                         const unsigned long long* in_box, const unsigned long long* in_ctr,
                                                         unsigned long long* match, int* ks, int A) {
@@ -157,16 +161,36 @@ __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const f
     const float* cr = cost + ((long)b * G_MAX + g) * A;
     const unsigned long long* mb = in_box + (long)b * A;
     const unsigned long long* mc = in_ctr + (long)b * A;
+    float vpw[PER > 0 ? PER : 1], vco[PER > 0 ? PER : 1];
+    if constexpr (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int a = threadIdx.x + 256 * j;
+            const bool cand = a < A && (mb[a] | mc[a]) != 0ull;
+            vpw[j] = cand ? pwr[a] : -INFINITY;                      // never selected
+            vco[j] = cand ? cr[a] : INFINITY;
+        }
+    }
     // top-min(10,P) largest pairwise values, summed in descending order (losses.py:452-456)
     float prev_v = INFINITY; int prev_i = -1;
     float total = 0.f;
     for (int r = 0; r < 10; ++r) {
         float bv = -INFINITY; int bi = -1;
-        for (int a = threadIdx.x; a < A; a += 256) {
-            if ((mb[a] | mc[a]) == 0ull) continue;
-            const float v = pwr[a];
-            const bool after = v < prev_v || (v == prev_v && a > prev_i);
-            if (after && (bi < 0 || v > bv)) { bv = v; bi = a; }     // ascending a: first hit keeps the smaller index
+        if constexpr (PER > 0) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int a = threadIdx.x + 256 * j;
+                const float v = vpw[j];
+                const bool after = v < prev_v || (v == prev_v && a > prev_i);
+                if (v > -INFINITY && after && (bi < 0 || v > bv)) { bv = v; bi = a; }
+            }
+        } else {
+            for (int a = threadIdx.x; a < A; a += 256) {
+                if ((mb[a] | mc[a]) == 0ull) continue;
+                const float v = pwr[a];
+                const bool after = v < prev_v || (v == prev_v && a > prev_i);
+                if (after && (bi < 0 || v > bv)) { bv = v; bi = a; }     // ascending a: first hit keeps the smaller index
+            }
         }
         block_best<true>(bv, bi, sv, si);
         if (bi < 0) break;                                          // fewer than 10 candidates
@@ -180,11 +204,21 @@ __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const f
     prev_v = -INFINITY; prev_i = -1;
     for (int r = 0; r < k; ++r) {
         float bv = INFINITY; int bi = -1;
-        for (int a = threadIdx.x; a < A; a += 256) {
-            if ((mb[a] | mc[a]) == 0ull) continue;
-            const float v = cr[a];
-            const bool after = v > prev_v || (v == prev_v && a > prev_i);
-            if (after && (bi < 0 || v < bv)) { bv = v; bi = a; }
+        if constexpr (PER > 0) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int a = threadIdx.x + 256 * j;
+                const float v = vco[j];
+                const bool after = v > prev_v || (v == prev_v && a > prev_i);
+                if (v < INFINITY && after && (bi < 0 || v < bv)) { bv = v; bi = a; }
+            }
+        } else {
+            for (int a = threadIdx.x; a < A; a += 256) {
+                if ((mb[a] | mc[a]) == 0ull) continue;
+                const float v = cr[a];
+                const bool after = v > prev_v || (v == prev_v && a > prev_i);
+                if (after && (bi < 0 || v < bv)) { bv = v; bi = a; }
+            }
         }
         block_best<false>(bv, bi, sv, si);
         if (bi < 0) break;
@@ -245,8 +279,12 @@ extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* la
 extern "C" int ep24_dynamic_k(const float* pw, const float* cost, const int32_t* num_gt, const uint64_t* in_box,
                               const uint64_t* in_ctr, uint64_t* match, int32_t* ks, int B, int A, void* stream) {
     EP24_REQUIRE(pw && cost && num_gt && in_box && in_ctr && match && ks, EP24_E_ARG, "dynamic_k: null pointer");
-    hipLaunchKernelGGL(dynamic_k_kernel, dim3(G_MAX, B), dim3(256), 0, (hipStream_t)stream, pw, cost, num_gt,
-                       (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, (unsigned long long*)match, ks, A);
+    if (A <= 33 * 256)
+        hipLaunchKernelGGL(dynamic_k_kernel<33>, dim3(G_MAX, B), dim3(256), 0, (hipStream_t)stream, pw, cost, num_gt,
+                           (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, (unsigned long long*)match, ks, A);
+    else
+        hipLaunchKernelGGL(dynamic_k_kernel<0>, dim3(G_MAX, B), dim3(256), 0, (hipStream_t)stream, pw, cost, num_gt,
+                           (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, (unsigned long long*)match, ks, A);
     EP24_LAUNCH_CHECK("ep24_dynamic_k");
     return EP24_OK;
 }

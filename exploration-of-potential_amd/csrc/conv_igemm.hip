@@ -90,10 +90,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         for (int i = 0; i < 4; ++i) {
             long m = m0 + lrow + 32 * i;
             rvalid[i] = m < p.M;
-            long mm = rvalid[i] ? m : 0;
-            int n = (int)(mm / (p.GH * p.GW));
-            int rem = (int)(mm - (long)n * (p.GH * p.GW));
-            int gy = rem / p.GW, gx = rem - gy * p.GW;
+            int mm = rvalid[i] ? (int)m : 0;
+            int n = fdiv(mm, p.d_plane);
+            int rem = mm - n * (p.GH * p.GW);
+            int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
             pixbase[i] = n * p.SH * p.SW;
             iy0[i] = gy * p.sy;
             ix0[i] = gx * p.sx;
@@ -110,12 +110,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
     bf16x8 ra[4], rb[B_PIECES];
     int ld_it = 0, ld_tile = blockIdx.x;             // (K-step, M tile) of the next load
+    int ld_t = 0, ld_kc = 0;                         // its (tap, channel chunk)
     bool ld_first = true;                            // still inside this workgroup's first M tile
 
     auto load_tile = [&]() {
-        if (ld_it == 0) setup_rows(ld_tile);
-        const int t = ld_it / KC;
-        const int kc = ld_it - t * KC;
+        if (ld_it == 0) { setup_rows(ld_tile); ld_t = 0; ld_kc = 0; }
+        const int t = ld_t, kc = ld_kc;
+        if (++ld_kc == KC) { ld_kc = 0; ++ld_t; }
         const int oy = p.oy[t], ox = p.ox[t];
         const bool kok = kc * BK + chunk * 8 < p.K;
 #pragma unroll
@@ -214,9 +215,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 if (m >= p.M) continue;
                 long dpix = m;
                 if (!fast_dst) {
-                    int n = (int)(m / (p.GH * p.GW));
-                    int rem = (int)(m - (long)n * (p.GH * p.GW));
-                    int gy = rem / p.GW, gx = rem - gy * p.GW;
+                    int n = fdiv((int)m, p.d_plane);
+                    int rem = (int)m - n * (p.GH * p.GW);
+                    int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
                     dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
                 }
                 float v[4];

@@ -523,6 +523,83 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, long 
     }
 }
 
+// All conv segments in ONE launch: desc[s] = {master offset, fwd offset, dgrad offset (-1: none), Cout, T, Cin,
+// Cin_pad, Cout_pad}; prefix[s] = first flat element index of segment s in the packed enumeration.
+__global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, const long* desc, const long* prefix, int n_seg,
+                                                          bf16* wf, bf16* wd) {
+    __shared__ int s_first;
+    const long total = prefix[n_seg];
+    for (long base = (long)blockIdx.x * 1024; base < total; base += (long)gridDim.x * 1024) {
+        if (threadIdx.x == 0) {
+            int lo = 0, hi = n_seg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (prefix[mid] <= base) lo = mid; else hi = mid - 1;
+            }
+            s_first = lo;
+        }
+        __syncthreads();
+        int seg = s_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long i = base + threadIdx.x + 256 * k;
+            if (i >= total) break;
+            while (i >= prefix[seg + 1]) ++seg;
+            const long* d = desc + (long)seg * 8;
+            const long e = i - prefix[seg];
+            const int T = (int)d[4], Cin = (int)d[5];
+            const int ci = (int)(e % Cin);
+            const long r = e / Cin;
+            const int t = (int)(r % T);
+            const int co = (int)(r / T);
+            wf[d[1] + ((long)co * T + t) * d[6] + ci] = (bf16)flat[d[0] + e];
+        }
+        __syncthreads();
+    }
+}
+
+// dgrad copy [Cin][T][Cout_pad] = transpose of the master [Cout][T][Cin] per tap: 64x64 tiles through LDS so that both
+// the fp32 reads (along ci) and the bf16 writes (along co) are coalesced.  tprefix[s] = first tile of segment s.
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* flat, const long* desc, const long* tprefix, int n_seg,
+                                                            bf16* wd) {
+    __shared__ float tile[64][65];
+    __shared__ int s_seg;
+    const long total = tprefix[n_seg];
+    for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+        if (threadIdx.x == 0) {
+            int lo = 0, hi = n_seg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (tprefix[mid] <= tl) lo = mid; else hi = mid - 1;
+            }
+            s_seg = lo;
+        }
+        __syncthreads();
+        const long* d = desc + (long)s_seg * 8;
+        const int Cout = (int)d[3], T = (int)d[4], Cin = (int)d[5];
+        const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
+        long r = tl - tprefix[s_seg];
+        const int ci0 = (int)(r % tci) * 64; r /= tci;
+        const int co0 = (int)(r % tco) * 64;
+        const int t = (int)(r / tco);
+        const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int co = co0 + r4 + 4 * k, ci = ci0 + c;
+            tile[r4 + 4 * k][c] = (co < Cout && ci < Cin) ? flat[d[0] + ((long)co * T + t) * Cin + ci] : 0.f;
+        }
+        __syncthreads();
+        if (d[2] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int ci = ci0 + r4 + 4 * k, co = co0 + c;
+                if (ci < Cin && co < Cout) wd[d[2] + ((long)ci * T + t) * d[7] + co] = (bf16)tile[c][r4 + 4 * k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float mom,
                                                   float gscale, const int* first_flag) {
     const int first = *first_flag;
@@ -701,5 +778,18 @@ extern "C" int ep24_memset_zero(void* p, int64_t bytes, void* stream) {
     EP24_REQUIRE(p && bytes >= 0, EP24_E_ARG, "memset_zero: bad arguments");
     hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
     EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "memset_zero: %s", hipGetErrorString(e));
+    return EP24_OK;
+}
+
+extern "C" int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int64_t* prefix, const int64_t* tile_prefix,
+                                         int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles, void* stream) {
+    EP24_REQUIRE(flat && desc && prefix && tile_prefix && w_fwd && w_dgrad && n_seg > 0 && total > 0, EP24_E_ARG,
+                 "pack_weights_batched: bad arguments");
+    long blocks = (total + 1023) / 1024;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, S_, flat, (const long*)desc,
+                       (const long*)prefix, n_seg, (bf16*)w_fwd, (bf16*)w_dgrad);
+    hipLaunchKernelGGL(pack_transpose_kernel, dim3((unsigned)(total_tiles > 8192 ? 8192 : total_tiles)), dim3(256), 0, S_, flat,
+                       (const long*)desc, (const long*)tile_prefix, n_seg, (bf16*)w_dgrad);
+    EP24_LAUNCH_CHECK("ep24_pack_weights_batched");
     return EP24_OK;
 }

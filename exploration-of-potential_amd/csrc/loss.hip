@@ -62,13 +62,23 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const float* outputs, i
     }
 }
 
-__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* partials, int nblocks, const int* num_gt, int B,
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partials, int nblocks, const int* num_gt, int B,
                                                            float* state, float* result) {
+    // fixed-order two-level fold (bitwise reproducible): 8 row groups x 32 columns, then the 8 group sums in order
+    __shared__ float grp[8][NS];
     __shared__ float sums[NS];
     const int t = threadIdx.x;
+    {
+        const int col = t & 31, g = t >> 5;
+        const int per = (nblocks + 7) / 8;
+        float s = 0.f;
+        for (int i = g * per; i < min(nblocks, (g + 1) * per); ++i) s += partials[(long)i * NS + col];
+        grp[g][col] = s;
+    }
+    __syncthreads();
     if (t < NS) {
         float s = 0.f;
-        for (int i = 0; i < nblocks; ++i) s += partials[(long)i * NS + t];
+        for (int g = 0; g < 8; ++g) s += grp[g][t];
         sums[t] = s;
     }
     __syncthreads();
@@ -215,7 +225,7 @@ extern "C" int ep24_loss_terms(const float* outputs, int ncols, const float* lab
 extern "C" int ep24_loss_finalize(const float* partials, int nblocks, const int32_t* num_gt, int B, float* state, float* result,
                                   void* stream) {
     EP24_REQUIRE(partials && num_gt && state && result && nblocks > 0, EP24_E_ARG, "loss_finalize: bad arguments");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblocks, num_gt, B, state, result);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nblocks, num_gt, B, state, result);
     EP24_LAUNCH_CHECK("ep24_loss_finalize");
     return EP24_OK;
 }

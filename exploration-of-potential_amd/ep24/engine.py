@@ -183,6 +183,16 @@ class ParamHome:
         self.wf = torch.zeros(max(wf, 8), dtype=BF16, device=dev)
         self.wd = torch.zeros(max(wd, 8), dtype=BF16, device=dev)
         self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
+        rows, pref, tpref = [], [0], [0]
+        for seg in self.convs:
+            rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
+            pref.append(pref[-1] + seg.numel)
+            tpref.append(tpref[-1] + seg.taps * ((seg.cout + 63) // 64) * ((seg.cin + 63) // 64))
+        self.pack_tprefix = torch.tensor(tpref, dtype=torch.int64, device=dev)
+        self.pack_tiles = tpref[-1]
+        self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.pack_prefix = torch.tensor(pref, dtype=torch.int64, device=dev)
+        self.pack_total = pref[-1]
         self.views = {}                                   # param -> (flat view, grad view, momentum view)
         with torch.no_grad():
             for seg in self.order:
@@ -217,11 +227,8 @@ class ParamHome:
 
     def pack(self):
         """fp32 masters -> bf16 [Cout][T][Cin] (forward) and [Cin][T][Cout_pad] (dgrad) copies."""
-        s = stream_ptr()
-        for seg in self.convs:
-            call("pack_weights", ptr(self.flat, seg.off), seg.taps * seg.cin, ptr(self.wf, seg.wf_off),
-                 ptr(self.wd, seg.wd_off) if seg.need_dgrad else None, seg.cout, seg.taps, seg.cin, seg.cin_pad,
-                 seg.cout_pad, s)
+        call("pack_weights_batched", ptr(self.flat), ptr(self.pack_desc), ptr(self.pack_prefix), ptr(self.pack_tprefix),
+             len(self.convs), ptr(self.wf), ptr(self.wd), self.pack_total, self.pack_tiles, stream_ptr())
 
     def zero_grad(self):
         call("memset_zero", ptr(self.gflat), self.numel * 4, stream_ptr())

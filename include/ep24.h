@@ -69,6 +69,13 @@ int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld
 int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, int Cout, int T, int Cin,
                       int Cin_pad, int Cout_pad, void* stream);
 
+/* The same for every conv segment of a model in one launch.  desc [n_seg][8] int64 = {master offset, w_fwd offset,
+ * w_dgrad offset or -1, Cout, T, Cin, Cin_pad, Cout_pad} (element offsets into flat / w_fwd / w_dgrad); prefix
+ * [n_seg+1] int64 = running sum of Cout*T*Cin (total = prefix[n_seg]); tile_prefix [n_seg+1] = running sum of
+ * T*ceil(Cout/64)*ceil(Cin/64), the 64x64 tiles of the LDS transpose that writes w_dgrad coalesced. */
+int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int64_t* prefix, const int64_t* tile_prefix,
+                              int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles, void* stream);
+
 /* y = silu(bn(z)) (+ residual), training-mode BatchNorm with batch statistics taken from `stats`
  * ([replicas][2][C] fixed-point sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
  * save[1][c]=invstd for the backward and updates running_mean / running_var (unbiased) / num_batches_tracked
