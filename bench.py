@@ -45,6 +45,10 @@ def instrumented_step(ts):
     def run(lst):
         s = _lib.stream_ptr()
         for name, args in lst:
+            if name[0] == "@":                      # stream-ordering entries: the instrumented pass is serial
+                continue
+            if name.startswith("side:"):
+                name = name[5:]
             a = [x.get() if hasattr(x, "get") else x for x in args]
             timed = name.startswith("conv_")
             if timed:
@@ -67,7 +71,7 @@ def instrumented_step(ts):
     torch.cuda.synchronize()
     if os.environ.get("EP24_LAYER_TABLE"):
         rows = {}
-        for (name, fl, e0, e1), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].startswith("conv_")]):
+        for (name, fl, e0, e1), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]):
             key = (name,) + tuple(args[-7:])
             r = rows.setdefault(key, [0, 0.0, 0.0])
             r[0] += 1
@@ -128,6 +132,7 @@ def main():
     ap.add_argument("--gts", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-backward", action="store_true", help="capture backward too (single stream)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -150,7 +155,7 @@ def main():
     lf = eloss.Loss_Function(80)
     reducer = dp.GradReducer() if world > 1 else None
     ts = etrain.TrainStep(model, lf, lr=0.001, momentum=0.9, batch=a.batch, size=a.size, reducer=reducer,
-                          use_graph=not a.no_graph)
+                          use_graph=not a.no_graph, graph_backward=a.graph_backward)
     # this rank's shard of the synthetic global batch (weak scaling: per-GPU work fixed)
     images = synth.make_images(a.batch, a.size, seed=1 + rank).to(dev)
     labels = synth.make_labels(a.batch, a.gts, size=a.size, seed=1000 + rank).to(dev)
@@ -188,7 +193,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "YOLOX-l-24p (CSPDarknet53+PAFPN+24p head) train step, %dx%d, batch %d/GPU, %d GTs/img, "
                                    "SimOTA + 24-circle GIoU loss, SGD nesterov" % (a.size, a.size, a.batch, a.gts),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": not a.no_graph},
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "all phases" if a.graph_backward else "fwd+loss, update; backward on 2 streams")},
             "loss": round(loss, 4),
             "step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE * (a.size / 640.0) ** 2 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,

@@ -298,6 +298,8 @@ class Engine:
         self.outputs = None
         self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
+        self._bwd_units = 0
+        self._side = None
         self._bwd_builders = []
         self.dyn = {}                            # run-time pointers (input images, incoming gradient)
         self._stats_specs, self._sum_specs = [], []
@@ -367,7 +369,8 @@ class Engine:
     def _finalize(self):
         """Allocate the shared scratch, then build the backward list in reverse op order and resolve pointers."""
         # scratch shared by all layers (single stream => no overlap in time)
-        self.dz = torch.zeros(max(self.max_dz, 8), dtype=BF16, device=self.dev)
+        # two dz scratch buffers: the weight gradient of layer L (side stream) may still read one while layer L-1 fills the other
+        self.dz2 = [torch.zeros(max(self.max_dz, 8), dtype=BF16, device=self.dev) for _ in range(2)]
         self.stats = torch.zeros(max(sum(self._stats_specs), 4), dtype=torch.int64, device=self.dev)
         self.bnsums = torch.zeros(max(sum(self._sum_specs), 4), dtype=torch.int64, device=self.dev)
         for b in reversed(self._bwd_builders):
@@ -394,7 +397,7 @@ class Engine:
         home = self.home
         seg = home.by_param[mod.conv.weight]
         gam, bet = home.by_param[mod.bn.weight], home.by_param[mod.bn.bias]
-        k = 1 if stem else mod.conv.kernel_size[0]
+        k = k_ = 1 if stem else mod.conv.kernel_size[0]
         s = 1 if stem else mod.conv.stride[0]
         cin = x.C                                  # stem: im2col width 112 (108 real columns)
         assert x.C == seg.cin_pad if stem else x.C == seg.cin, (x.C, seg.cin)
@@ -425,18 +428,26 @@ class Engine:
 
         def build_bwd():
             assert out.gready(), "activation without a gradient producer"
-            dz = lambda: self.dz.data_ptr()
+            k = self._bwd_units                       # position in backward execution order
+            self._bwd_units += 1
+            dz = (lambda k=k: self.dz2[k & 1].data_ptr())
+            # dz[k&1] was last read by the side-stream weight gradient of unit k-2
+            self._b("@main_wait_side", (k - 2,))
             self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                           ptr(flat, bet.off), sum_g, sum_b, M, cout, 1))
             self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                          ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
                                          dz, cout, M, cout, 1), writes=(gam, bet))
-            self._b("conv_wgrad_bf16", (x.ptr(), x.ld, dz, cout, ptr(gflat, seg.off), seg.taps * seg.cin, cout,
-                                        seg.cin, B, H, W, cin, cout, k, s), writes=(seg,))
+            # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
+            # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
+            self._b("@side_wait_main", ())
+            self._b("side:conv_wgrad_bf16", (x.ptr(), x.ld, dz, cout, ptr(gflat, seg.off), seg.taps * seg.cin, cout,
+                                             seg.cin, B, H, W, cin, cout, k_, s), writes=(seg,))
+            self._b("@side_record", (k,))
             if x.needs_grad:
                 acc = x.gwrite()
                 self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
-                                            seg.cout_pad, k, s))
+                                            seg.cout_pad, k_, s))
 
         self._bwd_builders.append(build_bwd)
         return out
@@ -525,12 +536,47 @@ class Engine:
 
     # ---- execution ----------------------------------------------------------------------------------
     def _run(self, lst):
-        s = stream_ptr()
+        """Launch a list on the current stream.  Entries named ``side:<fn>`` go to a second stream; the control
+        entries ``@side_wait_main`` / ``@side_record(k)`` / ``@main_wait_side(k)`` order the two with events.  The
+        call returns with the side stream joined.  Under hipGraph capture everything stays on the capturing stream:
+        a captured graph with ~240 cross-stream edges faulted at replay on ROCm 7.2, so
+        ep24.train replays graphs for the forward/loss and update phases and runs backward through this path."""
+        main = torch.cuda.current_stream()
+        s_main = main.cuda_stream
+        lanes = not torch.cuda.is_current_stream_capturing()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        side, s_side = self._side, self._side.cuda_stream
         fn = _lib.lib().fn
+        events, used_side = {}, False
         for name, args in lst:
+            if name[0] == "@":
+                if not lanes:
+                    continue
+                if name == "@side_wait_main":
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    used_side = True
+                elif name == "@side_record":
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events[args[0]] = ev
+                elif name == "@main_wait_side":
+                    ev = events.get(args[0])
+                    if ev is not None:
+                        main.wait_event(ev)
+                continue
+            s = s_main
+            if name.startswith("side:"):
+                name = name[5:]
+                if lanes:
+                    s = s_side
             rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
             if rc != 0:
                 raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
+        if used_side:
+            main.wait_stream(side)
 
     def zero_step_buffers(self):
         s = stream_ptr()

@@ -272,8 +272,10 @@ def test_model_gradients_are_finite_and_head_directions_match_oracle():
     assert torch.isfinite(torch.cat([p.grad.reshape(-1) for p in m.parameters()])).all()
 
 
-def test_eager_api_step_matches_captured_step():
-    """Reference-style loop (model -> Loss_Function -> backward -> optimizer.step) vs the hipGraph TrainStep."""
+@pytest.mark.parametrize("graph_backward", [False, True])
+def test_eager_api_step_matches_captured_step(graph_backward):
+    """Reference-style loop (model -> Loss_Function -> backward -> optimizer.step) vs the hipGraph TrainStep
+    (backward either launched on two streams or captured as well)."""
     from ep24 import loss as eloss, train as etrain
     torch.manual_seed(0)
     ma = tiny_model()
@@ -295,7 +297,7 @@ def test_eager_api_step_matches_captured_step():
         losses_a.append(float(tup[0]))
     # b) captured
     lf_b = eloss.Loss_Function(80)
-    ts = etrain.TrainStep(mb, lf_b, lr=0.01, momentum=0.9, batch=B, size=S)
+    ts = etrain.TrainStep(mb, lf_b, lr=0.01, momentum=0.9, batch=B, size=S, graph_backward=graph_backward)
     losses_b = [float(ts.step(images, labels)[0]) for _ in range(3)]
     print("eager", losses_a, "captured", losses_b)
     assert all(np.isfinite(losses_a)) and all(np.isfinite(losses_b))
