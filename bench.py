@@ -41,6 +41,7 @@ def instrumented_step(ts):
     eng = ts.eng
     fn = _lib.lib().fn
     rec = []
+    all_rec = [] if os.environ.get("EP24_LAYER_TABLE") else None
 
     def run(lst):
         s = _lib.stream_ptr()
@@ -51,6 +52,13 @@ def instrumented_step(ts):
                 name = name[5:]
             a = [x.get() if hasattr(x, "get") else x for x in args]
             timed = name.startswith("conv_")
+            if all_rec is not None and not timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn["ep24_" + name](*a, s)
+                e1.record()
+                all_rec.append((name, tuple(v for v in a[-5:] if isinstance(v, int) and abs(v) < (1 << 24)), e0, e1))
+                continue
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -81,6 +89,14 @@ def instrumented_step(ts):
             fh.write("kernel B H W Cin Cout k s : launches  ms_total  TFLOP/s\n")
             for key, (n, fl, ms) in sorted(rows.items(), key=lambda kv: -kv[1][2]):
                 fh.write("%-18s %s : %3d %8.3f %8.1f\n" % (key[0], " ".join("%4d" % v for v in key[1:]), n, ms, fl / ms / 1e9))
+            other = {}
+            for name, key, e0, e1 in all_rec:
+                r = other.setdefault((name,) + key, [0, 0.0])
+                r[0] += 1
+                r[1] += e0.elapsed_time(e1)
+            fh.write("\nother kernels (name, trailing int args) : launches ms_total\n")
+            for key, (n, ms) in sorted(other.items(), key=lambda kv: -kv[1][1]):
+                fh.write("%-22s %-40s : %3d %8.3f\n" % (key[0], " ".join(str(v) for v in key[1:]), n, ms))
     fam = {}
     for name, fl, e0, e1 in rec:
         kern = "wgrad_kernel" if name == "conv_wgrad_bf16" else "igemm_kernel"

@@ -457,12 +457,14 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         char* stage = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const int vo = (kok && ((vmask[i] >> t) & 1u)) ? rowoff[i] + a_s : OOB;
+            int vo = (kok && ((vmask[i] >> t) & 1u)) ? rowoff[i] + a_s : OOB;
+            if (DBG(p, 256) || (DBG(p, 1024) && (i & 1))) vo = OOB;          // ablation: drop (half of) the A fill traffic
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const int vo = kok ? wvoff[i] + b_s : OOB;
+            int vo = kok ? wvoff[i] + b_s : OOB;
+            if (DBG(p, 512)) vo = OOB;                                        // ablation: drop the B fill traffic
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
     };

@@ -22,11 +22,14 @@ struct WgradArgs {
     int B, H, W, OH, OW, Cin, Cout, ksize, stride, pad;
     long M;          // B*OH*OW
     long chunk;      // pixels per split (multiple of 64)
-    int tiles_ci, tiles_co, T;
+    int tiles_ci, tiles_co, T, tiles, xcd_remap;
     FastDiv d_plane, d_ow;      // pixel -> (n, oh, ow)
     unsigned x_bytes, dy_bytes; // extents for the buffer descriptors
+    int c_n, c_oh, c_ow, c_pix; // byte strides of X per image / output row / output column / input pixel
+    int s_dys, s_dxs, s_doff;   // what a 64-pixel step adds to (input row, input column, byte offset) before the wraps
     int dbg_skip_epilogue;      // tools/conv_probe.py experiments only
     int dbg_splits;
+    int dbg_noload;             // 1: dY loads dropped, 2: X loads (and their address decode) dropped
 };
 
 // Row keys of the 32-byte-block XOR permutation.  256-B rows (128 channels): one row per bank row, the 8 rows a
@@ -54,6 +57,14 @@ template <int TW> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, in
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// two transposed 8-byte reads (rows r..r+3 and r+4..r+7 of a 16-channel block) = one 8-deep MFMA k fragment
+template <int OFF_LO, int OFF_HI> __device__ __forceinline__ bf16x8 tr_pair(unsigned addr) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF_LO));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF_HI));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // TCO x TCI output tile of one tap per workgroup (128 or 64 each), 4 waves as 2x2.
 // Staging is LDS-DMA (buffer_load ... lds, 16 B per lane): no VGPR round trip and no ds_write - the VGPR->LDS
 // store path (~79 B/clk/CU) was the busiest pipe of the register-staged version.  The DMA writes LDS linearly, so
@@ -71,12 +82,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx = blockIdx.x;
+    // 1-D grid; workgroup L runs on XCD L % 8.  With a split count that is a multiple of 8, XCD k takes the pixel
+    // splits k, k+8, ... and all tiles of a split run on ONE XCD, so a split's dY / X rows cross the fabric once
+    // instead of once per XCD (each is re-read by 9 taps x the other operand's tile count).
+    int bx, by;
+    if (p.xcd_remap) {
+        const int L = blockIdx.x, k = L & 7, slot = L >> 3;
+        bx = slot % p.tiles;
+        by = (slot / p.tiles) * 8 + k;
+    } else {
+        bx = blockIdx.x % p.tiles;
+        by = blockIdx.x / p.tiles;
+    }
     const int tap = bx % p.T; bx /= p.T;
     const int ci0 = (bx % p.tiles_ci) * TCI;
     const int co0 = (bx / p.tiles_ci) * TCO;
     const int kh = tap / p.ksize, kw = tap % p.ksize;
-    const long p_begin = (long)blockIdx.y * p.chunk;
+    const long p_begin = (long)by * p.chunk;
     const long p_end = min(p.M, p_begin + p.chunk);
     const int n_iter = (int)((p_end - p_begin + 63) / 64);      // uniform over the workgroup
 
@@ -92,39 +114,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         y_row[j] = r;
         y_off[j] = co0 + c * 8 < p.Cout ? (int)((((p_begin + r) * p.ld_dy) + co0 + c * 8) * 2) : OOB;
     }
-    int x_row[XI], x_col[XI];
+    // X rows.  Which input pixel a tile row reads (and whether it is padding) depends only on (step, row), not on the
+    // lane's channel chunk, so the 64 row offsets of a step are produced ONCE per workgroup - 16 rows per wave, one row
+    // per lane, carried from step to step by constant deltas plus at most one wrap of ow and of oh - into a small LDS
+    // table two steps ahead; a DMA instruction then costs one ds_read_b32 and one add.  (Decoding per DMA instruction,
+    // two divisions and 64-bit multiplies each, kept the VALU busier than the MFMAs: 90 -> 62 us per 3x3 256-ch layer.)
+    int* xtab = reinterpret_cast<int*>(smem + 2 * STAGE);          // [2][64] byte offsets, XOOB = padding / past the end
+    constexpr int XOOB = 0x7FFF0000;
+    int x_row[XI], x_colb[XI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int U = (wave * XI + j) * 64 + lane;
         const int r = U / XCH, pc = U % XCH;
         const int c = ((((pc >> 1) ^ rkey<TCI>(r)) << 1) | (pc & 1));
         x_row[j] = r;
-        x_col[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : -1;
+        x_colb[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : XOOB;
     }
+    const int p_end_i = (int)p_end;
+    // producer state of tile row wave*16 + (lane & 15)
+    const int t_row = wave * 16 + (lane & 15);
+    int t_p = (int)p_begin + t_row, t_ys, t_xs, t_off;
+    {
+        const int pd = t_p < p.M ? t_p : 0;
+        const int n = fdiv(pd, p.d_plane);
+        const int rem = pd - n * (p.OH * p.OW);
+        const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
+        t_ys = oh * p.stride; t_xs = ow * p.stride;                 // input row / column of tap (pad, pad)
+        t_off = n * p.c_n + oh * p.c_oh + ow * p.c_ow + ((kh - p.pad) * p.W + (kw - p.pad)) * p.c_pix;
+    }
+    const int lo_y = p.pad - kh, lo_x = p.pad - kw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
+    auto produce = [&](int slot) {
+        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W &&
+                        !(p.dbg_noload & 2);
+        if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
+        t_p += 64; t_ys += p.s_dys; t_xs += p.s_dxs; t_off += p.s_doff;
+        if (t_xs >= wrap_x) { t_xs -= wrap_x; t_ys += p.stride; t_off += p.c_oh - p.OW * p.c_ow; }
+        if (t_ys >= wrap_y) { t_ys -= wrap_y; t_off += p.c_n - p.OH * p.c_oh; }
+    };
     const int y_step = (int)(64 * p.ld_dy * 2);
 
     auto issue = [&](int it, int buf) {
         char* stage = smem + buf * STAGE;
-        const long base = p_begin + (long)it * 64;
+        const int rows_left = p_end_i - (int)p_begin - it * 64;
+        const int* tab = xtab + (it & 1) * 64;
+        int xo[XI];
+#pragma unroll
+        for (int j = 0; j < XI; ++j) xo[j] = tab[x_row[j]];
 #pragma unroll
         for (int j = 0; j < YI; ++j) {
-            const bool ok = base + y_row[j] < p_end && y_off[j] != OOB;
-            const int vo = ok ? y_off[j] + it * y_step : OOB;
+            const bool ok = y_row[j] < rows_left && y_off[j] != OOB;
+            int vo = ok ? y_off[j] + it * y_step : OOB;
+            if (p.dbg_noload & 1) vo = OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lptr_t)(stage + (wave * YI + j) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < XI; ++j) {
-            const long pp = base + x_row[j];
-            int vo = OOB;
-            if (pp < p_end && x_col[j] >= 0) {
-                const int n = fdiv((int)pp, p.d_plane);
-                const int rem = (int)pp - n * (p.OH * p.OW);
-                const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
-                const int iy = oh * p.stride + kh - p.pad, ix = ow * p.stride + kw - p.pad;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) vo = (int)((((long)(n * p.H + iy) * p.W + ix) * p.ld_x) * 2) + x_col[j];
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(stage + Y_BYTES + (wave * XI + j) * 1024), 16, vo, 0, 0, 0);
-        }
+        for (int j = 0; j < XI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(stage + Y_BYTES + (wave * XI + j) * 1024), 16,
+                                                     (int)((unsigned)xo[j] + (unsigned)x_colb[j]), 0, 0, 0);
     };
 
     f32x4 acc[FM][FN];
@@ -137,26 +183,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int q = (lane & 15) >> 2;      // row inside the 4-row transposed block this lane addresses
     const int pp4 = lane & 3;            // 4-channel sub-slot this lane addresses
 
+    // LDS byte addresses of this lane's fragment reads in stage 0, rows (fq*8 + q) / +4, 32-pixel half 0; the other
+    // half, the +4 rows and the second stage are immediate / uniform offsets (they do not change the row key)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned ya[FM], xa[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) ya[i] = lds0 + tr_off<TCO>(fq * 8 + q, wm * FM + i, pp4);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) xa[j] = lds0 + Y_BYTES + tr_off<TCI>(fq * 8 + q, wn * FN + j, pp4);
+
+    produce(0);
+    produce(1);
+    __syncthreads();
     if (n_iter > 0) issue(0, 0);
     for (int it = 0; it < n_iter; ++it) {
         __syncthreads();                 // vmcnt(0) + barrier: step `it` landed, the other stage is free
+        produce(it & 1);                 // offsets of step it+2; slot it&1 was last read when step `it` was issued
         if (it + 1 < n_iter) issue(it + 1, (it + 1) & 1);
-        const char* lds_y = smem + (it & 1) * STAGE;
-        const char* lds_x = lds_y + Y_BYTES;
+        // Fragment reads are inline asm: the compiler puts an s_waitcnt vmcnt(0) in front of the
+        // ds_read_tr16_b64 BUILTIN (it treats it as a possible LDS store that must order behind the LDS-DMA just
+        // issued), which serialised every step's DMA round trip with its MFMAs.  LDS returns in order and lgkmcnt
+        // saturates at 15, so once all 32 reads are issued the 16 of the first 32-pixel half have landed.
+        const unsigned sb = (unsigned)((it & 1) * STAGE);
+        bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int row_lo = ks * 32 + fq * 8 + q;
-            bf16x8 fa[FM], fb[FN];
+        for (int i = 0; i < FM; ++i) fa0[i] = tr_pair<0, 4 * TCO * 2>(ya[i] + sb);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = tr_frag<TCO>(lds_y, row_lo, wm * FM + i, pp4);
+        for (int j = 0; j < FN; ++j) fb0[j] = tr_pair<0, 4 * TCI * 2>(xa[j] + sb);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = tr_frag<TCI>(lds_x, row_lo, wn * FN + j, pp4);
+        for (int i = 0; i < FM; ++i) fa1[i] = tr_pair<32 * TCO * 2, 36 * TCO * 2>(ya[i] + sb);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+        for (int j = 0; j < FN; ++j) fb1[j] = tr_pair<32 * TCI * 2, 36 * TCI * 2>(xa[j] + sb);
+        // wait until only the second half's 2*(FM+FN) reads are outstanding (the counter saturates at 15)
+        if constexpr (2 * (FM + FN) >= 16) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        else if constexpr (2 * (FM + FN) == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        static_assert(2 * (FM + FN) == 16 || 2 * (FM + FN) == 12 || 2 * (FM + FN) == 8, "fragment read count");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // keep the first half's MFMAs in front of the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
     }
 
     // D[row = co][col = ci]: row = 4*fq + r, col = lane & 15
@@ -206,8 +282,10 @@ void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     if (splits < 1) splits = 1;
     a.chunk = ((steps + splits - 1) / splits) * 64;
     splits = (a.M + a.chunk - 1) / a.chunk;
-    dim3 grid(tiles, (unsigned)splits);
-    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2, stream, a);
+    a.tiles = tiles;
+    a.xcd_remap = (splits % 8 == 0) && !getenv("EP24_DBG_WGRAD_NOREMAP");
+    dim3 grid((unsigned)(tiles * splits));
+    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
 }
 
 }  // namespace
@@ -231,9 +309,16 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     EP24_REQUIRE(a.M < (1L << 31), EP24_E_UNSUPPORTED, "conv_wgrad: more than 2^31 output pixels");
     a.d_plane = make_fastdiv((unsigned)(a.OH * a.OW)); a.d_ow = make_fastdiv((unsigned)a.OW);
     a.x_bytes = (unsigned)((((long)B * H * W - 1) * ld_x + Cin) * 2);
+    EP24_REQUIRE((((long)B * H * W) * ld_x) * 2 < 0x7FFF0000L, EP24_E_UNSUPPORTED, "conv_wgrad: input larger than 2 GiB");
+    a.c_pix = (int)(ld_x * 2); a.c_ow = stride * a.c_pix; a.c_oh = stride * W * a.c_pix; a.c_n = H * W * a.c_pix;
+    { const int plane = a.OH * a.OW, dn = 64 / plane, rem = 64 % plane;
+      const int doh = rem / a.OW, dow = rem % a.OW;
+      a.s_dys = doh * stride; a.s_dxs = dow * stride;
+      a.s_doff = dn * a.c_n + doh * a.c_oh + dow * a.c_ow; }
     a.dy_bytes = (unsigned)(((a.M - 1) * ld_dy + Cout) * 2);
     { const char* e = getenv("EP24_DBG_WGRAD_SKIP_EPI"); a.dbg_skip_epilogue = e && e[0] == '1';
-      const char* f = getenv("EP24_DBG_WGRAD_SPLITS"); a.dbg_splits = f ? atoi(f) : 0; }
+      const char* f = getenv("EP24_DBG_WGRAD_SPLITS"); a.dbg_splits = f ? atoi(f) : 0;
+      const char* h = getenv("EP24_DBG_WGRAD_NOLOAD"); a.dbg_noload = h ? atoi(h) : 0; }
     // 1x1 layers are tall-skinny (huge pixel count, small dW): 64x64 tiles quarter the atomic traffic per workgroup
     bool co64 = Cout <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256), ci64 = Cin <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256);
     if (const char* g = getenv("EP24_DBG_WGRAD_TILE")) { co64 = g[0] == '6'; ci64 = g[1] == '6'; }

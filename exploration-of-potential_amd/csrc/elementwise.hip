@@ -1,6 +1,8 @@
 // ep24 - HBM-bound glue kernels of the conv graph: BN(train)+SiLU forward/backward, stem packing, SPP pools,
 // nearest upsample, head decode, bias sums, SGD.  All are streaming kernels: 16-byte (8 x bf16) accesses per
 // lane, consecutive lanes on consecutive addresses, grid capped and row-strided.
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -21,7 +23,7 @@ __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
 
 struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by rows_per_pass
     int tpr, rpb;      // threads per row, rows per block
-    __device__ RowMap(int C) { tpr = C >> 3; rpb = tpr >= 256 ? 1 : 256 / tpr; }
+    __device__ RowMap(int C, int nt = 256) { tpr = C >> 3; rpb = tpr >= nt ? 1 : nt / tpr; }
 };
 
 // ---------------------------------------------------------------------------------------- BN + act forward
@@ -64,31 +66,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
     const int cgs = C >> 3;
     const long total = M * cgs;
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += 2 * stride) {
-        const long i2 = i + stride;
-        const bool two = i2 < total;
-        const long m0 = i / cgs, m1 = two ? i2 / cgs : 0;
-        const int g0 = (int)(i - m0 * cgs), g1 = two ? (int)(i2 - m1 * cgs) : 0;
-        float v0[8], v1[8], r0[8], r1[8];
-        load8(z + m0 * ld_z + g0 * 8, v0);
-        if (two) load8(z + m1 * ld_z + g1 * 8, v1);
-        if (res) {
-            load8(res + m0 * ld_res + g0 * 8, r0);
-            if (two) load8(res + m1 * ld_res + g1 * 8, r1);
+    constexpr int U = 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += U * stride) {
+        long mm[U];
+        int gg[U];
+        bf16x8 v[U], r[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long ik = i + k * stride;
+            const bool ok = ik < total;
+            mm[k] = ok ? ik / cgs : -1;
+            gg[k] = ok ? (int)(ik - mm[k] * cgs) : 0;
+            if (ok) {
+                v[k] = *reinterpret_cast<const bf16x8*>(z + mm[k] * ld_z + gg[k] * 8);
+                if (res) r[k] = *reinterpret_cast<const bf16x8*>(res + mm[k] * ld_res + gg[k] * 8);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float u = v0[j] * sc[g0 * 8 + j] + sh[g0 * 8 + j];
-            v0[j] = (act ? u * sigmoidf_(u) : u) + (res ? r0[j] : 0.f);
-        }
-        store8(y + m0 * ld_y + g0 * 8, v0);
-        if (two) {
+        for (int k = 0; k < U; ++k) {
+            if (mm[k] < 0) break;
+            bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float u = v1[j] * sc[g1 * 8 + j] + sh[g1 * 8 + j];
-                v1[j] = (act ? u * sigmoidf_(u) : u) + (res ? r1[j] : 0.f);
+                const float u = (float)v[k][j] * sc[gg[k] * 8 + j] + sh[gg[k] * 8 + j];
+                o[j] = (bf16)((act ? u * sigmoidf_(u) : u) + (res ? (float)r[k][j] : 0.f));
             }
-            store8(y + m1 * ld_y + g1 * 8, v1);
+            *reinterpret_cast<bf16x8*>(y + mm[k] * ld_y + gg[k] * 8) = o;
         }
     }
 }
@@ -106,21 +109,33 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     return s * (1.f + u * (1.f - s));
 }
 
-template <int UNROLL>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
-                                                                const float* save, const float* gamma,
-                                                                const float* beta, long long* dgamma, long long* dbeta,
-                                                                long M, int C, int act) {
-    __shared__ float red[2][256][8 + 1];
-    __shared__ float fin[2][2048];
-    const RowMap rm(C);
+template <int UNROLL, int NT>
+__global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                               const float* save, const float* gamma,
+                                                               const float* beta, long long* dgamma, long long* dbeta,
+                                                               long M, int C, int act) {
+    // Wide blocks (NT threads) so that one batch of UNROLL rows per thread covers the tensor with few blocks: the
+    // per-block cost is 2*C memory-side int64 atomics, and all of a thread's loads are in flight at once.
+    __shared__ float red[NT][16 + 1];
+    const RowMap rm(C, NT);
     const int tid = threadIdx.x;
-    for (int cg0 = 0; cg0 < (C >> 3); cg0 += 256) {
+    for (int cg0 = 0; cg0 < (C >> 3); cg0 += NT) {               // only loops when C > 8*NT
         const int cg = cg0 + tid % rm.tpr;
-        const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
+        const int slot = rm.tpr >= NT ? 0 : tid / rm.tpr;
         const bool active = slot < rm.rpb && cg < (C >> 3);
         float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (active) {
+            const long step = (long)gridDim.x * rm.rpb;
+            const long m_first = (long)blockIdx.x * rm.rpb + slot;
+            bf16x8 vdy[UNROLL], vz[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {                  // first batch issued before the constants are needed
+                const long mm = m_first + k * step;
+                if (mm < M) {
+                    vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
+                    vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
+                }
+            }
             float sc[8], sh[8], iv[8], mi[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -128,17 +143,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
                 const float mean = save[c], inv = save[C + c];
                 sc[j] = gamma[c] * inv; sh[j] = beta[c] - mean * sc[j]; iv[j] = inv; mi[j] = mean * inv;
             }
-            const long step = (long)gridDim.x * rm.rpb;
-            for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += UNROLL * step) {
-                bf16x8 vdy[UNROLL], vz[UNROLL];
-#pragma unroll
-                for (int k = 0; k < UNROLL; ++k) {
-                    const long mm = m + k * step;
-                    if (mm < M) {
-                        vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
-                        vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
-                    }
-                }
+            for (long m = m_first; m < M; m += UNROLL * step) {
 #pragma unroll
                 for (int k = 0; k < UNROLL; ++k) {
                     if (m + k * step >= M) break;
@@ -150,25 +155,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16* dy, 
                         sg[j] += du * (zz * iv[j] - mi[j]);
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < UNROLL; ++k) {
+                    const long mm = m + (UNROLL + k) * step;
+                    if (mm < M) {
+                        vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
+                        vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[0][tid][j] = sg[j]; red[1][tid][j] = sb[j]; }
+        for (int j = 0; j < 8; ++j) { red[tid][j] = sg[j]; red[tid][8 + j] = sb[j]; }
         __syncthreads();
-        if (active && slot == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = 0.f, b2 = 0.f;
-                for (int s = 0; s < rm.rpb; ++s) { a += red[0][s * rm.tpr + tid][j]; b2 += red[1][s * rm.tpr + tid][j]; }
-                fin[0][(cg - cg0) * 8 + j] = a;
-                fin[1][(cg - cg0) * 8 + j] = b2;
-            }
-        }
-        __syncthreads();
-        const int nch = min(2048, C - cg0 * 8);
-        for (int c = tid; c < nch; c += 256) {
-            atomicAdd((unsigned long long*)(dgamma + cg0 * 8 + c), (unsigned long long)to_fix(fin[0][c]));
-            atomicAdd((unsigned long long*)(dbeta + cg0 * 8 + c), (unsigned long long)to_fix(fin[1][c]));
+        // thread t sums value t%16 of channel group t/16 over the block's row slots and publishes it
+        const int ngrp = min(rm.tpr, (C >> 3) - cg0);
+        for (int t = tid; t < ngrp * 16; t += NT) {
+            const int g = t >> 4, v = t & 15;
+            float a = 0.f;
+            for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
+            long long* dst = (v < 8 ? dgamma : dbeta) + (cg0 + g) * 8 + (v & 7);
+            atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(a));
         }
         __syncthreads();
     }
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
             for (int k = 0; k < UNROLL; ++k) {
                 const long mm = m + k * step;
                 if (mm < M) {
-                    vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
-                    vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
+                    vdy[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8));
+                    vz[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8));
                 }
             }
 #pragma unroll
@@ -232,9 +239,9 @@ int flat_grid(long M, int C, int per_thread) {       // flat 16-byte chunks, `pe
     long blocks = (M * (C >> 3) + 256L * per_thread - 1) / (256L * per_thread);
     return (int)(blocks < 1 ? 1 : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks));
 }
-int rows_grid(long M, int C, int rows_per_thread, int max_blocks) {   // fixed channel group per thread, strided rows
+int rows_grid(long M, int C, int rows_per_thread, int max_blocks, int nt = 256) {   // fixed channel group per thread, strided rows
     int tpr = C >> 3;
-    int rpb = tpr >= 256 ? 1 : 256 / tpr;
+    int rpb = tpr >= nt ? 1 : nt / tpr;
     long blocks = (M + (long)rpb * rows_per_thread - 1) / ((long)rpb * rows_per_thread);
     return (int)(blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks));
 }
@@ -645,7 +652,9 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(M, C, 4)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
+    int fw_per = 2;
+    if (const char* e = getenv("EP24_DBG_BN_FWD")) sscanf(e, "%d", &fw_per);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
@@ -657,7 +666,10 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
                                       int act, void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<4>, dim3(rows_grid(M, C, 16, 512)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+    int red_cap = 256;                                      // one 512-thread block per CU: tools/bn_probe.py sweep
+    int red_rows = 4;
+    if (const char* e = getenv("EP24_DBG_BN_RED")) sscanf(e, "%d,%d", &red_rows, &red_cap);
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<4, 512>), dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
@@ -669,7 +681,9 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
                                      void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(rows_grid(M, C, 8, 2048)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+    int ap_rows = 16, ap_cap = 2048;
+    if (const char* e = getenv("EP24_DBG_BN_APPLY")) sscanf(e, "%d,%d", &ap_rows, &ap_cap);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
                        (bf16*)dz, ld_dz, M, C, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
@@ -774,10 +788,34 @@ extern "C" int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n
     return EP24_OK;
 }
 
+// A kernel, not hipMemsetAsync: a captured memset NODE refilled its buffer with a stale 16-byte pattern (pointer-like
+// garbage) from the second replay of the graph on (ROCm 7.2), which silently corrupted the BatchNorm statistics.
+namespace {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p, long n16, unsigned char* tail, int ntail) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(256) void zero_fill_bytes_kernel(unsigned char* p, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0;
+}
+}  // namespace
+
 extern "C" int ep24_memset_zero(void* p, int64_t bytes, void* stream) {
     EP24_REQUIRE(p && bytes >= 0, EP24_E_ARG, "memset_zero: bad arguments");
-    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
-    EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "memset_zero: %s", hipGetErrorString(e));
+    if (bytes == 0) return EP24_OK;
+    if (((uintptr_t)p & 15) == 0) {
+        const long n16 = bytes / 16;
+        long blocks = (n16 + 1023) / 1024;                 // 4 stores per thread
+        blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, S_, (uint4*)p, n16,
+                           (unsigned char*)p + n16 * 16, (int)(bytes - n16 * 16));
+    } else {
+        long blocks = (bytes + 255) / 256;
+        hipLaunchKernelGGL(zero_fill_bytes_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, S_,
+                           (unsigned char*)p, (long)bytes);
+    }
+    EP24_LAUNCH_CHECK("ep24_memset_zero");
     return EP24_OK;
 }
 

@@ -300,6 +300,7 @@ class Engine:
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
         self._bwd_units = 0
         self._side = None
+        self.use_side = True                    # weight gradients on a second stream (eager launches only)
         self._bwd_builders = []
         self.dyn = {}                            # run-time pointers (input images, incoming gradient)
         self._stats_specs, self._sum_specs = [], []
@@ -543,7 +544,7 @@ class Engine:
         ep24.train replays graphs for the forward/loss and update phases and runs backward through this path."""
         main = torch.cuda.current_stream()
         s_main = main.cuda_stream
-        lanes = not torch.cuda.is_current_stream_capturing()
+        lanes = self.use_side and not torch.cuda.is_current_stream_capturing()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         side, s_side = self._side, self._side.cuda_stream

@@ -314,6 +314,42 @@ def test_eager_api_step_matches_captured_step(graph_backward):
     assert int(mb.backbone.backbone.stem.conv.bn.num_batches_tracked) == 3
 
 
+@pytest.mark.parametrize("graph_backward", [False, True])
+def test_replayed_steps_are_reproducible(graph_backward):
+    """With lr = 0 and the stateful inputs restored, every replay of the captured step must give the same loss
+    (bitwise: the forward is deterministic) and the same gradients as the eager launch lists (fp32 atomics order
+    only).  Guards the graph nodes themselves: a captured hipMemsetAsync node once refilled the BN statistics with
+    garbage from the second replay on."""
+    from ep24 import loss as eloss, train as etrain
+    torch.manual_seed(0)
+    m = tiny_model()
+    B, S = 4, 256
+    lf = eloss.Loss_Function(80)
+    ts = etrain.TrainStep(m, lf, lr=0.0, momentum=0.9, batch=B, size=S, graph_backward=graph_backward)
+    ts.eng.images.copy_(synth.make_images(B, S, seed=3).to(DEV))
+    ts.labels.copy_(synth.make_labels(B, [3, 1, 6, 2], size=S, seed=4).to(DEV))
+    keep = [b.clone() for b in m.buffers()] + [ts.state.clone()]
+
+    def restore():
+        with torch.no_grad():
+            for b, k in zip(list(m.buffers()) + [ts.state], keep):
+                b.copy_(k)
+
+    restore()
+    ts._phase_forward()
+    ts._phase_backward(0, len(ts.eng.bwd))
+    torch.cuda.synchronize()
+    loss0, g0 = float(ts.ws.result[0]), ts.home.gflat.clone()
+    assert np.isfinite(loss0) and float(g0.abs().max()) > 0
+    for rep in range(5):
+        restore()
+        ts.step()
+        torch.cuda.synchronize()
+        assert float(ts.ws.result[0]) == loss0, (rep, float(ts.ws.result[0]), loss0)
+        err = float((ts.home.gflat - g0).abs().max() / g0.abs().max())
+        assert err < 1e-4, (rep, err)
+
+
 def test_loss_of_model_outputs_matches_oracle_assignment():
     """L2 boundary on real network outputs: feed the HIP model's own outputs to the CPU oracle loss."""
     from ep24 import loss as eloss
