@@ -99,7 +99,7 @@ def instrumented_step(ts):
                 fh.write("%-22s %-40s : %3d %8.3f\n" % (key[0], " ".join(str(v) for v in key[1:]), n, ms))
     fam = {}
     for name, fl, e0, e1 in rec:
-        kern = "wgrad_kernel" if name == "conv_wgrad_bf16" else "igemm_kernel"
+        kern = "wgrad_kernel" if name.startswith("conv_wgrad") else "igemm_kernel"
         f = fam.setdefault(kern, dict(flops=0.0, ms=0.0, launches=0))
         f["flops"] += fl
         f["ms"] += e0.elapsed_time(e1)

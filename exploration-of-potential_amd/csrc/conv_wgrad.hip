@@ -18,6 +18,7 @@ namespace {
 
 struct WgradArgs {
     const bf16* x; long ld_x; const bf16* dy; long ld_dy; float* dw; long ld_dw;
+    float* slab; long slab_stride;   // non-null: pixel split `s` stores its partial dW at slab + s*slab_stride (no atomics)
     int cout_valid, cin_valid;
     int B, H, W, OH, OW, Cin, Cout, ksize, stride, pad;
     long M;          // B*OH*OW
@@ -260,46 +261,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     for (int row = wave; row < TCO; row += 4) {
         const int co = co0 + row;
         if (co >= p.cout_valid) break;
-        float* d = p.dw + (long)co * p.ld_dw + (long)tap * p.cin_valid + ci0;
+        const long e = (long)co * p.ld_dw + (long)tap * p.cin_valid + ci0;
+        if (p.slab) {
+            float* d = p.slab + (long)by * p.slab_stride + e;
 #pragma unroll
-        for (int h = 0; h < TCI / 64; ++h) {
-            const int c = h * 64 + lane;
-            if (ci0 + c < p.cin_valid) atomicAdd(d + c, tile[row * TCI + c]);
+            for (int h = 0; h < TCI / 64; ++h) {
+                const int c = h * 64 + lane;
+                if (ci0 + c < p.cin_valid) d[c] = tile[row * TCI + c];
+            }
+        } else {
+            float* d = p.dw + e;
+#pragma unroll
+            for (int h = 0; h < TCI / 64; ++h) {
+                const int c = h * 64 + lane;
+                if (ci0 + c < p.cin_valid) atomicAdd(d + c, tile[row * TCI + c]);
+            }
         }
     }
+}
+
+// Pixel splits: fill the chip's resident-workgroup slots exactly once (LDS allows 2 / 3 / 4 workgroups per CU for
+// the 128x128 / mixed / 64x64 tiles): one slot more than a full round costs a whole extra round (576 workgroups on
+// 512 slots ran 1.9x slower than 504), fewer leave CUs idle.  A split keeps at least 8 (16 for the small tile)
+// 64-pixel steps so that its prologue and epilogue stay amortised.  tools/conv_probe.py sweeps, round-1 profiles.
+template <int TCO, int TCI>
+long wgrad_splits(const WgradArgs& a) {
+    const int tiles = ep24_cdiv(a.Cin, TCI) * ep24_cdiv(a.Cout, TCO) * a.T;
+    const bool small = TCO == 64 && TCI == 64, big = TCO == 128 && TCI == 128;
+    const long slots = 256L * (small ? 4 : (big ? 2 : 3));
+    const long min_steps = small ? 16 : 8;
+    const long steps = (a.M + 63) / 64;
+    long splits = slots / tiles;
+    if (splits > steps / min_steps) splits = steps / min_steps;
+    if (a.dbg_splits > 0) splits = a.dbg_splits;
+    if (splits < 1) splits = 1;
+    return splits;                                          // trailing splits may be empty (they contribute zeros)
 }
 
 template <int TCO, int TCI>
 void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
     const int tiles = a.tiles_ci * a.tiles_co * a.T;
-    // ~2 workgroups per CU and at least 8 K-steps (512 pixels) per split: the fp32 atomic epilogue moves
-    // splits x |dW| bytes at the ~1.3 TB/s memory-side atomic rate and was a third of the kernel at 25 splits
     long steps = (a.M + 63) / 64;
-    long splits = (512 + tiles - 1) / tiles;
-    if (splits > steps / 8) splits = steps / 8;
-    if (a.dbg_splits > 0) splits = a.dbg_splits;
-    if (splits < 1) splits = 1;
+    long splits = wgrad_splits<TCO, TCI>(a);
     a.chunk = ((steps + splits - 1) / splits) * 64;
-    splits = (a.M + a.chunk - 1) / a.chunk;
     a.tiles = tiles;
     a.xcd_remap = (splits % 8 == 0) && !getenv("EP24_DBG_WGRAD_NOREMAP");
     dim3 grid((unsigned)(tiles * splits));
     hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
 }
 
-}  // namespace
-
-extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw,
-                                    int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
-                                    int stride, void* stream) {
-    EP24_REQUIRE(x && dy && dw, EP24_E_ARG, "conv_wgrad: null pointer");
+int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw, int cout_valid,
+              int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
     EP24_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ld_x % 8 == 0 && ld_dy % 8 == 0, EP24_E_ARG,
                  "conv_wgrad: channel counts / strides must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
                  "conv_wgrad: k=%d s=%d unsupported", ksize, stride);
     EP24_REQUIRE(cout_valid <= Cout && cin_valid <= Cin, EP24_E_ARG, "conv_wgrad: valid > padded");
-    WgradArgs a{};
     a.x = (const bf16*)x; a.ld_x = ld_x; a.dy = (const bf16*)dy; a.ld_dy = ld_dy; a.dw = dw; a.ld_dw = ld_dw;
     a.cout_valid = cout_valid; a.cin_valid = cin_valid;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ksize = ksize; a.stride = stride; a.pad = (ksize - 1) / 2;
@@ -319,13 +337,101 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     { const char* e = getenv("EP24_DBG_WGRAD_SKIP_EPI"); a.dbg_skip_epilogue = e && e[0] == '1';
       const char* f = getenv("EP24_DBG_WGRAD_SPLITS"); a.dbg_splits = f ? atoi(f) : 0;
       const char* h = getenv("EP24_DBG_WGRAD_NOLOAD"); a.dbg_noload = h ? atoi(h) : 0; }
-    // 1x1 layers are tall-skinny (huge pixel count, small dW): 64x64 tiles quarter the atomic traffic per workgroup
-    bool co64 = Cout <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256), ci64 = Cin <= 64 || (ksize == 1 && Cout <= 256 && Cin <= 256);
+    return EP24_OK;
+}
+
+// tile shape: 1x1 layers are tall-skinny (huge pixel count, small dW): 64x64 tiles quarter the epilogue bytes per workgroup
+void tile_choice(const WgradArgs& a, bool& co64, bool& ci64) {
+    co64 = a.Cout <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
+    ci64 = a.Cin <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
     if (const char* g = getenv("EP24_DBG_WGRAD_TILE")) { co64 = g[0] == '6'; ci64 = g[1] == '6'; }
-    if (co64 && ci64) launch_wgrad<64, 64>(a, (hipStream_t)stream);
-    else if (co64) launch_wgrad<64, 128>(a, (hipStream_t)stream);
-    else if (ci64) launch_wgrad<128, 64>(a, (hipStream_t)stream);
-    else launch_wgrad<128, 128>(a, (hipStream_t)stream);
+}
+
+long splits_of(const WgradArgs& a) {
+    bool co64, ci64;
+    tile_choice(a, co64, ci64);
+    if (co64 && ci64) return wgrad_splits<64, 64>(a);
+    if (co64) return wgrad_splits<64, 128>(a);
+    if (ci64) return wgrad_splits<128, 64>(a);
+    return wgrad_splits<128, 128>(a);
+}
+
+void dispatch(WgradArgs& a, hipStream_t stream) {
+    bool co64, ci64;
+    tile_choice(a, co64, ci64);
+    if (co64 && ci64) launch_wgrad<64, 64>(a, stream);
+    else if (co64) launch_wgrad<64, 128>(a, stream);
+    else if (ci64) launch_wgrad<128, 64>(a, stream);
+    else launch_wgrad<128, 128>(a, stream);
+}
+
+// gflat[off + i] += sum_s slab[slab_off + s * numel + i] for a list of layers: desc rows (off, numel, splits, slab_off)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const long* desc, float* grad, const float* slab) {
+    const long* d = desc + 4 * blockIdx.y;
+    const long off = d[0], numel = d[1], splits = d[2], soff = d[3];
+    float* g = grad + off;
+    const float* sl = slab + soff;
+    if (((off | numel | soff) & 3) == 0) {
+        const long n4 = numel >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 acc = reinterpret_cast<const float4*>(sl)[i];
+            for (long s2 = 1; s2 < splits; ++s2) {
+                const float4 v = reinterpret_cast<const float4*>(sl + s2 * numel)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float4 o = reinterpret_cast<float4*>(g)[i];
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            reinterpret_cast<float4*>(g)[i] = o;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+            float acc = sl[i];
+            for (long s2 = 1; s2 < splits; ++s2) acc += sl[s2 * numel + i];
+            g[i] += acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw,
+                                    int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
+                                    int stride, void* stream) {
+    EP24_REQUIRE(x && dy && dw, EP24_E_ARG, "conv_wgrad: null pointer");
+    WgradArgs a{};
+    if (int rc = fill_args(a, x, ld_x, dy, ld_dy, dw, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
+    dispatch(a, (hipStream_t)stream);
     EP24_LAUNCH_CHECK("ep24_conv_wgrad");
+    return EP24_OK;
+}
+
+extern "C" int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    WgradArgs a{};
+    if (int rc = fill_args(a, nullptr, 8, nullptr, 8, nullptr, 0, Cout, Cin, B, H, W, Cin, Cout, ksize, stride)) return rc;
+    return (int)splits_of(a);
+}
+
+extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
+                                         int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
+                                         int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+    EP24_REQUIRE(x && dy && slab, EP24_E_ARG, "conv_wgrad_slab: null pointer");
+    WgradArgs a{};
+    if (int rc = fill_args(a, x, ld_x, dy, ld_dy, nullptr, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
+    a.slab = slab;
+    a.slab_stride = (long)cout_valid * ld_dw;
+    EP24_REQUIRE(splits_of(a) * a.slab_stride <= slab_floats, EP24_E_ARG, "conv_wgrad_slab: slab holds %ld floats, %ld needed",
+                 (long)slab_floats, splits_of(a) * a.slab_stride);
+    dispatch(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_conv_wgrad_slab");
+    return EP24_OK;
+}
+
+extern "C" int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream) {
+    EP24_REQUIRE(desc && grad && slab && n_layers > 0 && max_numel > 0, EP24_E_ARG, "wgrad_reduce: bad arguments");
+    long bx = (max_numel / 4 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
+                       grad, slab);
+    EP24_LAUNCH_CHECK("ep24_wgrad_reduce");
     return EP24_OK;
 }

@@ -18,12 +18,15 @@ backward) over pre-allocated NHWC bf16 buffers:
 The lists contain no host synchronisation, no allocation and no shape-dependent Python, so a training step
 is captured into a hipGraph (``ep24.train.TrainStep``).
 """
+import os
+
 import torch
 
 from . import _lib, nn as enn
 from ._lib import call, ptr, stream_ptr
 
 BF16 = torch.bfloat16
+WGRAD_REDUCE_GROUP = 16        # layers per weight-gradient reduce launch
 STATS_REPLICAS = 8
 STRIDES = (8, 16, 32)
 
@@ -299,8 +302,11 @@ class Engine:
         self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
         self._bwd_units = 0
+        self._slab_floats, self._pending_reduce, self._keep = 0, [], []
         self._side = None
-        self.use_side = True                    # weight gradients on a second stream (eager launches only)
+        self.use_side = True                    # weight gradients on a second stream
+        self.capture_side = os.environ.get("EP24_CAPTURE_SIDE") == "1"   # also inside captured graphs (experimental)
+        self._events = []
         self._bwd_builders = []
         self.dyn = {}                            # run-time pointers (input images, incoming gradient)
         self._stats_specs, self._sum_specs = [], []
@@ -376,11 +382,24 @@ class Engine:
         self.bnsums = torch.zeros(max(sum(self._sum_specs), 4), dtype=torch.int64, device=self.dev)
         for b in reversed(self._bwd_builders):
             b()
+        self._flush_reduce()
+        self.slab = torch.zeros(max(self._slab_floats, 4), dtype=torch.float32, device=self.dev)
         fw, bw = [], []
         for lst, out in ((self.fwd, fw), (self.bwd, bw)):
             for name, args in lst:
                 out.append((name, tuple(a() if callable(a) else a for a in args)))   # Dyn stays for run time
         self.fwd, self.bwd = fw, bw
+
+    def _flush_reduce(self):
+        """One reduce launch (side stream, behind the weight-gradient kernels it sums) for the pending layers."""
+        if not self._pending_reduce:
+            return
+        rows = [[seg.off, seg.numel, splits, soff] for seg, splits, soff in self._pending_reduce]
+        desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        self._keep.append(desc)
+        self._b("side:wgrad_reduce", (ptr(desc), len(rows), max(r[1] for r in rows), ptr(self.home.gflat),
+                                     (lambda: self.slab.data_ptr())), writes=tuple(seg for seg, _, _ in self._pending_reduce))
+        self._pending_reduce = []
 
     def _stats_slot(self, C):
         off = sum(self._stats_specs)
@@ -442,9 +461,18 @@ class Engine:
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             self._b("@side_wait_main", ())
-            self._b("side:conv_wgrad_bf16", (x.ptr(), x.ld, dz, cout, ptr(gflat, seg.off), seg.taps * seg.cin, cout,
-                                             seg.cin, B, H, W, cin, cout, k_, s), writes=(seg,))
+            # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
+            # few layers folds them into the flat gradient in a fixed order (no atomics: bitwise reproducible)
+            splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k_, s)
+            assert splits >= 1, splits
+            soff = self._slab_floats
+            self._slab_floats += splits * seg.numel
+            self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, cout, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
+                                                  splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k_, s))
             self._b("@side_record", (k,))
+            self._pending_reduce.append((seg, splits, soff))
+            if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
+                self._flush_reduce()
             if x.needs_grad:
                 acc = x.gwrite()
                 self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
@@ -544,7 +572,9 @@ class Engine:
         ep24.train replays graphs for the forward/loss and update phases and runs backward through this path."""
         main = torch.cuda.current_stream()
         s_main = main.cuda_stream
-        lanes = self.use_side and not torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_current_stream_capturing()
+        lanes = self.use_side and (not capturing or self.capture_side)
+        keep = self._events if capturing else []      # events that are edges of a graph under capture must outlive it
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         side, s_side = self._side, self._side.cuda_stream
@@ -556,11 +586,13 @@ class Engine:
                     continue
                 if name == "@side_wait_main":
                     ev = torch.cuda.Event()
+                    keep.append(ev)
                     ev.record(main)
                     side.wait_event(ev)
                     used_side = True
                 elif name == "@side_record":
                     ev = torch.cuda.Event()
+                    keep.append(ev)
                     ev.record(side)
                     events[args[0]] = ev
                 elif name == "@main_wait_side":
@@ -573,6 +605,7 @@ class Engine:
                 name = name[5:]
                 if lanes:
                     s = s_side
+                    used_side = True
             rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
             if rc != 0:
                 raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))

@@ -63,6 +63,18 @@ int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld
                          int cout_valid, int cin_valid,
                          int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
+/* The same weight gradient without atomics (bitwise reproducible): pixel split s of the launch stores its partial
+ * dW (layout of dw above, cout_valid * ld_dw floats) at slab + s * cout_valid * ld_dw with plain stores; every
+ * element of every split is written.  ep24_conv_wgrad_splits returns the number of splits that launch uses (>= 1, a
+ * pure function of the shape), so the caller can size the slab; ep24_wgrad_reduce then does, for n_layers rows
+ * desc[i] = (grad offset, numel, splits, slab offset) (all in floats), grad[off + j] += sum_s slab[soff + s*numel + j]
+ * in a fixed order.  Together they replace autograd's conv weight gradient for the training engine. */
+int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
+                              int64_t ld_dw, int cout_valid, int cin_valid,
+                              int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream);
+
 /* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad
  * [Cin][T][Cout_pad] (either may be null).  Only real elements are written; the caller zero-initialises the
  * padded buffers once. */

@@ -78,6 +78,26 @@ def test_conv_fwd_dgrad_wgrad(B, H, Cin, Cout, k, s):
     call("conv_wgrad_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(dw), k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, sp())
     close(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * wr.grad, rel=5e-3)      # += semantics
 
+    # the atomic-free form: per-split slabs + ordered reduce; bitwise reproducible, same += semantics
+    from ep24 import _lib
+    splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, Cin, Cout, k, s)
+    assert splits >= 1
+    numel = Cout * k * k * Cin
+    pad = 24                                                             # odd offsets: the reducer's scalar path
+    slab = torch.full((pad + splits * numel,), float("nan"), device=DEV)  # every element must be overwritten
+    grads = []
+    for rep in range(2):
+        g = torch.zeros(8 + numel, device=DEV)
+        desc = torch.tensor([[8, numel, splits, pad]], dtype=torch.int64, device=DEV)
+        call("conv_wgrad_slab_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(slab, pad), splits * numel, k * k * Cin, Cout, Cin,
+             B, H, W, Cin, Cout, k, s, sp())
+        call("wgrad_reduce", ptr(desc), 1, numel, ptr(g), ptr(slab), sp())
+        call("wgrad_reduce", ptr(desc), 1, numel, ptr(g), ptr(slab), sp())
+        grads.append(g.clone())
+    assert float(grads[0][:8].abs().max()) == 0.0
+    close(grads[0][8:].view(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * wr.grad, rel=5e-3)
+    assert torch.equal(grads[0], grads[1])
+
 
 def test_conv_slices_fp32_out_bias_and_row_mapping():
     """1x1 predictor form: input is a channel slice of a wider buffer, output fp32 + bias into rows n*A + a0 + hw."""

@@ -20,11 +20,14 @@ def main():
     dx = torch.zeros(B * H * W, Cin, device=dev, dtype=torch.bfloat16)
     dw = torch.zeros(Cout, k * k, Cin, device=dev)
     stats = torch.zeros(8, 2, Cout, dtype=torch.int64, device=dev)
+    slab = torch.zeros(128 * dw.numel(), device=dev) if (kind == "wgrad" and os.environ.get("EP24_PROBE_SLAB")) else None
     def run():
         if kind == "fwd":
             call("conv_fwd_bf16", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, k, s, stream_ptr())
         elif kind == "dgrad":
             call("conv_dgrad_bf16", ptr(dy), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, k, s, stream_ptr())
+        elif os.environ.get("EP24_PROBE_SLAB"):
+            call("conv_wgrad_slab_bf16", ptr(x), Cin, ptr(dy), Cout, ptr(slab), slab.numel(), k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, stream_ptr())
         else:
             call("conv_wgrad_bf16", ptr(x), Cin, ptr(dy), Cout, ptr(dw), k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, stream_ptr())
     for _ in range(3):
