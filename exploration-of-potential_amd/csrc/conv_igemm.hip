@@ -674,6 +674,179 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     igemm_epilogue<BN, OUT_F32, MT>(p, acc, m0, n0, tile_m, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Streaming kernel for 1x1 stride-1 layers with K <= 256 (forward and input-gradient).  These layers are HBM
+// bound (K/2 .. K FLOP per byte), and as 2-4 K-step tiles of the tiled kernels every workgroup spent its life in
+// prologue / DMA round trip / epilogue.  Here the weight tile [BN][K] is loaded into LDS ONCE per workgroup and
+// every wave streams its own 64-row blocks of the activation matrix straight from global memory into MFMA
+// A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
+// block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
+// registers until the end.  Waves of a workgroup share the rows (WN waves, 64 columns each) through L1.
+template <int BN, int H>
+__global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
+    constexpr int WN = BN / 64, WM = 4 / WN, MT = 2, RG = WM * MT * 16;   // 32-row blocks per wave: ~170 VGPRs, 3 waves per SIMD
+    constexpr int OOB = 0x7FFFFFF0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n_tiles = (p.N + BN - 1) / BN;
+    // workgroup L runs on XCD L & 7: the n_tiles workgroups that walk the same rows get the same XCD (shared L2)
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int nt = rest % n_tiles, rb = (rest / n_tiles) * 8 + xcd;
+    const int n0 = nt * BN;
+    const int npan = (p.K + 63) >> 6;
+    const int nks = (p.K + 31) >> 5;
+
+    for (int u = tid; u < BN * npan * 8; u += 256) {
+        const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+        const int l = L & 63;
+        const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
+        const int k = pan * 64 + chunk * 8;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ch < p.N && k < p.K) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)ch * p.WT * p.K + k);
+        *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
+    }
+    __syncthreads();
+
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const long n_groups = (p.M + RG - 1) / RG;
+    const long my_groups = rb < n_groups ? (n_groups - rb + bpn - 1) / bpn : 0;
+    const long units = my_groups * H;                                      // (row group, K half) pairs
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto load = [&](bf16x8 (&A)[MT][4], long u) {
+        const long g = rb + (u / H) * bpn;
+        const int h = (int)(u % H);
+        const long r0 = g * RG + wm * (MT * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const long row = r0 + i * 16 + frow;
+            const int base = row < p.M ? (int)((row * p.ld_src + fq * 8 + h * 128) * 2) : OOB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int vo = (h * 128 + ks * 32 + fq * 8 < p.K) ? base + ks * 64 : OOB;
+                if (h * 4 + ks < nks) {
+                    v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+                    A[i][ks] = __builtin_bit_cast(bf16x8, t);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][4];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = n0 + wn * 64 + 4 * frow;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](bf16x8 (&A)[MT][4], long u) {
+        const int h = (int)(u % H);
+        if (h == 0) zero_acc();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = h * 4 + ks;
+            if (kk < nks) {
+                bf16x8 fb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    fb[q] = *reinterpret_cast<const bf16x8*>(smem + (kk >> 1) * (BN * 128) + swz(wn * 64 + q * 16 + frow, (kk & 1) * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], fb[q], acc[i][q], 0, 0, 0);
+            }
+        }
+        if (h != H - 1) return;
+        const long g = rb + (u / H) * bpn;
+        const long r0 = g * RG + wm * (MT * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = r0 + i * 16 + 4 * fq + r;
+                if (m >= p.M) continue;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = acc[i][q][r];
+                    s1[q] += v[q];
+                    s2[q] += v[q] * v[q];
+                }
+                bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
+                if (c0 + 3 < p.N) {
+                    if (p.accumulate) {
+                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                    }
+                    bf16x4 w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                    *reinterpret_cast<bf16x4*>(d) = w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                }
+            }
+        }
+    };
+
+    bf16x8 A0[MT][4], A1[MT][4];
+    if (units > 0) load(A0, 0);
+    for (long u = 0; u < units; u += 2) {
+        if (u + 1 < units) load(A1, u + 1);
+        compute(A0, u);
+        if (u + 2 < units) load(A0, u + 2);
+        if (u + 1 < units) compute(A1, u + 1);
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]; the weight tile is no longer needed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (fq == 0) {
+                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
+                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+            }
+        }
+        __syncthreads();
+        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            const int wcol = c >> 6;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+        }
+    }
+}
+
+template <int BN, int H>
+void launch_stream(const IgemmArgs& a, hipStream_t stream) {
+    constexpr int RG = (4 / (BN / 64)) * 32;
+    const int n_tiles = ep24_cdiv(a.N, BN);
+    const long n_groups = (a.M + RG - 1) / RG;
+    // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
+    long bpn = (512 / n_tiles + 7) / 8 * 8;
+    if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
+    if (const char* e = getenv("EP24_DBG_STREAM_BPN")) bpn = atoi(e);
+    const int npan = (a.K + 63) / 64;
+    size_t lds = (size_t)npan * BN * 128;
+    if (lds < 2048) lds = 2048;
+    hipLaunchKernelGGL((igemm_stream_kernel<BN, H>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+}
+
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
     if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
@@ -691,6 +864,15 @@ void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hip
 }
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
+    a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
+    const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
+    if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
+        !a.bias && plain_dst && a.ld_dst % 4 == 0 && !getenv("EP24_NO_STREAM")) {
+        if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
+        else          { if (a.K > 128) launch_stream<64, 2>(a, stream); else launch_stream<64, 1>(a, stream); }
+        EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
+        return EP24_OK;
+    }
     const bool wide = a.N > 64;
     const int gy = ep24_cdiv(a.N, wide ? 128 : 64);
     const int tiles_m = ep24_cdiv(a.M, BM);

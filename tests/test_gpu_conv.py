@@ -33,6 +33,8 @@ def close(got, want, rel=1.2e-2):
 CONV_CASES = [  # B, H, Cin, Cout, k, s
     (2, 20, 64, 64, 3, 1), (3, 16, 128, 128, 3, 1), (2, 16, 64, 128, 3, 2), (2, 10, 256, 256, 1, 1),
     (2, 12, 16, 24, 3, 1), (1, 24, 8, 16, 3, 2), (5, 9, 72, 200, 3, 1), (2, 8, 512, 64, 1, 1),
+    # 1x1, K <= 256: the streaming kernel (row / channel / K tails, several row groups per workgroup)
+    (3, 13, 128, 48, 1, 1), (2, 24, 112, 64, 1, 1), (1, 33, 24, 200, 1, 1), (4, 40, 64, 64, 1, 1), (20, 40, 256, 128, 1, 1),
 ]
 
 
