@@ -374,10 +374,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const long* desc, flo
     if (((off | numel | soff) & 3) == 0) {
         const long n4 = numel >> 2;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-            float4 acc = reinterpret_cast<const float4*>(sl)[i];
-            for (long s2 = 1; s2 < splits; ++s2) {
-                const float4 v = reinterpret_cast<const float4*>(sl + s2 * numel)[i];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            float4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (long s2 = 0; s2 < splits; s2 += 8) {              // 8 loads in flight, summed in split order
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (s2 + k < splits) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sl + (s2 + k) * numel) + i);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (s2 + k < splits) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
             }
             float4 o = reinterpret_cast<float4*>(g)[i];
             o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;

@@ -72,7 +72,15 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
         const int col = t & 31, g = t >> 5;
         const int per = (nblocks + 7) / 8;
         float s = 0.f;
-        for (int i = g * per; i < min(nblocks, (g + 1) * per); ++i) s += partials[(long)i * NS + col];
+        const int lo = g * per, hi = min(nblocks, (g + 1) * per);
+        for (int i = lo; i < hi; i += 16) {                  // 16 loads in flight, added in row order
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = i + k < hi ? partials[(long)(i + k) * NS + col] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i + k < hi) s += v[k];
+        }
         grp[g][col] = s;
     }
     __syncthreads();

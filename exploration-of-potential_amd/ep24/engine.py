@@ -501,7 +501,9 @@ class Engine:
         t = self.unit(mod.conv1, x, out=cat.slice(0, h))
         y5, y9, y13 = cat.slice(h, h), cat.slice(2 * h, h), cat.slice(3 * h, h)
         idx = torch.zeros(3 * t.M * h, dtype=torch.uint8, device=self.dev)
-        self._f("spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h)
+        scratch = torch.zeros(9 * t.M * h, dtype=torch.uint8, device=self.dev)
+        self._keep.append(scratch)
+        self._f("spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h, ptr(scratch))
 
         def build_bwd():
             assert y5.gready() and y9.gready() and y13.gready()

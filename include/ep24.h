@@ -119,9 +119,10 @@ int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int S, vo
 
 /* SPP max pools k = 5, 9, 13, stride 1, pad k/2 over x[B,H,W,C] (network_blocks.py:131-143).  Writes the
  * three pooled maps into y5/y9/y13 (row stride ld_y) and the winning window offset (dy*16+dx biased by 8)
- * into idx [3][B*H*W][C] uint8 for the backward (first maximum in row-major window order, as ATen). */
+ * into idx [3][B*H*W][C] uint8 for the backward (first maximum in row-major window order, as ATen).
+ * scratch: 9*B*H*W*C bytes for the separable two-pass form (row maxima + their column offsets); null = one pass. */
 int ep24_spp_fwd(const void* x, int64_t ld_x, void* y5, void* y9, void* y13, int64_t ld_y, uint8_t* idx,
-                 int B, int H, int W, int C, void* stream);
+                 int B, int H, int W, int C, void* scratch, void* stream);
 /* dx (+)= routed gradients of the three pools. */
 int ep24_spp_bwd(const void* dy5, const void* dy9, const void* dy13, int64_t ld_dy, const uint8_t* idx,
                  void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C, void* stream);

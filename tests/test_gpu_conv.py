@@ -186,7 +186,14 @@ def test_spp_fwd_bwd():
     cat = torch.zeros(B * H * W, 4 * C, dtype=BF, device=DEV)
     cat[:, :C] = nhwc(x).reshape(-1, C).to(DEV)
     idx = torch.zeros(3 * B * H * W * C, dtype=torch.uint8, device=DEV)
-    call("spp_fwd", ptr(cat), 4 * C, ptr(cat, C), ptr(cat, 2 * C), ptr(cat, 3 * C), 4 * C, ptr(idx), B, H, W, C, sp())
+    call("spp_fwd", ptr(cat), 4 * C, ptr(cat, C), ptr(cat, 2 * C), ptr(cat, 3 * C), 4 * C, ptr(idx), B, H, W, C, None, sp())
+    # the separable two-pass form must give the same maps and the same winner codes
+    cat2 = cat.clone()
+    cat2[:, C:] = 0
+    idx2 = torch.zeros_like(idx)
+    scratch = torch.zeros(9 * B * H * W * C, dtype=torch.uint8, device=DEV)
+    call("spp_fwd", ptr(cat2), 4 * C, ptr(cat2, C), ptr(cat2, 2 * C), ptr(cat2, 3 * C), 4 * C, ptr(idx2), B, H, W, C, ptr(scratch), sp())
+    assert torch.equal(cat2, cat) and torch.equal(idx2, idx)
     for i, p in enumerate(pools):
         got = cat[:, (i + 1) * C:(i + 2) * C].reshape(B, H, W, C).permute(0, 3, 1, 2)
         assert torch.equal(got.float().cpu(), p.detach())
