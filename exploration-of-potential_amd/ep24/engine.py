@@ -306,6 +306,9 @@ class Engine:
         self._side = None
         self.use_side = True                    # weight gradients on a second stream
         self.capture_side = os.environ.get("EP24_CAPTURE_SIDE") == "1"   # also inside captured graphs (experimental)
+        # one-launch BN backward (grid barrier, rows kept in registers): measured 15-25 % SLOWER than the two kernels at
+        # YOLOX-l / B=20 (the barrier's serial latency chain outweighs the saved re-read), so it stays an experiment switch
+        self.fuse_bn_bwd = os.environ.get("EP24_FUSED_BN") == "1"
         self._events = []
         self._bwd_builders = []
         self.dyn = {}                            # run-time pointers (input images, incoming gradient)
@@ -408,8 +411,9 @@ class Engine:
 
     def _sums_slot(self, C):
         off = sum(self._sum_specs)
-        self._sum_specs.append(2 * C)
-        return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
+        self._sum_specs.append(2 * C + 2)             # + the arrival counter of the fused backward's grid barrier
+        return ((lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C)),
+                (lambda: self.bnsums.data_ptr() + 8 * (off + 2 * C)))
 
     # ---- ops ---------------------------------------------------------------------------------------
     def unit(self, mod, x, out=None, residual=None, stem=False):
@@ -433,7 +437,7 @@ class Engine:
         self.max_dz = max(self.max_dz, M * cout)
         save = torch.zeros(2 * cout, dtype=torch.float32, device=self.dev)
         stats = self._stats_slot(cout)
-        sum_g, sum_b = self._sums_slot(cout)
+        sum_g, sum_b, bar_cnt = self._sums_slot(cout)
         bn = mod.bn
         flat, gflat = home.flat, home.gflat
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
@@ -453,11 +457,17 @@ class Engine:
             dz = (lambda k=k: self.dz2[k & 1].data_ptr())
             # dz[k&1] was last read by the side-stream weight gradient of unit k-2
             self._b("@main_wait_side", (k - 2,))
-            self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, 1))
-            self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                         ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                         dz, cout, M, cout, 1), writes=(gam, bet))
+            if self.fuse_bn_bwd and _lib.lib().fn["ep24_bn_act_bwd_fused_rows"](M, cout) > 0:
+                # both passes in one launch: dy and z are read once and stay in registers across a grid barrier
+                self._b("bn_act_bwd_fused", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
+                                             sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, 1,
+                                             bar_cnt), writes=(gam, bet))
+            else:
+                self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, 1))
+                self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                             ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
+                                             dz, cout, M, cout, 1), writes=(gam, bet))
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             self._b("@side_wait_main", ())

@@ -110,6 +110,17 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           void* stream);
 
+/* Both passes in one launch (dy and z read once, kept in registers across a grid-wide barrier) for the shapes whose
+ * slices fit: ep24_bn_act_bwd_fused_rows(M, C) > 0.  counter: one zeroed uint32 per call (the barrier's arrival
+ * count); dgamma/dbeta zeroed by the caller as for pass 1.  ep24_debug_sync_timeouts() returns how many barrier waits
+ * gave up since the library was loaded (0 in a healthy run; the wait is bounded so that nothing can hang). */
+int ep24_bn_act_bwd_fused_rows(int64_t M, int C);
+int ep24_bn_act_bwd_fused(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                          const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta,
+                          float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                          uint32_t* counter, void* stream);
+int ep24_debug_sync_timeouts(void);
+
 /* ------------------------------------------------------------------------------------------------
  * a1/a2  glue ops of the graph
  * ------------------------------------------------------------------------------------------------ */

@@ -131,7 +131,8 @@ def test_wgrad_padded_valid_region():
     close(dw, dy.float()[:, :Cv].t() @ x.float().cpu(), rel=5e-3)
 
 
-@pytest.mark.parametrize("M,C,res", [(400, 64, False), (1000, 24, True), (130, 512, True), (33, 8, False)])
+@pytest.mark.parametrize("M,C,res", [(400, 64, False), (1000, 24, True), (130, 512, True), (33, 8, False), (32000, 256, False),
+                                     (128000, 128, True)])
 def test_bn_silu_fwd_bwd(M, C, res):
     call, ptr, sp = _abi()
     z = rnd(M, C, seed=31, scale=2.0)
@@ -172,6 +173,22 @@ def test_bn_silu_fwd_bwd(M, C, res):
     close(dz, zr.grad, rel=2e-2)
     close(ggrad - 1, g_.grad, rel=5e-3)
     close(bgrad - 1, b_.grad, rel=5e-3)
+    # the one-launch form (grid barrier between the two passes) must agree with the two kernels
+    from ep24 import _lib
+    fn = _lib.lib().fn
+    assert fn["ep24_bn_act_bwd_fused_rows"](M, C) > 0
+    before = fn["ep24_debug_sync_timeouts"]()
+    sums2 = torch.zeros(2 * C + 2, dtype=torch.int64, device=DEV)
+    gg2, bg2 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    dz2 = torch.zeros(M, C, dtype=BF, device=DEV)
+    call("bn_act_bwd_fused", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums2), ptr(sums2, C), ptr(gg2), ptr(bg2),
+         ptr(dz2), C, M, C, 1, ptr(sums2, 2 * C), sp())
+    torch.cuda.synchronize()
+    assert fn["ep24_debug_sync_timeouts"]() == before
+    close(dz2, dz.float().cpu(), rel=1e-2)
+    close(gg2, ggrad.cpu(), rel=1e-5)
+    close(bg2, bgrad.cpu(), rel=1e-5)
+    assert int(sums2[2 * C]) == min(256, -(-M // (512 // (C // 8))))        # every workgroup arrived exactly once
 
 
 def test_spp_fwd_bwd():
