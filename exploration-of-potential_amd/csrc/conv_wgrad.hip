@@ -83,14 +83,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // 1-D grid; workgroup L runs on XCD L % 8.  With a split count that is a multiple of 8, XCD k takes the pixel
-    // splits k, k+8, ... and all tiles of a split run on ONE XCD, so a split's dY / X rows cross the fabric once
-    // instead of once per XCD (each is re-read by 9 taps x the other operand's tile count).
+    // 1-D grid; workgroup L runs on XCD L % 8.  Every XCD takes one contiguous run of the (split, tile) sequence
+    // (split-major), so the tiles of a pixel split - which all re-read that split's dY / X rows, 9 taps x the other
+    // operand's tile count - run on one XCD (two at a run boundary) and the rows cross the fabric once or twice
+    // instead of once per XCD: FETCH_SIZE showed 6x the algorithmic bytes with the splits dealt round-robin.
     int bx, by;
     if (p.xcd_remap) {
-        const int L = blockIdx.x, k = L & 7, slot = L >> 3;
-        bx = slot % p.tiles;
-        by = (slot / p.tiles) * 8 + k;
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+        const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+        bx = v % p.tiles;
+        by = v / p.tiles;
     } else {
         bx = blockIdx.x % p.tiles;
         by = blockIdx.x / p.tiles;
@@ -306,7 +308,7 @@ void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     long splits = wgrad_splits<TCO, TCI>(a);
     a.chunk = ((steps + splits - 1) / splits) * 64;
     a.tiles = tiles;
-    a.xcd_remap = (splits % 8 == 0) && !getenv("EP24_DBG_WGRAD_NOREMAP");
+    a.xcd_remap = !getenv("EP24_DBG_WGRAD_NOREMAP");
     dim3 grid((unsigned)(tiles * splits));
     hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
 }
