@@ -35,6 +35,29 @@ def conv_flops(args):
     return 2.0 * B * OH * OW * Cin * Cout * k * k
 
 
+def conv_bytes(args):
+    """Algorithmic HBM bytes of one conv launch: every operand element once (bf16 activations / packed weights)."""
+    B, H, W, Cin, Cout, k, s = args[-7:]
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    return 2.0 * (B * H * W * Cin + B * OH * OW * Cout + Cout * k * k * Cin)
+
+
+def pmc_traffic(prefix):
+    """Average HBM-side bytes per launch of the kernels whose name starts with `prefix`, from the committed PMC passes
+    (profiles/*_pmc_traffic.json: rocprofv3 FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied there)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    n = b = 0
+    for name, v in d["kernels"].items():
+        if name.startswith(prefix):
+            n += v["launches"]
+            b += v["traffic_bytes"] * v["launches"]
+    return (round(b / n) if n else None), os.path.basename(files[-1])
+
+
 def instrumented_step(ts):
     """Eager pass over the same launch lists with an event pair round every conv launch."""
     from ep24 import _lib, loss as eloss
@@ -66,7 +89,7 @@ def instrumented_step(ts):
             assert rc == 0, (name, _lib.lib().last_error())
             if timed:
                 e1.record()
-                rec.append((name, conv_flops(args), e0, e1))
+                rec.append((name, conv_flops(args), e0, e1, conv_bytes(args)))
 
     ts.home.zero_grad()
     eng.zero_step_buffers()
@@ -79,7 +102,7 @@ def instrumented_step(ts):
     torch.cuda.synchronize()
     if os.environ.get("EP24_LAYER_TABLE"):
         rows = {}
-        for (name, fl, e0, e1), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]):
+        for (name, fl, e0, e1, _by), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]):
             key = (name,) + tuple(args[-7:])
             r = rows.setdefault(key, [0, 0.0, 0.0])
             r[0] += 1
@@ -98,10 +121,11 @@ def instrumented_step(ts):
             for key, (n, ms) in sorted(other.items(), key=lambda kv: -kv[1][1]):
                 fh.write("%-22s %-40s : %3d %8.3f\n" % (key[0], " ".join(str(v) for v in key[1:]), n, ms))
     fam = {}
-    for name, fl, e0, e1 in rec:
+    for name, fl, e0, e1, by in rec:
         kern = "wgrad_kernel" if name.startswith("conv_wgrad") else "igemm_kernel"
-        f = fam.setdefault(kern, dict(flops=0.0, ms=0.0, launches=0))
+        f = fam.setdefault(kern, dict(flops=0.0, ms=0.0, launches=0, bytes=0.0))
         f["flops"] += fl
+        f["bytes"] += by
         f["ms"] += e0.elapsed_time(e1)
         f["launches"] += 1
     return fam
@@ -203,6 +227,7 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic("igemm" if dom == "igemm_kernel" else "wgrad_kernel")
         out = {
             "metric": "training images/sec, YOLOX-l 24p 640x640 bf16", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -213,7 +238,10 @@ def main():
             "loss": round(loss, 4),
             "step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE * (a.size / 640.0) ** 2 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,
+                         "algorithmic_bytes_per_launch": round(f["bytes"] / f["launches"]),
+                         "algorithmic_gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
                          "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
                          "families": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"], 3),
                                           "launches": v["launches"]} for k, v in fam.items()}},

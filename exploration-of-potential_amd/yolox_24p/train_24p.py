@@ -65,7 +65,7 @@ class Trainer:
         if not args.no_graph:
             step_fn = TrainStep(model, self.loss_func, lr=args.learn_rate, momentum=exp.momentum, batch=args.batch_size,
                                 size=self.input_size[0], reducer=reducer)
-        print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "hipGraph step" if step_fn else "eager API"))
+        print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "captured step" if step_fn else "eager API"))
         done = False
         for epoch in range(self.max_epoch):
             self.epoch = epoch
