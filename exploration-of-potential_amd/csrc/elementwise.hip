@@ -566,25 +566,20 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const bf16* dy5, const bf1
                 const long op = (long)(n * H + oy) * W + ox;
                 const uint8_t code = (uint8_t)(((dy + 8) << 4) | (dxo + 8));
                 const uint8_t* ip = idx + op * C + cg * 8;
-                float g13[8];
-                load8(dy13 + op * ld_dy + cg * 8, g13);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (ip[2 * plane + j] == code) acc[j] += g13[j];
-                if (dy >= -4 && dy <= 4 && dxo >= -4 && dxo <= 4) {
-                    float g9[8];
-                    load8(dy9 + op * ld_dy + cg * 8, g9);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (ip[plane + j] == code) acc[j] += g9[j];
-                }
-                if (dy >= -2 && dy <= 2 && dxo >= -2 && dxo <= 2) {
-                    float g5[8];
-                    load8(dy5 + op * ld_dy + cg * 8, g5);
+                // the 8 winner codes of a window arrive as one 8-byte load; a matching byte XORs to zero
+                const unsigned rep = code * 0x01010101u;
+                auto gather = [&](const bf16* g, const uint8_t* codes) {
+                    uint2 c = *reinterpret_cast<const uint2*>(codes);
+                    c.x ^= rep; c.y ^= rep;
+                    float v[8];
+                    load8(g + op * ld_dy + cg * 8, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (ip[j] == code) acc[j] += g5[j];
-                }
+                        if ((((j < 4 ? c.x : c.y) >> (8 * (j & 3))) & 0xFFu) == 0u) acc[j] += v[j];
+                };
+                gather(dy13, ip + 2 * plane);
+                if (dy >= -4 && dy <= 4 && dxo >= -4 && dxo <= 4) gather(dy9, ip + plane);
+                if (dy >= -2 && dy <= 2 && dxo >= -2 && dxo <= 2) gather(dy5, ip);
             }
         }
         bf16* d = dx + pix * ld_dx + cg * 8;
@@ -775,13 +770,11 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, co
             if (i >= total) break;
             while (i >= prefix[seg + 1]) ++seg;
             const long* d = desc + (long)seg * 8;
-            const long e = i - prefix[seg];
-            const int T = (int)d[4], Cin = (int)d[5];
-            const int ci = (int)(e % Cin);
-            const long r = e / Cin;
-            const int t = (int)(r % T);
-            const int co = (int)(r / T);
-            wf[d[1] + ((long)co * T + t) * d[6] + ci] = (bf16)flat[d[0] + e];
+            const int e = (int)(i - prefix[seg]);                    // a segment has < 2^31 elements
+            const int Cin = (int)d[5], Cin_pad = (int)d[6];
+            long o = e;                                             // Cin == Cin_pad: the forward copy is a pure conversion
+            if (Cin != Cin_pad) o = (long)(e / Cin) * Cin_pad + e % Cin;
+            wf[d[1] + o] = (bf16)flat[d[0] + e];
         }
         __syncthreads();
     }
