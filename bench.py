@@ -121,8 +121,21 @@ def instrumented_step(ts):
             for key, (n, ms) in sorted(other.items(), key=lambda kv: -kv[1][1]):
                 fh.write("%-22s %-40s : %3d %8.3f\n" % (key[0], " ".join(str(v) for v in key[1:]), n, ms))
     fam = {}
-    for name, fl, e0, e1, by in rec:
-        kern = "wgrad_kernel" if name.startswith("conv_wgrad") else "igemm_kernel"
+    def kernel_of(name, args):
+        """Which device kernel a conv launch runs (mirrors the dispatch in csrc/conv_igemm.hip: launch())."""
+        if name.startswith("conv_wgrad"):
+            return "wgrad_kernel"
+        B, H, W, Cin, Cout, k, s = args[-7:]
+        K = Cin if name == "conv_fwd_bf16" else Cout          # dgrad reduces over the (padded) output channels
+        f32_out = name == "conv_fwd_bf16" and args[5] != 0
+        M = B * H * W
+        if k == 1 and s == 1 and not f32_out and (K <= 128 or (K <= 256 and M >= 100000)):
+            return "igemm_stream_kernel"
+        return "igemm_dma_kernel"
+
+    convs = [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]
+    for (name, fl, e0, e1, by), (_, args) in zip(rec, convs):
+        kern = kernel_of(name, args)
         f = fam.setdefault(kern, dict(flops=0.0, ms=0.0, launches=0, bytes=0.0))
         f["flops"] += fl
         f["bytes"] += by
@@ -227,7 +240,7 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic("igemm" if dom == "igemm_kernel" else "wgrad_kernel")
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "training images/sec, YOLOX-l 24p 640x640 bf16", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),

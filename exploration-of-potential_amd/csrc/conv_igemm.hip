@@ -873,7 +873,9 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
         EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
         return EP24_OK;
     }
-    const bool wide = a.N > 64;
+    // 128-wide N tiles unless that leaves at most one workgroup per CU (the 20x20 level at B = 20): 64-wide tiles then
+    // double the workgroups (+3 .. +27 % on those layers)
+    const bool wide = a.N > 64 && (long)ep24_cdiv(a.M, BM) * ep24_cdiv(a.N, 128) > 256;
     const int gy = ep24_cdiv(a.N, wide ? 128 : 64);
     const int tiles_m = ep24_cdiv(a.M, BM);
     // The register-staged persistent kernel (workgroups walking several M tiles) is kept as an experiment switch
