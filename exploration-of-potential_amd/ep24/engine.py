@@ -302,6 +302,7 @@ class Engine:
         self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
         self._bwd_units = 0
+        self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
         self._side = None
         self.use_side = True                    # weight gradients on a second stream
@@ -379,14 +380,15 @@ class Engine:
     def _finalize(self):
         """Allocate the shared scratch, then build the backward list in reverse op order and resolve pointers."""
         # scratch shared by all layers (single stream => no overlap in time)
-        # two dz scratch buffers: the weight gradient of layer L (side stream) may still read one while layer L-1 fills the other
-        self.dz2 = [torch.zeros(max(self.max_dz, 8), dtype=BF16, device=self.dev) for _ in range(2)]
         self.stats = torch.zeros(max(sum(self._stats_specs), 4), dtype=torch.int64, device=self.dev)
         self.bnsums = torch.zeros(max(sum(self._sum_specs), 4), dtype=torch.int64, device=self.dev)
         for b in reversed(self._bwd_builders):
             b()
         self._flush_reduce()
         self.slab = torch.zeros(max(self._slab_floats, 4), dtype=torch.float32, device=self.dev)
+        # every layer keeps its own dz (the gradient w.r.t. the raw conv output): the weight-gradient lane may lag the
+        # main lane by a whole segment without a write-after-read hazard (3.4 GB at -l / B=20; there are 288)
+        self.dzbuf = torch.zeros(max(self._dz_elems, 8), dtype=BF16, device=self.dev)
         fw, bw = [], []
         for lst, out in ((self.fwd, fw), (self.bwd, bw)):
             for name, args in lst:
@@ -454,9 +456,9 @@ class Engine:
             assert out.gready(), "activation without a gradient producer"
             k = self._bwd_units                       # position in backward execution order
             self._bwd_units += 1
-            dz = (lambda k=k: self.dz2[k & 1].data_ptr())
-            # dz[k&1] was last read by the side-stream weight gradient of unit k-2
-            self._b("@main_wait_side", (k - 2,))
+            dzoff = self._dz_elems
+            self._dz_elems += M * cout
+            dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
             if self.fuse_bn_bwd and _lib.lib().fn["ep24_bn_act_bwd_fused_rows"](M, cout) > 0:
                 # both passes in one launch: dy and z are read once and stay in registers across a grid barrier
                 self._b("bn_act_bwd_fused", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
@@ -623,6 +625,28 @@ class Engine:
                 raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
         if used_side:
             main.wait_stream(side)
+
+    def lane_lists(self, lo, hi):
+        """Backward entries [lo, hi) split into the main lane and the weight-gradient lane (control entries dropped).
+        The side entries of a segment depend only on main entries of the same or earlier segments."""
+        main, side = [], []
+        for name, args in self.bwd[lo:hi]:
+            if name[0] == "@":
+                continue
+            if name.startswith("side:"):
+                side.append((name[5:], args))
+            else:
+                main.append((name, args))
+        return main, side
+
+    def run_lane(self, lst):
+        """Launch plain entries on the current stream (capturable)."""
+        s = stream_ptr()
+        fn = _lib.lib().fn
+        for name, args in lst:
+            rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
+            if rc != 0:
+                raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
 
     def zero_step_buffers(self):
         s = stream_ptr()

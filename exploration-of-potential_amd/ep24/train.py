@@ -56,12 +56,12 @@ class TrainStep:
     ``ep24_loss_finalize`` (loss at [0]); nothing synchronises unless the caller reads it.
 
     ``reducer`` (ep24.dp.GradReducer or None) averages the flat gradient across ranks between backward and
-    SGD; with ``segments > 1`` the backward list is cut into that many graphs so buckets can be all-reduced on
-    the communication stream while the rest of backward still runs.
+    SGD: the backward list is cut where a gradient bucket is complete and the bucket's all-reduce is issued on
+    the communication stream while the rest of backward still runs (no collective inside a graph).
     """
 
     def __init__(self, model, loss_fn, lr, momentum=0.9, batch=None, size=640, reducer=None, use_graph=True,
-                 graph_backward=False):
+                 graph_backward=True):
         _lib.require_gpu()
         self.model, self.loss_fn = model, loss_fn
         self.eng = model.engine(batch, size)
@@ -76,10 +76,11 @@ class TrainStep:
         self.st = torch.cat(eng.exp_strides, 1)[0].contiguous()
         self.labels = torch.zeros(eng.B, 50, 51, dtype=torch.float32, device=eng.dev)
         self.graphs = None
+        self._side = None
         self.use_graph = use_graph
-        # backward is launched from the host by default: its weight-gradient kernels run on a second stream
-        # (engine._run), which beats the single-stream graph by ~8 % at YOLOX-l/B=20; graph_backward=True
-        # captures backward too (single lane) for host-bound cases (small models, busy CPUs)
+        # backward runs on two lanes (main: BN backward / dgrad / glue, side: weight gradients).  graph_backward=True
+        # replays each lane as a chain of captured segments (no launch gaps: 28.7 ms/step at YOLOX-l / B=20);
+        # False launches the same lanes from the host with per-layer events (29.4 ms)
         self.graph_backward = graph_backward
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
@@ -101,9 +102,27 @@ class TrainStep:
     def _phase_update(self):
         self.home.sgd(self.lr, self.momentum, 1.0 / self.world)
 
+    def _segments(self):
+        """Cut points of the backward list.  The weight-gradient lane runs one segment behind the main lane, so the last
+        segments are short (what is left of the lane after the main lane has finished is exposed); with a reducer its
+        bucket boundaries are cut points too."""
+        n = len(self.eng.bwd)
+        fr = (0.12, 0.24, 0.36, 0.48, 0.58, 0.68, 0.76, 0.83, 0.89, 0.93, 0.96, 0.98)
+        import os
+        if os.environ.get("EP24_BWD_CUTS"):
+            e = os.environ["EP24_BWD_CUTS"]
+            fr = [(i + 1) / int(e[1:]) for i in range(int(e[1:]) - 1)] if e[0] == "u" else [float(v) for v in e.split(",")]
+        cuts = {0, n} | {int(n * f) for f in fr}
+        ready = {}
+        if self.reducer is not None:
+            rc = self.reducer.cuts(self.eng)
+            cuts |= set(rc)
+            ready = {c: i for i, c in enumerate(rc[1:])}          # cut index -> reducer segment that ends there
+        cuts = sorted(cuts)
+        return list(zip(cuts[:-1], cuts[1:])), ready
+
     def _capture(self):
         eng = self.eng
-        cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
         # warm-up outside capture (lazy code-object loads); it must not count as a training step, so the
         # stateful pieces it touches (BN running statistics, the loss's "last loss" weights) are restored
         keep = [b.clone() for b in self.model.buffers()] + [self.state.clone()]
@@ -117,20 +136,32 @@ class TrainStep:
         with torch.no_grad():
             for b, k in zip(list(self.model.buffers()) + [self.state], keep):
                 b.copy_(k)
-        graphs = []
-        pool = None
-        self._cuts = cuts
-        phases = [self._phase_forward]
-        if self.graph_backward:
-            phases += [(lambda a=a, b=b: self._phase_backward(a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
-        phases.append(self._phase_update)
-        for ph in phases:
+        pool = [None]
+
+        def capture(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                ph()
-            pool = g.pool()
-            graphs.append(g)
-        self.graphs = graphs
+            with torch.cuda.graph(g, pool=pool[0]):
+                fn()
+            pool[0] = g.pool()
+            return g
+
+        self.g_fwd = capture(self._phase_forward)
+        self.g_upd = capture(self._phase_update)
+        self._cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
+        self.g_bwd = None
+        if self.graph_backward:
+            # two lanes, each a chain of graphs: the main lane (BN backward, dgrad, glue) and the weight-gradient lane,
+            # which starts a segment when the main lane has finished it - one event per segment, none inside a graph
+            segs, ready = self._segments()
+            self.g_bwd = []
+            for lo, hi in segs:
+                main, side = eng.lane_lists(lo, hi)
+                gm = capture(lambda: eng.run_lane(main)) if main else None
+                gs = capture(lambda: eng.run_lane(side)) if side else None
+                self.g_bwd.append((gm, gs, ready.get(hi)))
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=eng.dev)
+        self.graphs = True
 
     def step(self, images=None, labels=None):
         eng = self.eng
@@ -147,13 +178,21 @@ class TrainStep:
             return self.ws.result
         if self.graphs is None:
             self._capture()
-        g = self.graphs
-        g[0].replay()
-        if self.graph_backward:
-            for i in range(1, len(g) - 1):
-                g[i].replay()
-                if self.reducer is not None:
-                    self.reducer.bucket_ready(i - 1)
+        self.g_fwd.replay()
+        if self.g_bwd is not None:
+            main, side = torch.cuda.current_stream(), self._side
+            for gm, gs, ready in self.g_bwd:
+                if gm is not None:
+                    gm.replay()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    if gs is not None:
+                        gs.replay()
+                    if ready is not None:
+                        self.reducer.bucket_ready(ready)      # recorded on the side lane: it has waited for the main one
+            main.wait_stream(side)
         else:
             for i, (lo, hi) in enumerate(zip(self._cuts[:-1], self._cuts[1:])):
                 self._phase_backward(lo, hi)
@@ -161,5 +200,5 @@ class TrainStep:
                     self.reducer.bucket_ready(i)
         if self.reducer is not None:
             self.reducer.wait()
-        g[-1].replay()
+        self.g_upd.replay()
         return self.ws.result

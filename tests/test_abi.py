@@ -21,7 +21,7 @@ def test_header_declares_the_hot_path_entry_points():
     for name, (ret, params) in protos.items():
         for tstr, _ in params:
             base = tstr.replace("const", "").replace("*", "").strip()
-            assert base in allowed | {"void", "float", "double", "uint8_t", "uint64_t", "int32_t", "int64_t", "char"}, (name, tstr)
+            assert base in allowed | {"void", "float", "double", "uint8_t", "uint32_t", "uint64_t", "int32_t", "int64_t", "char"}, (name, tstr)
 
 
 def test_library_loads_and_exports_every_declared_symbol():

@@ -64,11 +64,11 @@ for i in range(int(os.environ.get("REPS", 6))):
     if mode == "" or ts2.graphs is None:
         ts2.step()
     else:
-        ts2.graphs[0].replay()
+        ts2.g_fwd.replay()
         if "nobwd" not in mode:
             ts2._phase_backward(0, len(eng.bwd))
         if "noupd" not in mode:
-            ts2.graphs[-1].replay()
+            ts2.g_upd.replay()
     torch.cuda.synchronize()
     g = ts2.home.gflat
     d = float((g - ref).abs().max())
