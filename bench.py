@@ -29,15 +29,20 @@ TRAIN_GFLOP_PER_IMAGE = 466.2       # 3 x 2 x 77.694 GMAC, BASELINE.md section 3
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
+def conv_shape(name, args):
+    """(B, H, W, Cin, Cout, k, s) of a conv launch entry."""
+    return args[6:13] if name.startswith("conv_dgrad") else args[-7:]
+
+
 def conv_flops(args):
-    B, H, W, Cin, Cout, k, s = args[-7:]
+    B, H, W, Cin, Cout, k, s = args
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
     return 2.0 * B * OH * OW * Cin * Cout * k * k
 
 
 def conv_bytes(args):
     """Algorithmic HBM bytes of one conv launch: every operand element once (bf16 activations / packed weights)."""
-    B, H, W, Cin, Cout, k, s = args[-7:]
+    B, H, W, Cin, Cout, k, s = args
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
     return 2.0 * (B * H * W * Cin + B * OH * OW * Cout + Cout * k * k * Cin)
 
@@ -89,7 +94,7 @@ def instrumented_step(ts):
             assert rc == 0, (name, _lib.lib().last_error())
             if timed:
                 e1.record()
-                rec.append((name, conv_flops(args), e0, e1, conv_bytes(args)))
+                rec.append((name, conv_flops(conv_shape(name, args)), e0, e1, conv_bytes(conv_shape(name, args))))
 
     ts.home.zero_grad()
     eng.zero_step_buffers()
@@ -103,7 +108,7 @@ def instrumented_step(ts):
     if os.environ.get("EP24_LAYER_TABLE"):
         rows = {}
         for (name, fl, e0, e1, _by), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]):
-            key = (name,) + tuple(args[-7:])
+            key = (name,) + tuple(conv_shape(name, args))
             r = rows.setdefault(key, [0, 0.0, 0.0])
             r[0] += 1
             r[1] += fl
@@ -125,7 +130,7 @@ def instrumented_step(ts):
         """Which device kernel a conv launch runs (mirrors the dispatch in csrc/conv_igemm.hip: launch())."""
         if name.startswith("conv_wgrad"):
             return "wgrad_kernel"
-        B, H, W, Cin, Cout, k, s = args[-7:]
+        B, H, W, Cin, Cout, k, s = conv_shape(name, args)
         K = Cin if name == "conv_fwd_bf16" else Cout          # dgrad reduces over the (padded) output channels
         f32_out = name == "conv_fwd_bf16" and args[5] != 0
         M = B * H * W

@@ -48,6 +48,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// d act(u) / du of the BN+act blocks (act = 1: SiLU, 0: identity)
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (!act) return 1.f;
+    const float s = sigmoidf_(u);
+    return s * (1.f + u * (1.f - s));
+}
 
 // BatchNorm statistics are accumulated across workgroups as 2^-20 fixed point in int64 atomics: integer
 // addition is associative, so the batch statistics (and with them the whole forward pass) are bitwise

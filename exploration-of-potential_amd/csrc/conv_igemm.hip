@@ -34,6 +34,10 @@ struct IgemmArgs {
     int accumulate;
     const float* bias;
     long long* stats; int stats_replicas;
+    // fused pass 1 of the NEXT BatchNorm backward (input gradient only): D is the complete gradient of a BN+act output
+    // whose pre-activation is bn_z; the epilogue adds sum(du) / sum(du*zhat) per channel to bn_sb / bn_sg
+    const bf16* bn_z; long bn_ldz; const float* bn_save; const float* bn_gamma; const float* bn_beta;
+    long long* bn_sg; long long* bn_sb; int bn_act;
     int b_resident_max;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernel
@@ -170,6 +174,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bnr = !OUT_F32 && p.bn_z != nullptr;
+    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bnr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < p.N) {
+                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
+                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
+            }
+    }
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
                            p.dbs == (long)p.GH * p.GW);
 
@@ -304,6 +318,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bnr = !OUT_F32 && p.bn_z != nullptr;
+    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bnr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < p.N) {
+                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
+                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
+            }
+    }
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
                            p.dbs == (long)p.GH * p.GW);
 #pragma unroll
@@ -323,8 +347,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v[q] = acc[i][q][r] + bias4[q];
-                s1[q] += v[q];
-                s2[q] += v[q] * v[q];
+                if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
             }
             if (DBG(p, 16)) continue;
             if constexpr (OUT_F32) {
@@ -344,15 +367,34 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
                     *reinterpret_cast<bf16x4*>(d) = w;
+                    if (bnr) {
+                        const bf16x4 zz = *reinterpret_cast<const bf16x4*>(p.bn_z + dpix * p.bn_ldz + c0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float zf = (float)zz[q];
+                            const float du = (float)w[q] * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
+                            s1[q] += du;                             // -> sum(du)
+                            s2[q] += du * (zf * biv[q] - bmi[q]);    // -> sum(du * zhat)
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                        if (c0 + q < p.N) {
+                            const bf16 w = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                            d[q] = w;
+                            if (bnr) {
+                                const float zf = (float)p.bn_z[dpix * p.bn_ldz + c0 + q];
+                                const float du = (float)w * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
+                                s1[q] += du;
+                                s2[q] += du * (zf * biv[q] - bmi[q]);
+                            }
+                        }
                 }
             }
         }
     }
-    if (p.stats && !DBG(p, 32)) {
+    if ((p.stats || bnr) && !DBG(p, 32)) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
 #pragma unroll
@@ -366,14 +408,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             }
         }
         __syncthreads();
-        long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
+        long long* st = bnr ? nullptr : p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, c = i - which * BN;
             const int wcol = c >> 6;
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+            if (n0 + c < p.N) {
+                long long* dst = bnr ? (which ? p.bn_sg : p.bn_sb) + n0 + c : st + (long)which * p.N + n0 + c;
+                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(v));
+            }
         }
     }
 }
@@ -737,6 +782,16 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     f32x4 acc[MT][4];
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int c0 = n0 + wn * 64 + 4 * frow;
+    const bool bnr = p.bn_z != nullptr;                     // fused pass 1 of the next BN backward (see igemm_epilogue)
+    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bnr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < p.N) {
+                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
+                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
+            }
+    }
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -774,8 +829,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[q] = acc[i][q][r];
-                    s1[q] += v[q];
-                    s2[q] += v[q] * v[q];
+                    if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
                 }
                 bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
                 if (c0 + 3 < p.N) {
@@ -788,10 +842,29 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
                     *reinterpret_cast<bf16x4*>(d) = w;
+                    if (bnr) {
+                        const bf16x4 zz = *reinterpret_cast<const bf16x4*>(p.bn_z + m * p.bn_ldz + c0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float zf = (float)zz[q];
+                            const float du = (float)w[q] * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
+                            s1[q] += du;
+                            s2[q] += du * (zf * biv[q] - bmi[q]);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                        if (c0 + q < p.N) {
+                            const bf16 w = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                            d[q] = w;
+                            if (bnr) {
+                                const float zf = (float)p.bn_z[m * p.bn_ldz + c0 + q];
+                                const float du = (float)w * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
+                                s1[q] += du;
+                                s2[q] += du * (zf * biv[q] - bmi[q]);
+                            }
+                        }
                 }
             }
         }
@@ -806,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         if (u + 1 < units) compute(A1, u + 1);
     }
 
-    if (p.stats) {
+    if (p.stats || bnr) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]; the weight tile is no longer needed
 #pragma unroll
@@ -820,14 +893,17 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
             }
         }
         __syncthreads();
-        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        long long* st = bnr ? nullptr : p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, c = i - which * BN;
             const int wcol = c >> 6;
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+            if (n0 + c < p.N) {
+                long long* dst = bnr ? (which ? p.bn_sg : p.bn_sb) + n0 + c : st + (long)which * p.N + n0 + c;
+                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(v));
+            }
         }
     }
 }
@@ -934,9 +1010,30 @@ extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, vo
     return launch(a, y_f32 != 0, (hipStream_t)stream);
 }
 
+namespace {
+struct BnReduce { const void* z; int64_t ld_z; const float* save; const float* gamma; const float* beta; int64_t* sg; int64_t* sb; int act; };
+int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin,
+               int Cout_k, int ksize, int stride, const BnReduce* bn, void* stream);
+}  // namespace
+
 extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
                                     int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
                                     void* stream) {
+    return dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, nullptr, stream);
+}
+
+extern "C" int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
+                                        int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                                        const void* z, int64_t ld_z, const float* save, const float* gamma, const float* beta,
+                                        int64_t* dgamma, int64_t* dbeta, int act, void* stream) {
+    EP24_REQUIRE(z && save && gamma && beta && dgamma && dbeta && ld_z % 4 == 0, EP24_E_ARG, "conv_dgrad_bnr: bad BN arguments");
+    const BnReduce bn{z, ld_z, save, gamma, beta, dgamma, dbeta, act};
+    return dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, &bn, stream);
+}
+
+namespace {
+int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin,
+               int Cout_k, int ksize, int stride, const BnReduce* bn, void* stream) {
     EP24_REQUIRE(dy && wt && dx, EP24_E_ARG, "conv_dgrad: null pointer");
     EP24_REQUIRE(Cout_k % 8 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 8", Cout_k);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
@@ -949,6 +1046,10 @@ extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* w
     a.wt = (const bf16*)wt; a.WT = ksize * ksize; a.K = Cout_k; a.N = Cin;
     a.dst = dx; a.ld_dst = ld_dx; a.DH = H; a.DW = W; a.dbs = (long)H * W; a.dp0 = 0;
     a.accumulate = accumulate; a.bias = nullptr; a.stats = nullptr; a.stats_replicas = 1;
+    if (bn) {
+        a.bn_z = (const bf16*)bn->z; a.bn_ldz = bn->ld_z; a.bn_save = bn->save; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+        a.bn_sg = (long long*)bn->sg; a.bn_sb = (long long*)bn->sb; a.bn_act = bn->act;
+    }
     if (stride == 1) {
         // dx[y,x] = sum_{kh,kw} dy[y + pad - kh, x + pad - kw] . w[:,kh,kw,:]
         a.GH = H; a.GW = W; a.sy = a.sx = 1;
@@ -980,3 +1081,4 @@ extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* w
         }
     return EP24_OK;
 }
+}  // namespace

@@ -103,11 +103,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
 //   dz = k1*du - k2 - k3*z         (k1 = gamma*invstd, k3 = k1*invstd*mean(du*zhat), k2 = k1*(mean(du) - mean*invstd*mean(du*zhat)))
 // Every thread owns one 8-channel group for the whole kernel (constants in registers) and walks rows with
 // several 16-byte loads in flight.
-__device__ __forceinline__ float act_grad(float u, int act) {
-    if (!act) return 1.f;
-    const float s = sigmoidf_(u);
-    return s * (1.f + u * (1.f - s));
-}
 
 template <int UNROLL, int NT>
 __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,

@@ -61,6 +61,9 @@ class Dyn:
         return self.table[self.key]
 
 
+_PENDING_GW = []
+
+
 class Act:
     """Channel slice [c0, c0+C) of a Buf, viewed as an NHWC tensor [B,H,W,C]."""
 
@@ -107,8 +110,14 @@ class Act:
         r = self._groot()
         return r.buf.gwritten, r.c0, r.c0 + r.C
 
+    def gregion(self):
+        """(gradient buffer identity, first channel, one past the last) of this Act's gradient."""
+        r = self._groot()
+        return (id(r.buf), r.c0, r.c0 + r.C)
+
     def gwrite(self):
         """Called while the backward list is built: 0 = first producer (overwrite), 1 = accumulate."""
+        _PENDING_GW.append(self.gregion())           # picked up by the next Engine._b(): that entry writes this region
         w, lo, hi = self._interval()
         if any(a <= lo and hi <= b for a, b in w):
             return 1
@@ -301,6 +310,11 @@ class Engine:
         self.outputs = None
         self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
+        self.bwd_gw, self.bwd_rd = [], []        # per backward launch: activation-gradient regions written / the one a BN reduce reads
+        # folding pass 1 of the BN backward into the epilogue of the dgrad that completes dy removes 101 of 122 reduce
+        # launches, but the exposed epilogue (z loads + SiLU' per element at the end of a one-round grid) costs more than
+        # the streaming kernel it replaces: +3.2 ms dgrad vs -2.8 ms reduce at YOLOX-l / B=20.  Experiment switch.
+        self.fuse_bn_reduce = os.environ.get("EP24_BNR") == "1"
         self._bwd_units = 0
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
@@ -324,9 +338,12 @@ class Engine:
     def _f(self, name, *args):
         self.fwd.append((name, args))
 
-    def _b(self, name, args, writes=()):
+    def _b(self, name, args, writes=(), reads=None):
         self.bwd.append((name, args))
         self.bwd_writes.append([(seg.off, seg.numel) for seg in writes])
+        self.bwd_gw.append(list(_PENDING_GW))        # activation-gradient regions this entry writes
+        del _PENDING_GW[:]
+        self.bwd_rd.append(reads.gregion() if reads is not None else None)
 
     # ---- graph construction -------------------------------------------------------------------------
     def _build(self):
@@ -385,6 +402,10 @@ class Engine:
         for b in reversed(self._bwd_builders):
             b()
         self._flush_reduce()
+        del _PENDING_GW[:]
+        self.bn_reduce_fused = 0
+        if self.fuse_bn_reduce:
+            self._fuse_reduce_into_dgrad()
         self.slab = torch.zeros(max(self._slab_floats, 4), dtype=torch.float32, device=self.dev)
         # every layer keeps its own dz (the gradient w.r.t. the raw conv output): the weight-gradient lane may lag the
         # main lane by a whole segment without a write-after-read hazard (3.4 GB at -l / B=20; there are 288)
@@ -394,6 +415,37 @@ class Engine:
             for name, args in lst:
                 out.append((name, tuple(a() if callable(a) else a for a in args)))   # Dyn stays for run time
         self.fwd, self.bwd = fw, bw
+
+    def _fuse_reduce_into_dgrad(self):
+        """Pass 1 of a layer's BN backward (the per-channel sums over dy) moves into the epilogue of the input-gradient
+        kernel that is the LAST writer of that dy, when that kernel writes exactly the layer's output gradient: it has
+        the final values in registers, so the separate reduce kernel and its read of dy disappear.  Everything else
+        (concat-wide dgrads, pooling / upsample / copy writers, network outputs) keeps the reduce kernel."""
+        drop = set()
+        for r, (name, a) in enumerate(self.bwd):
+            reg = self.bwd_rd[r]
+            if name != "bn_act_bwd_reduce" or reg is None:
+                continue
+            j, hit = r - 1, None
+            while j >= 0 and hit is None:
+                for g in self.bwd_gw[j]:
+                    if g[0] == reg[0] and g[1] < reg[2] and reg[1] < g[2]:
+                        hit = j
+                        break
+                j -= 1
+            if hit is None or hit in drop:
+                continue
+            dn, da = self.bwd[hit]
+            if dn != "conv_dgrad_bf16" or self.bwd_gw[hit] != [reg]:
+                continue
+            M, C = a[9], a[10]
+            if da[9] != C or da[6] * da[7] * da[8] != M:
+                continue
+            self.bwd[hit] = ("conv_dgrad_bnr_bf16", tuple(da) + (a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[11]))
+            drop.add(r)
+        self.bn_reduce_fused = len(drop)
+        for lst in ("bwd", "bwd_writes", "bwd_gw", "bwd_rd"):
+            setattr(self, lst, [v for i, v in enumerate(getattr(self, lst)) if i not in drop])
 
     def _flush_reduce(self):
         """One reduce launch (side stream, behind the weight-gradient kernels it sums) for the pending layers."""
@@ -466,7 +518,7 @@ class Engine:
                                              bar_cnt), writes=(gam, bet))
             else:
                 self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, 1))
+                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, 1), reads=out)
                 self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                              ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
                                              dz, cout, M, cout, 1), writes=(gam, bet))

@@ -56,6 +56,15 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
 int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
                          int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, void* stream);
 
+/* The same input gradient, and in its epilogue pass 1 of the BatchNorm backward of the layer that PRODUCED x: when dx
+ * is the complete gradient of y = act(bn(z)) (this launch is its last writer), dbeta[c] += sum du and dgamma[c] += sum
+ * du*zhat with du = dx * act'(bn(z)) are accumulated from the values just stored (2^-20 fixed point, as
+ * ep24_bn_act_bwd_reduce), which saves that kernel's read of dx.  z [B*H*W, Cin] row stride ld_z; save = mean|invstd. */
+int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
+                             int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                             const void* z, int64_t ld_z, const float* save, const float* gamma, const float* beta,
+                             int64_t* dgamma, int64_t* dbeta, int act, void* stream);
+
 /* dw[co][t][ci] += sum_pixels dy[.,co] * x[.@t,ci]   fp32, row stride ld_dw between co rows (= taps*cin_valid
  * when dense), only co < cout_valid and ci < cin_valid are written.  Split over pixels with fp32 atomics.
  * Replaces autograd's conv weight gradient. */
