@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bnr = !OUT_F32 && p.bn_z != nullptr;
+    constexpr bool bnr = false;                        // (the fused BN reduce exists in the LDS-DMA and streaming kernels only)
     float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
     if (bnr) {
 #pragma unroll
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 }
 
 // Shared epilogue of the DMA kernels: bias, BN statistics, bf16 / fp32 stores, fixed-point statistic atomics.
-template <int BN, bool OUT_F32, int MT>
+template <int BN, bool OUT_F32, int MT, bool BNR = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
     constexpr int WN = BN / 64, WM = 4 / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bnr = !OUT_F32 && p.bn_z != nullptr;
+    constexpr bool bnr = BNR && !OUT_F32;              // compiled in only for the experiment's instantiation
     float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
     if (bnr) {
 #pragma unroll
@@ -433,7 +433,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, bool BNR = false>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         }
     }
 
-    igemm_epilogue<BN, OUT_F32, MT>(p, acc, m0, n0, tile_m, smem);
+    igemm_epilogue<BN, OUT_F32, MT, BNR>(p, acc, m0, n0, tile_m, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 // A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
 // block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
 // registers until the end.  Waves of a workgroup share the rows (WN waves, 64 columns each) through L1.
-template <int BN, int H>
+template <int BN, int H, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = 2, RG = WM * MT * 16;   // 32-row blocks per wave: ~170 VGPRs, 3 waves per SIMD
     constexpr int OOB = 0x7FFFFFF0;
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     f32x4 acc[MT][4];
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int c0 = n0 + wn * 64 + 4 * frow;
-    const bool bnr = p.bn_z != nullptr;                     // fused pass 1 of the next BN backward (see igemm_epilogue)
+    constexpr bool bnr = BNR;                               // fused pass 1 of the next BN backward (see igemm_epilogue)
     float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
     if (bnr) {
 #pragma unroll
@@ -920,12 +920,14 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     const int npan = (a.K + 63) / 64;
     size_t lds = (size_t)npan * BN * 128;
     if (lds < 2048) lds = 2048;
-    hipLaunchKernelGGL((igemm_stream_kernel<BN, H>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    if (a.bn_z) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, true>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, false>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
 }
 
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
     if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
+    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, true>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
     else if (!getenv("EP24_IGEMM_RING")) hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
     else {
         // experimental: BK=32 ring with counted vmcnt (EP24_IGEMM_RING=2|3|4 stages); measured within +-10 % of the
