@@ -726,6 +726,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* g, long ld, flo
     }
 }
 
+// the same partial sums without atomics: block b stores its partial at slab[b * N + c]; ep24_wgrad_reduce folds the
+// gridDim.x "splits" in order (bitwise reproducible bias gradients)
+__global__ __launch_bounds__(256) void colsum_slab_kernel(const bf16* g, long ld, float* slab, long M, int N) {
+    __shared__ float red[256];
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int c = c0 + (threadIdx.x & 63);
+        float acc = 0.f;
+        if (c < N)
+            for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) acc += (float)g[m * ld + c];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64 && c < N)
+            slab[(long)blockIdx.x * N + c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------- weights / SGD
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, long ld_w, bf16* wf, bf16* wd, int Cout, int T,
                                                            int Cin, int Cin_pad, int Cout_pad) {
@@ -1002,6 +1019,18 @@ extern "C" int ep24_head_decode_bwd(const float* dout, const float* out, void* d
     hipLaunchKernelGGL(decode_bwd_kernel, dim3(cap_grid((long)B * H * W * (4 + (ncols - 27 + 7) / 8))), dim3(256), 0, S_, dout, out, (bf16*)d_regobj,
                        (bf16*)d_cls, B, A, a0, H, W, stride, ncols);
     EP24_LAUNCH_CHECK("ep24_head_decode_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_colsum_splits(int64_t M) {
+    long blocks = (M + 3) / 4;
+    return (int)(blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks));
+}
+
+extern "C" int ep24_colsum_slab(const void* g, int64_t ld, float* slab, int64_t M, int N, void* stream) {
+    EP24_REQUIRE(g && slab && N > 0 && M > 0, EP24_E_ARG, "colsum_slab: bad arguments");
+    hipLaunchKernelGGL(colsum_slab_kernel, dim3((unsigned)ep24_colsum_splits(M)), dim3(256), 0, S_, (const bf16*)g, ld, slab, M, N);
+    EP24_LAUNCH_CHECK("ep24_colsum_slab");
     return EP24_OK;
 }
 

@@ -616,12 +616,23 @@ class Engine:
         def build_bwd():
             dout = Dyn(self.dyn, "dout")
             self._b("head_decode_bwd", (dout, ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols))
-            self._b("colsum", (ptr(d_ro), 32, ptr(gflat, ro_b.off), M, 27), writes=(ro_b,))
-            self._b("colsum", (ptr(d_cl), ldc, ptr(gflat, cl_b.off), M, C), writes=(cl_b,))
-            self._b("conv_wgrad_bf16", (rf.ptr(), rf.ld, ptr(d_ro), 32, ptr(gflat, ro_seg.off), hch, 27, hch, B, H, W,
-                                        hch, 32, 1, 1), writes=(ro_seg,))
-            self._b("conv_wgrad_bf16", (cf.ptr(), cf.ld, ptr(d_cl), ldc, ptr(gflat, cl_seg.off), hch, C, hch, B, H, W,
-                                        hch, ldc, 1, 1), writes=(cl_seg,))
+            # bias and weight gradients of the prediction convs: side lane, slab partials folded by the next reduce launch
+            fn = _lib.lib().fn
+            self._b("@side_wait_main", ())
+            for dsrc, ld_d, bseg, n in ((d_ro, 32, ro_b, 27), (d_cl, ldc, cl_b, C)):
+                sp = fn["ep24_colsum_splits"](M)
+                soff = self._slab_floats
+                self._slab_floats += sp * n + (-(sp * n)) % 4
+                self._b("side:colsum_slab", (ptr(dsrc), ld_d, (lambda soff=soff: self.slab.data_ptr() + 4 * soff), M, n))
+                self._pending_reduce.append((bseg, sp, soff))
+            for feat_in, dsrc, ld_d, wseg, n, npad in ((rf, d_ro, 32, ro_seg, 27, 32), (cf, d_cl, ldc, cl_seg, C, ldc)):
+                sp = fn["ep24_conv_wgrad_splits"](B, H, W, hch, npad, 1, 1)
+                soff = self._slab_floats
+                self._slab_floats += sp * wseg.numel
+                self._b("side:conv_wgrad_slab_bf16", (feat_in.ptr(), feat_in.ld, ptr(dsrc), ld_d,
+                                                      (lambda soff=soff: self.slab.data_ptr() + 4 * soff), sp * wseg.numel, hch, n, hch,
+                                                      B, H, W, hch, npad, 1, 1))
+                self._pending_reduce.append((wseg, sp, soff))
             self._b("conv_dgrad_bf16", (ptr(d_ro), 32, ptr(home.wd, ro_seg.wd_off), rf.gptr(), rf.gld, rf.gwrite(), B, H,
                                         W, hch, 32, 1, 1))
             self._b("conv_dgrad_bf16", (ptr(d_cl), ldc, ptr(home.wd, cl_seg.wd_off), cf.gptr(), cf.gld, cf.gwrite(), B, H,

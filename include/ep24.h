@@ -171,6 +171,10 @@ int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, vo
                          int H, int W, float stride, int ncols, void* stream);
 /* bias gradient: db[n] += sum_m g[m][n] for n < N (bf16 rows of stride ld). */
 int ep24_colsum(const void* g, int64_t ld, float* db, int64_t M, int N, void* stream);
+/* the same without atomics: ep24_colsum_splits(M) partial rows slab[s*N + n], folded in order by ep24_wgrad_reduce
+ * with a row (offset, N, splits, slab offset). */
+int ep24_colsum_splits(int64_t M);
+int ep24_colsum_slab(const void* g, int64_t ld, float* slab, int64_t M, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a4-a8  SimOTA assignment, batched over images, no host synchronisation

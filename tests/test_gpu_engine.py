@@ -350,6 +350,41 @@ def test_replayed_steps_are_reproducible(graph_backward):
         assert err < 1e-4, (rep, err)
 
 
+def test_full_size_step_properties():
+    """BASELINE config 2 itself (YOLOX-l-24p, B = 20, 640x640) through size-independent properties: (1) two training
+    runs from the same state are bitwise identical - loss AND every parameter after 3 steps (fixed-point BN sums,
+    slab-ordered weight gradients, no float atomics on the path); (2) the step with lr = 0 leaves the weights
+    untouched and the loss of a repeated batch unchanged; (3) gradients are finite and reach every parameter."""
+    from ep24 import loss as eloss, nn as enn, train as etrain
+
+    def run(lr, steps):
+        torch.manual_seed(0)
+        m = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
+        m.head.initialize_biases(1e-2)
+        m.to(DEV)
+        lf = eloss.Loss_Function(80)
+        ts = etrain.TrainStep(m, lf, lr=lr, momentum=0.9, batch=20, size=640)
+        ts.eng.images.copy_(synth.make_images(20, 640, seed=1).to(DEV))
+        ts.labels.copy_(synth.make_labels(20, 10, size=640, seed=1000).to(DEV))
+        losses = [float(ts.step()[0]) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return losses, ts.home.flat.clone(), ts.home.gflat.clone(), m
+
+    la, wa, ga, _ = run(0.001, 3)
+    lb, wb, gb, _ = run(0.001, 3)
+    assert la == lb and torch.equal(wa, wb) and torch.equal(ga, gb), (la, lb)
+    assert all(np.isfinite(la)) and la[0] != la[1]
+    assert bool(torch.isfinite(ga).all()) and float((ga != 0).float().mean()) > 0.99
+    l0, w0, _, m0 = run(0.0, 2)
+    torch.manual_seed(0)
+    ref = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
+    ref.head.initialize_biases(1e-2)
+    assert l0[0] == la[0]
+    for (n, p_new), p_ref in zip(m0.named_parameters(), ref.parameters()):      # lr = 0 changes nothing
+        assert torch.equal(p_new.detach().cpu(), p_ref.detach()), n
+    assert abs(l0[1] - l0[0]) / l0[0] < 0.2                                 # only the loss's dynamic weights moved
+
+
 def test_loss_of_model_outputs_matches_oracle_assignment():
     """L2 boundary on real network outputs: feed the HIP model's own outputs to the CPU oracle loss."""
     from ep24 import loss as eloss
