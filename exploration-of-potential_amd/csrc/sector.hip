@@ -143,6 +143,52 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* sr
 }
 }  // namespace
 
+// Gather and resize in one pass: the texel that output pixel i takes from the [T, n_ang] resized image is computed on
+// the spot from the source image with the same fixed-point bilinear arithmetic, so the 35 MB intermediate (T x 13200 x 3)
+// is never written or read: 114 -> ~15 us per image + mask at 1280x1280.
+namespace {
+__global__ __launch_bounds__(256) void sector_warp_kernel(const uint8_t* src, int sh, int sw, const int* winner, int canvas_w,
+                                                          int y0, int x0, int out_h, int out_w, int T, int n_ang, uint8_t* dst,
+                                                          int fill, float scale_x, float scale_y) {
+    // one output pixel per thread (four per thread with packed dword stores measured 1.4x slower: the gathers serialise)
+    const long total = (long)out_h * out_w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int oy = (int)(i / out_w), ox = (int)(i - (long)oy * out_w);
+        const int key = winner[(long)(y0 + oy) * canvas_w + x0 + ox];
+        uint8_t c[3] = {(uint8_t)fill, (uint8_t)fill, (uint8_t)fill};
+        if (key >= 0) {
+            const int a = key / T, r = key - a * T;
+            const int dy = T - 1 - r, dx = n_ang - 1 - a;                 // img_resize[ptx[:, ::-1], pty[::-1, :]]
+            int xa, xb, axa, axb, ya, yb, bya, byb;
+            lin_coef(dx, scale_x, sw, xa, xb, axa, axb);
+            lin_coef(dy, scale_y, sh, ya, yb, bya, byb);
+            const uint8_t* r0 = src + (long)ya * sw * 3;
+            const uint8_t* r1 = src + (long)yb * sw * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int h0 = r0[xa * 3 + ch] * axa + r0[xb * 3 + ch] * axb;
+                const int h1 = r1[xa * 3 + ch] * axa + r1[xb * 3 + ch] * axb;
+                const int v = (((bya * (h0 >> 4)) >> 16) + ((byb * (h1 >> 4)) >> 16) + 2) >> 2;
+                c[ch] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+        dst[i * 3 + 0] = c[0]; dst[i * 3 + 1] = c[1]; dst[i * 3 + 2] = c[2];
+    }
+}
+}  // namespace
+
+extern "C" int ep24_sector_warp_u8(const uint8_t* src, int sh, int sw, const int32_t* winner, int canvas_w, int y0, int x0,
+                                   int out_h, int out_w, int T, int n_ang, uint8_t* dst, int fill, void* stream) {
+    EP24_REQUIRE(src && winner && dst && sh > 0 && sw > 0 && out_h > 0 && out_w > 0 && T > 0 && n_ang > 0, EP24_E_ARG,
+                 "sector_warp: bad arguments");
+    long blocks = ((long)out_h * out_w + 255) / 256;
+    hipLaunchKernelGGL(sector_warp_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, src, sh,
+                       sw, winner, canvas_w, y0, x0, out_h, out_w, T, n_ang, dst, fill, (float)((double)sw / n_ang),
+                       (float)((double)sh / T));
+    EP24_LAUNCH_CHECK("ep24_sector_warp_u8");
+    return EP24_OK;
+}
+
 extern "C" int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream) {
     EP24_REQUIRE(src && dst && sh > 0 && sw > 0 && dh > 0 && dw > 0, EP24_E_ARG, "resize_linear_u8: bad arguments");
     long blocks = ((long)dh * dw + 255) / 256;

@@ -56,6 +56,7 @@ class Image_Distortion:
         self.sector_length = MAX_ROWS
         self.draw_resolution = 80
         self.device = torch.device(device)
+        self.two_pass = False
         self._maps = {}
 
     def _map(self, theta_deg, h, w, custom_rows):
@@ -80,10 +81,13 @@ class Image_Distortion:
     def _warp(self, img, winner, cw, box, T, fill):
         y0, y1, x0, x1 = box
         h, w = img.shape[0], img.shape[1]
-        resized = torch.empty((T, N_ANG, 3), dtype=torch.uint8, device=self.device)
-        call("resize_linear_u8", ptr(img), h, w, ptr(resized), T, N_ANG, stream_ptr())
         out = torch.empty((y1 - y0, x1 - x0, 3), dtype=torch.uint8, device=self.device)
-        call("sector_gather", ptr(resized), ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, ptr(out), fill, None, stream_ptr())
+        if self.two_pass:                      # cv2.resize(image, (13200, T)) materialised, then the gather
+            resized = torch.empty((T, N_ANG, 3), dtype=torch.uint8, device=self.device)
+            call("resize_linear_u8", ptr(img), h, w, ptr(resized), T, N_ANG, stream_ptr())
+            call("sector_gather", ptr(resized), ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, ptr(out), fill, None, stream_ptr())
+        else:                                  # the same texels sampled on the fly: no 35 MB intermediate
+            call("sector_warp_u8", ptr(img), h, w, ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, ptr(out), fill, stream_ptr())
         return out
 
     def sector_distort(self, image, mask, Theta=60, custom_rows=None):

@@ -254,6 +254,10 @@ int ep24_mask_bbox(const uint8_t* mask3, int out_h, int out_w, int32_t* box, voi
 /* uint8 HWC bilinear resize with OpenCV's INTER_LINEAR fixed-point arithmetic (cv2.resize(image, (13200, T)),
  * demo_featuremap.py:285).  src [sh][sw][3] -> dst [dh][dw][3]. */
 int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
+/* gather + resize in one pass (no [T, n_ang] intermediate): dst[oy][ox] = bilinear sample of src at the texel the
+ * winner map selects, with the arithmetic of ep24_resize_linear_u8 / ep24_sector_gather (bit-identical results). */
+int ep24_sector_warp_u8(const uint8_t* src, int sh, int sw, const int32_t* winner, int canvas_w, int y0, int x0,
+                        int out_h, int out_w, int T, int n_ang, uint8_t* dst, int fill, void* stream);
 
 #ifdef __cplusplus
 }

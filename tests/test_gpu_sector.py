@@ -25,9 +25,12 @@ def test_winner_map_bit_exact(golden, dist, theta, h, w):
     assert zlib.crc32(np.ascontiguousarray(src).tobytes()) == int(z[key + "src_crc"])
 
 
+@pytest.mark.parametrize("two_pass", [False, True])
 @pytest.mark.parametrize("theta,h,w", [(60, 640, 640), (90, 427, 640), (30, 1280, 1280)])
-def test_full_warp_vs_oracle(dist, theta, h, w):
+def test_full_warp_vs_oracle(dist, theta, h, w, two_pass):
+    """Both device forms - resize + gather as two kernels, and the fused one-pass warp - reproduce the oracle."""
     from oracle import sector as osec
+    dist.two_pass = two_pass
     rng = np.random.RandomState(theta)
     image = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
     mask = np.zeros((h, w, 3), np.uint8)
@@ -35,6 +38,7 @@ def test_full_warp_vs_oracle(dist, theta, h, w):
     got_img, got_box = dist.sector_distort(image, mask, Theta=theta)
     want_img, want_box = osec.sector_distort(image, mask, theta)
     assert got_img.shape == want_img.shape and got_img.dtype == np.uint8
+    dist.two_pass = False
     assert np.array_equal(got_img, want_img)
     assert got_box == want_box
 
