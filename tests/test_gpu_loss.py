@@ -81,9 +81,9 @@ def test_candidate_masks_vs_golden(L, golden, tag):
     assert np.array_equal((in_box & in_ctr)[:, fg], z["in_both"])
 
 
-def _run_loss(L, lf, outputs, labels):
+def _run_loss(L, lf, outputs, labels, size=640):
     outputs = outputs.to(DEV).requires_grad_(True)
-    tup = lf(synth.outputs_train_tuple(outputs), labels.to(DEV))
+    tup = lf(synth.outputs_train_tuple(outputs, size=size), labels.to(DEV))
     tup[0].backward()
     return tup, outputs.grad
 
@@ -134,6 +134,33 @@ def test_assignment_g50_vs_golden(L, golden):
     assert nfg == int(z["nfg"])
     assert torch.equal(fg.cpu(), t(z["fg"])) and torch.equal(gt_idx.cpu(), t(z["gt"])) and torch.equal(cls_m.cpu(), t(z["cls"]))
     torch.testing.assert_close(tup[0].detach().cpu(), t(z["loss"]), rtol=1e-4, atol=1e-6)
+
+
+def test_config5_sizes_vs_oracle():
+    """BASELINE config 5 loss sizes: 1280x1280 (33 600 anchors), batch 8, up to the maximum of 50 GTs per image and
+    an image without any - the circle_inter / SimOTA kernels under their largest shapes."""
+    from ep24 import loss as L
+    from oracle.loss import LossOracle
+    B, S = 8, 1280
+    counts = [50, 0, 17, 50, 3, 28, 1, 41]
+    labels = synth.make_labels(B, counts, size=S, seed=501)
+    outputs = synth.decode_head(synth.make_raw_head(B, size=S, seed=502), size=S)
+    lf = L.Loss_Function(80)
+    tup, grad = _run_loss(L, lf, outputs, labels, size=S)
+    ora = LossOracle(80)
+    o_out = outputs.clone().requires_grad_(True)
+    o_tup = ora(synth.outputs_train_tuple(o_out, size=S), labels)
+    o_tup[0].backward()
+    for b in range(B):
+        cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, b)
+        if counts[b] == 0:
+            assert nfg == 0
+            continue
+        o_cls, o_fg, o_ious, o_idx, o_nfg = ora.trace[b]
+        assert nfg == o_nfg and torch.equal(fg.cpu(), o_fg) and torch.equal(gt_idx.cpu(), o_idx), b
+    torch.testing.assert_close(tup[0].detach().cpu(), o_tup[0].detach(), rtol=1e-4, atol=1e-6)
+    g, og = grad.cpu(), o_out.grad
+    assert float((g - og).abs().max()) <= 2e-3 * float(og.abs().max())
 
 
 def test_full_batch_vs_oracle():
