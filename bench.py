@@ -199,10 +199,18 @@ def main():
     world = a.gpus
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # rehearsal hooks (one-GPU box): EP24_REHEARSE=1 puts every rank on cuda:0, uses gloo for the collective and gives
+    # all ranks the same batch, so the N-rank loss must equal the 1-rank loss (tests the whole data-parallel step)
+    rehearse = os.environ.get("EP24_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         assert int(os.environ.get("WORLD_SIZE", 1)) == world, "launch with torch.distributed.run --nproc-per-node N"
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -215,8 +223,9 @@ def main():
     ts = etrain.TrainStep(model, lf, lr=0.001, momentum=0.9, batch=a.batch, size=a.size, reducer=reducer,
                           use_graph=not a.no_graph, graph_backward=not a.eager_backward)
     # this rank's shard of the synthetic global batch (weak scaling: per-GPU work fixed)
-    images = synth.make_images(a.batch, a.size, seed=1 + rank).to(dev)
-    labels = synth.make_labels(a.batch, a.gts, size=a.size, seed=1000 + rank).to(dev)
+    shard = 0 if rehearse else rank
+    images = synth.make_images(a.batch, a.size, seed=1 + shard).to(dev)
+    labels = synth.make_labels(a.batch, a.gts, size=a.size, seed=1000 + shard).to(dev)
     ts.eng.images.copy_(images)
     ts.labels.copy_(labels)
 
