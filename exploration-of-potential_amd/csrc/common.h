@@ -47,7 +47,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each).  Written as a division the compiler emits the full IEEE sequence (div_scale,
+// rcp, 4 fma, div_fmas, div_fixup: ~10 instructions per element), which made the BN + SiLU kernels VALU-bound.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // d act(u) / du of the BN+act blocks (act = 1: SiLU, 0: identity)
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (!act) return 1.f;

@@ -67,7 +67,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
     const long total = M * cgs;
     const long stride = (long)gridDim.x * 256;
     constexpr int U = 4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += U * stride) {
+    // When the grid stride is a multiple of the channel-group count every chunk of a thread belongs to ONE group, so
+    // its 16 constants live in registers.  (Reading them from LDS per chunk - 16 ds_read_b32 with a 32-byte lane
+    // stride, 4-way bank conflicts - made this kernel LDS-bound at ~4.9 TB/s of input: SQ_LDS_BANK_CONFLICT was 81 %
+    // of the LDS-active cycles.)
+    const bool fixed_group = stride % cgs == 0;
+    const int g_fixed = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cgs);
+    float rsc[8], rsh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rsc[j] = sc[g_fixed * 8 + j]; rsh[j] = sh[g_fixed * 8 + j]; }
+    const long m_fixed = ((long)blockIdx.x * 256 + threadIdx.x) / cgs, m_step = stride / cgs;
+    int it = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += U * stride, ++it) {
         long mm[U];
         int gg[U];
         bf16x8 v[U], r[U];
@@ -75,8 +86,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
         for (int k = 0; k < U; ++k) {
             const long ik = i + k * stride;
             const bool ok = ik < total;
-            mm[k] = ok ? ik / cgs : -1;
-            gg[k] = ok ? (int)(ik - mm[k] * cgs) : 0;
+            if (fixed_group) {                                   // row = (ik - g) / cgs without a 64-bit division
+                mm[k] = ok ? m_fixed + (long)(it * U + k) * m_step : -1;
+                gg[k] = g_fixed;
+            } else {
+                mm[k] = ok ? ik / cgs : -1;
+                gg[k] = ok ? (int)(ik - mm[k] * cgs) : 0;
+            }
             if (ok) {
                 v[k] = *reinterpret_cast<const bf16x8*>(z + mm[k] * ld_z + gg[k] * 8);
                 if (res) r[k] = *reinterpret_cast<const bf16x8*>(res + mm[k] * ld_res + gg[k] * 8);
@@ -88,7 +104,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float u = (float)v[k][j] * sc[gg[k] * 8 + j] + sh[gg[k] * 8 + j];
+                const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 8 + j];
+                const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 8 + j];
+                const float u = (float)v[k][j] * a_ + b_;
                 o[j] = (bf16)((act ? u * sigmoidf_(u) : u) + (res ? (float)r[k][j] : 0.f));
             }
             *reinterpret_cast<bf16x8*>(y + mm[k] * ld_y + gg[k] * 8) = o;
