@@ -54,7 +54,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (!act) return 1.f;
     const float s = sigmoidf_(u);
-    return s * (1.f + u * (1.f - s));
+    return s * fmaf(u, 1.f - s, 1.f);
 }
 
 // BatchNorm statistics are accumulated across workgroups as 2^-20 fixed point in int64 atomics: integer

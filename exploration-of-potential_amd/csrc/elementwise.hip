@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
             for (int j = 0; j < 8; ++j) {
                 const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 8 + j];
                 const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 8 + j];
-                const float u = (float)v[k][j] * a_ + b_;
+                const float u = fmaf((float)v[k][j], a_, b_);
                 o[j] = (bf16)((act ? u * sigmoidf_(u) : u) + (res ? (float)r[k][j] : 0.f));
             }
             *reinterpret_cast<bf16x8*>(y + mm[k] * ld_y + gg[k] * 8) = o;
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float zz = (float)vz[k][j];
-                        const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
+                        const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
                         sb[j] += du;
-                        sg[j] += du * (zz * iv[j] - mi[j]);
+                        sg[j] = fmaf(du, fmaf(zz, iv[j], -mi[j]), sg[j]);
                     }
                 }
 #pragma unroll
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float zz = (float)vz[k][j];
-                    const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
-                    o[j] = (bf16)(k1[j] * du - k2[j] - k3[j] * zz);
+                    const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
+                    o[j] = (bf16)fmaf(-k3[j], zz, fmaf(k1[j], du, -k2[j]));
                 }
                 *reinterpret_cast<bf16x8*>(dz + mm * ld_dz + cg * 8) = o;
             }
@@ -297,9 +297,9 @@ __global__ __launch_bounds__(512) void bn_act_bwd_fused_kernel(const bf16* dy, l
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float zz = (float)vz[k][j];
-                const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
+                const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
                 sb[j] += du;
-                sg[j] += du * (zz * iv[j] - mi[j]);
+                sg[j] = fmaf(du, fmaf(zz, iv[j], -mi[j]), sg[j]);
             }
         }
     }
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(512) void bn_act_bwd_fused_kernel(const bf16* dy, l
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float zz = (float)vz[k][j];
-            const float du = (float)vdy[k][j] * act_grad(zz * sc[j] + sh[j], act);
-            o[j] = (bf16)(k1[j] * du - k2[j] - k3[j] * zz);
+            const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
+            o[j] = (bf16)fmaf(-k3[j], zz, fmaf(k1[j], du, -k2[j]));
         }
         *reinterpret_cast<bf16x8*>(dz + mm * ld_dz + cg * 8) = o;
     }
