@@ -392,8 +392,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const long* desc, flo
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
-            float acc = sl[i];
-            for (long s2 = 1; s2 < splits; ++s2) acc += sl[s2 * numel + i];
+            float acc = 0.f;
+            for (long s2 = 0; s2 < splits; s2 += 8) {              // 8 loads in flight, summed in split order
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = s2 + k < splits ? sl[(s2 + k) * numel + i] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (s2 + k < splits) acc += v[k];
+            }
             g[i] += acc;
         }
     }

@@ -747,17 +747,34 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* g, long ld, flo
 // the same partial sums without atomics: block b stores its partial at slab[b * N + c]; ep24_wgrad_reduce folds the
 // gridDim.x "splits" in order (bitwise reproducible bias gradients)
 __global__ __launch_bounds__(256) void colsum_slab_kernel(const bf16* g, long ld, float* slab, long M, int N) {
-    __shared__ float red[256];
-    for (int c0 = 0; c0 < N; c0 += 64) {
-        const int c = c0 + (threadIdx.x & 63);
-        float acc = 0.f;
-        if (c < N)
-            for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) acc += (float)g[m * ld + c];
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x < 64 && c < N)
-            slab[(long)blockIdx.x * N + c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        __syncthreads();
+    // thread = (row lane, 8-column chunk): 16-byte loads, 4 rows in flight, then a fixed-order fold over the row lanes
+    __shared__ float red[256][8 + 1];
+    const int chunks = (N + 7) >> 3;                       // ld >= 8 * chunks (rows are padded to a multiple of 8)
+    const int rpp = 256 / chunks;
+    const int r = threadIdx.x / chunks, c = threadIdx.x - r * chunks;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < rpp) {
+        const long step = (long)gridDim.x * rpp;
+        for (long m = (long)blockIdx.x * rpp + r; m < M; m += 4 * step) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m + k * step < M) v[k] = *reinterpret_cast<const bf16x8*>(g + (m + k * step) * ld + c * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m + k * step < M) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)v[k][j];
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) s += red[rr * chunks + (n >> 3)][n & 7];
+        slab[(long)blockIdx.x * N + n] = s;
     }
 }
 
@@ -1041,12 +1058,13 @@ extern "C" int ep24_head_decode_bwd(const float* dout, const float* out, void* d
 }
 
 extern "C" int ep24_colsum_splits(int64_t M) {
-    long blocks = (M + 3) / 4;
-    return (int)(blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks));
+    long blocks = (M + 3) / 4;                         // few partial rows: the ordered fold reads them one after another
+    return (int)(blocks > 64 ? 64 : (blocks < 1 ? 1 : blocks));
 }
 
 extern "C" int ep24_colsum_slab(const void* g, int64_t ld, float* slab, int64_t M, int N, void* stream) {
-    EP24_REQUIRE(g && slab && N > 0 && M > 0, EP24_E_ARG, "colsum_slab: bad arguments");
+    EP24_REQUIRE(g && slab && N > 0 && N <= 2048 && M > 0 && ld % 8 == 0 && ld >= ((N + 7) / 8) * 8, EP24_E_ARG,
+                 "colsum_slab: bad arguments (rows must be padded to a multiple of 8 columns)");
     hipLaunchKernelGGL(colsum_slab_kernel, dim3((unsigned)ep24_colsum_splits(M)), dim3(256), 0, S_, (const bf16*)g, ld, slab, M, N);
     EP24_LAUNCH_CHECK("ep24_colsum_slab");
     return EP24_OK;
