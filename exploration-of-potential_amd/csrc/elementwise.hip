@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, co
                                                           bf16* wf, bf16* wd) {
     __shared__ int s_first;
     const long total = prefix[n_seg];
-    for (long base = (long)blockIdx.x * 1024; base < total; base += (long)gridDim.x * 1024) {
+    for (long base = (long)blockIdx.x * 4096; base < total; base += (long)gridDim.x * 4096) {
         if (threadIdx.x == 0) {
             int lo = 0, hi = n_seg - 1;
             while (lo < hi) {
@@ -813,15 +813,30 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, co
         int seg = s_first;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const long i = base + threadIdx.x + 256 * k;
+            const long i = base + 4 * (threadIdx.x + 256 * k);       // four consecutive elements per thread
             if (i >= total) break;
             while (i >= prefix[seg + 1]) ++seg;
             const long* d = desc + (long)seg * 8;
             const int e = (int)(i - prefix[seg]);                    // a segment has < 2^31 elements
             const int Cin = (int)d[5], Cin_pad = (int)d[6];
-            long o = e;                                             // Cin == Cin_pad: the forward copy is a pure conversion
-            if (Cin != Cin_pad) o = (long)(e / Cin) * Cin_pad + e % Cin;
-            wf[d[1] + o] = (bf16)flat[d[0] + e];
+            const float* src = flat + d[0] + e;
+            bf16* dst = wf + d[1] + e;
+            if (Cin == Cin_pad && i + 3 < prefix[seg + 1] && (((uintptr_t)src & 15) | ((uintptr_t)dst & 7)) == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(src);   // the forward copy is a pure conversion
+                bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+                for (int j = 0; j < 4 && i + j < total; ++j) {
+                    long ii = i + j;
+                    int sg2 = seg;
+                    while (ii >= prefix[sg2 + 1]) ++sg2;
+                    const long* d2 = desc + (long)sg2 * 8;
+                    const int e2 = (int)(ii - prefix[sg2]);
+                    const int c2 = (int)d2[5], cp2 = (int)d2[6];
+                    const long o2 = c2 == cp2 ? e2 : (long)(e2 / c2) * cp2 + e2 % c2;
+                    wf[d2[1] + o2] = (bf16)flat[d2[0] + e2];
+                }
+            }
         }
         __syncthreads();
     }
@@ -1134,7 +1149,7 @@ extern "C" int ep24_pack_weights_batched(const float* flat, const int64_t* desc,
                                          int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles, void* stream) {
     EP24_REQUIRE(flat && desc && prefix && tile_prefix && w_fwd && w_dgrad && n_seg > 0 && total > 0, EP24_E_ARG,
                  "pack_weights_batched: bad arguments");
-    long blocks = (total + 1023) / 1024;
+    long blocks = (total + 4095) / 4096;
     hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, S_, flat, (const long*)desc,
                        (const long*)prefix, n_seg, (bf16*)w_fwd, (bf16*)w_dgrad);
     hipLaunchKernelGGL(pack_transpose_kernel, dim3((unsigned)(total_tiles > 8192 ? 8192 : total_tiles)), dim3(256), 0, S_, flat,
