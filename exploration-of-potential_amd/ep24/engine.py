@@ -309,6 +309,7 @@ class Engine:
         self.fwd, self.bwd = [], []              # launch lists: (abi name, args)
         self.outputs = None
         self.unit_acts = {}                      # BaseConv module -> (input, raw conv output, activated output)
+        self.fwd_eval = []                       # eval-mode forward (running-statistics BN, sigmoid head): SURVEY 8f N3
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
         self.bwd_gw, self.bwd_rd = [], []        # per backward launch: activation-gradient regions written / the one a BN reduce reads
         # folding pass 1 of the BN backward into the epilogue of the dgrad that completes dy removes 101 of 122 reduce
@@ -335,8 +336,10 @@ class Engine:
     def new_act(self, C, H, W, ld=None):
         return Act(Buf(self.dev, self.B * H * W, ld or C), 0, C, self.B, H, W)
 
-    def _f(self, name, *args):
+    def _f(self, name, *args, ev=None):
+        """Append a forward launch; `ev` = the (name, args) that replaces it in the eval-mode list (default: the same)."""
         self.fwd.append((name, args))
+        self.fwd_eval.append(ev if ev is not None else (name, args))
 
     def _b(self, name, args, writes=(), reads=None):
         self.bwd.append((name, args))
@@ -410,11 +413,11 @@ class Engine:
         # every layer keeps its own dz (the gradient w.r.t. the raw conv output): the weight-gradient lane may lag the
         # main lane by a whole segment without a write-after-read hazard (3.4 GB at -l / B=20; there are 288)
         self.dzbuf = torch.zeros(max(self._dz_elems, 8), dtype=BF16, device=self.dev)
-        fw, bw = [], []
-        for lst, out in ((self.fwd, fw), (self.bwd, bw)):
+        fw, bw, fe = [], [], []
+        for lst, out in ((self.fwd, fw), (self.bwd, bw), (self.fwd_eval, fe)):
             for name, args in lst:
                 out.append((name, tuple(a() if callable(a) else a for a in args)))   # Dyn stays for run time
-        self.fwd, self.bwd = fw, bw
+        self.fwd, self.bwd, self.fwd_eval = fw, bw, fe
 
     def _fuse_reduce_into_dgrad(self):
         """Pass 1 of a layer's BN backward (the per-channel sums over dy) moves into the epilogue of the input-gradient
@@ -495,11 +498,15 @@ class Engine:
         bn = mod.bn
         flat, gflat = home.flat, home.gflat
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
-        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s)
+        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s,
+                ev=("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s)))
+        res_p = residual.ptr() if residual is not None else None
+        res_ld = residual.ld if residual is not None else 0
         self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
                 ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld,
-                residual.ptr() if residual is not None else None, residual.ld if residual is not None else 0,
-                M, cout, float(bn.eps), float(bn.momentum), 1)
+                res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), 1,
+                ev=("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
+                                     ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), 1)))
         if residual is not None:
             residual.alias_grad(out)
         self.unit_acts[mod] = (x, z, out)
@@ -608,7 +615,8 @@ class Engine:
                 ptr(flat, ro_b.off), None, 1, B, H, W, hch, 27, 1, 1)
         self._f("conv_fwd_bf16", cf.ptr(), cf.ld, ptr(home.wf, cl_seg.wf_off), ptr(out, 27), self.ncols, 1, self.A, a0,
                 ptr(flat, cl_b.off), None, 1, B, H, W, hch, C, 1, 1)
-        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols)
+        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols,
+                ev=("head_decode_eval", (ptr(out), B, self.A, a0, H, W, s, self.ncols)))
         ldc = _r8(C)
         d_ro = torch.zeros(M * 32, dtype=BF16, device=self.dev)
         d_cl = torch.zeros(M * ldc, dtype=BF16, device=self.dev)
@@ -725,6 +733,15 @@ class Engine:
         self._run(self.fwd)
         return self.outputs
 
+    def forward_eval(self, images=None):
+        """Eval-mode forward (BatchNorm with running statistics, sigmoid on obj / class): decoded [B,A,27+C] fp32, the
+        tensor the reference's YOLOXHead returns with decode_in_inference (yolo_head_24p.py:190-210)."""
+        if images is not None:
+            self.images.copy_(images)
+        self.home.pack()
+        self._run(self.fwd_eval)
+        return self.outputs
+
     def backward(self, dout):
         """Accumulates parameter gradients into the flat gradient buffer; dout [B,A,27+C] fp32 contiguous."""
         self.dyn["dout"] = dout.data_ptr()
@@ -733,8 +750,12 @@ class Engine:
     # ---- nn.Module / autograd entry -----------------------------------------------------------------
     def run_module_forward(self, x, train):
         if not train:
-            raise NotImplementedError("eval-mode decode/NMS is the next hot-path row (SURVEY.md 8f N3); "
-                                      "this build implements the training path")
+            # inference (show_24p.py): the reference calls model.eval() first, so BatchNorm uses its running statistics
+            if self.model.training:
+                raise NotImplementedError("ep24: model(x, train=False) on a model in training mode (batch-statistics BN with "
+                                          "the eval head) is not implemented - call model.eval() first, as show_24p.py does")
+            with torch.no_grad():
+                return self.forward_eval(x).clone()
         out = _NetFn.apply(x, self, *list(self.home.views.keys()))
         return self.x_shifts, self.y_shifts, self.exp_strides, out, []
 

@@ -1,4 +1,5 @@
-"""The slice of the reference's ``utils`` package the 24p training path uses: ``bboxes_iou`` (utils/boxes.py:166-243),
+"""The slice of the reference's ``utils`` package the 24p path uses: ``bboxes_iou`` (utils/boxes.py:166-243),
+``postprocess`` (utils/boxes.py:29-99),
 ``save_checkpoint`` / ``load_ckpt`` (utils/checkpoint.py:11-43) and the ``yoloxwarmcos`` schedule
 (utils/lr_scheduler.py:121-148)."""
 import math
@@ -8,6 +9,7 @@ import shutil
 import _path  # noqa: F401
 import torch
 from ep24.loss import bboxes_iou  # noqa: F401
+from ep24.infer import postprocess  # noqa: F401      (utils/boxes.py:29-99)
 
 
 def save_checkpoint(state, is_best, save_dir, model_name=""):

@@ -259,6 +259,31 @@ int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int 
 int ep24_sector_warp_u8(const uint8_t* src, int sh, int sw, const int32_t* winner, int canvas_w, int y0, int x0,
                         int out_h, int out_w, int T, int n_ang, uint8_t* dst, int fill, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N3  inference path: eval-mode network + postprocess
+ * ------------------------------------------------------------------------------------------------ */
+/* BaseConv in eval mode (network_blocks.py:50-51 with BatchNorm2d.eval()): y = act(z*scale + shift) (+ residual),
+ * scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale. */
+int ep24_bn_act_infer(const void* z, int64_t ld_z, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, void* y, int64_t ld_y, const void* residual, int64_t ld_res,
+                      int64_t M, int C, float eps, int act, void* stream);
+/* eval head (yolo_head_24p.py:190-191, 239-256): decode xy / radii in place and apply sigmoid to obj and class logits. */
+int ep24_head_decode_eval(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream);
+/* postprocess (utils/boxes.py:29-99) in three launches.  prepare: per row best class (first maximum), class_conf,
+ * score = obj*class_conf or -1 when below conf_thre, bounding rectangle of the 24 points (with the reference's
+ * theta*cos(theta) factors, passed in as the host computes them).  nms: per image (one workgroup) candidates sorted by score (ties: lower row first), greedy
+ * suppression of IoU > nms_thre within a class (torchvision batched_nms) or across classes (class_agnostic); keep
+ * [B][A] receives the kept rows in order, keep_count[B] their number; sort_key / sort_idx / dead are [B][P] scratch,
+ * P a power of two >= A.  gather: det[n][29] = (pred[:, :27], class_conf, class_pred) of one image's kept rows. */
+int ep24_post_prepare(const float* pred, int ncols, int num_classes, int64_t n_rows, float conf_thre,
+                      const float* ray_factors /* [48]: theta_k*cos(theta_k), then theta_k*sin(theta_k) */, float* score,
+                      float* conf, int32_t* cls, float* rect, void* stream);
+int ep24_post_nms(const float* score, const int32_t* cls, const float* rect, int B, int A, float nms_thre,
+                  int class_agnostic, float* sort_key, int32_t* sort_idx, uint8_t* dead, int32_t* keep,
+                  int32_t* keep_count, int P, void* stream);
+int ep24_post_gather(const float* pred, int ncols, const float* conf, const int32_t* cls, const int32_t* keep, int n,
+                     float* det, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

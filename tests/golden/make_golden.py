@@ -407,9 +407,36 @@ def _sector_rows(theta, h, w):
     return int(got["dsize"][1])
 
 
+def gen_post(utils, models):
+    # G9: postprocess (utils/boxes.py:29-99) with the oracle's NMS standing in for the absent torchvision ops
+    sys.path.insert(0, ROOT)
+    from oracle import post as opost
+    tv_ops = sys.modules["torchvision.ops"]
+    tv_ops.nms = opost.nms
+    tv_ops.batched_nms = opost.batched_nms
+    sys.modules["torchvision"].ops = tv_ops
+    for tag, agnostic in (("a", False), ("b", True)):
+        raw = synth.make_raw_head(3, seed=90, num_classes=80)
+        pred = synth.decode_head(raw)
+        gq = torch.Generator().manual_seed(91)
+        pred[..., 26:] = torch.sigmoid(raw[..., 26:] + 4.5 + torch.randn(raw[..., 26:].shape, generator=gq))
+        pred[2, :, 26] = 0.0                                   # an image where nothing passes the confidence filter
+        # the reference re-binds cos_theta_all inside its image loop (boxes.py:64-65) and raises on the second image that
+        # has detections, so it is run one image at a time (show_24p.py uses batch 1)
+        outs = [utils.postprocess(pred[i:i + 1].clone(), 80, conf_thre=0.7, nms_thre=0.45, class_agnostic=agnostic)[0]
+                for i in range(3)]
+        store = {"head_seed": 90, "noise_seed": 91, "agnostic": int(agnostic), "n_img": 3}
+        for i, o in enumerate(outs):
+            store["img%d_n" % i] = -1 if o is None else o.shape[0]
+            if o is not None:
+                store["img%d_det" % i] = o
+        save("g9_postprocess_" + tag, **store)
+
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -419,3 +446,5 @@ if __name__ == "__main__":
         gen_model(utils, models)
     if "sector" in which:
         gen_sector()
+    if "post" in which:
+        gen_post(utils, models)
