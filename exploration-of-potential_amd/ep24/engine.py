@@ -317,6 +317,11 @@ class Engine:
         # the streaming kernel it replaces: +3.2 ms dgrad vs -2.8 ms reduce at YOLOX-l / B=20.  Experiment switch.
         self.fuse_bn_reduce = os.environ.get("EP24_BNR") == "1"
         self._bwd_units = 0
+        self._cur_tag = None
+        self._force_side = False
+        self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
+        self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
+        self.parallel_head = os.environ.get("EP24_NO_PAR_HEAD") != "1"
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
         self._side = None
@@ -342,6 +347,8 @@ class Engine:
         self.fwd_eval.append(ev if ev is not None else (name, args))
 
     def _b(self, name, args, writes=(), reads=None):
+        if self._force_side and name[0] != "@" and not name.startswith("side:"):
+            name = "side:" + name
         self.bwd.append((name, args))
         self.bwd_writes.append([(seg.off, seg.numel) for seg in writes])
         self.bwd_gw.append(list(_PENDING_GW))        # activation-gradient regions this entry writes
@@ -387,6 +394,7 @@ class Engine:
         self.levels = []
         for k, feat in enumerate((pan_out2, pan_out1, pan_out0)):
             self.head_level(head, k, feat, a0)
+            self._cur_tag = None
             a0 += feat.H * feat.W
         # anchor tables of the train-mode tuple (yolo_head_24p.py:172-176)
         self.x_shifts, self.y_shifts, self.exp_strides = [], [], []
@@ -402,8 +410,27 @@ class Engine:
         # scratch shared by all layers (single stream => no overlap in time)
         self.stats = torch.zeros(max(sum(self._stats_specs), 4), dtype=torch.int64, device=self.dev)
         self.bnsums = torch.zeros(max(sum(self._sum_specs), 4), dtype=torch.int64, device=self.dev)
+        # The backward of head levels 1 and 2 (40x40 and 20x20: kernels that leave most of the chip idle) depends on
+        # nothing but the loss gradient, and nothing needs its results before the PAFPN backward: all of it goes to the
+        # weight-gradient lane, where it runs next to the level-0 chain of the main lane; the main lane joins before
+        # the first trunk entry.
+        in_head = False
         for b in reversed(self._bwd_builders):
+            tag = getattr(b, "tag", None)
+            is_head = tag is not None and tag[0] == "head"
+            if self.parallel_head:
+                if in_head and not is_head:
+                    self._b("@main_wait_side", ("all",))
+                    self.bwd_join = len(self.bwd)
+                want = is_head and tag[1] >= 1
+                if want and not self._force_side:
+                    self._b("@side_wait_main", ())
+                if self._force_side and not want:
+                    self.bwd_par_end = len(self.bwd)
+                self._force_side = want
+            in_head = is_head
             b()
+        self._force_side = False
         self._flush_reduce()
         del _PENDING_GW[:]
         self.bn_reduce_fused = 0
@@ -449,6 +476,10 @@ class Engine:
         self.bn_reduce_fused = len(drop)
         for lst in ("bwd", "bwd_writes", "bwd_gw", "bwd_rd"):
             setattr(self, lst, [v for i, v in enumerate(getattr(self, lst)) if i not in drop])
+
+    def _add_builder(self, fn):
+        fn.tag = self._cur_tag                    # which part of the network registered it (head level k / trunk)
+        self._bwd_builders.append(fn)
 
     def _flush_reduce(self):
         """One reduce launch (side stream, behind the weight-gradient kernels it sums) for the pending layers."""
@@ -549,7 +580,7 @@ class Engine:
                 self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
                                             seg.cout_pad, k_, s))
 
-        self._bwd_builders.append(build_bwd)
+        self._add_builder(build_bwd)
         return out
 
     def csp(self, mod, x, out=None):
@@ -582,7 +613,7 @@ class Engine:
             self._b("spp_bwd", (y5.gptr(), y9.gptr(), y13.gptr(), y5.gld, ptr(idx), t.gptr(), t.gld, acc,
                                 t.B, t.H, t.W, h))
 
-        self._bwd_builders.append(build_bwd)
+        self._add_builder(build_bwd)
         return self.unit(mod.conv2, cat)
 
     def up2(self, x, y):
@@ -593,13 +624,14 @@ class Engine:
             acc = x.gwrite()
             self._b("upsample2_bwd", (y.gptr(), y.gld, x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
 
-        self._bwd_builders.append(build_bwd)
+        self._add_builder(build_bwd)
 
     def head_level(self, head, k, feat, a0):
         """stem -> {cls branch -> cls_preds, reg branch -> reg_preds + obj_preds} -> decode (yolo_head_24p.py:150-189)."""
         home, B, C = self.home, self.B, self.C
         H, W, s = feat.H, feat.W, float(head.strides[k])
         self.levels.append((H, W, s))
+        self._cur_tag = ("head", k)
         x = self.unit(head.stems[k], feat)
         cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x))
         rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x))
@@ -646,7 +678,7 @@ class Engine:
             self._b("conv_dgrad_bf16", (ptr(d_cl), ldc, ptr(home.wd, cl_seg.wd_off), cf.gptr(), cf.gld, cf.gwrite(), B, H,
                                         W, hch, ldc, 1, 1))
 
-        self._bwd_builders.append(build_bwd)
+        self._add_builder(build_bwd)
 
     # ---- execution ----------------------------------------------------------------------------------
     def _run(self, lst):
@@ -681,9 +713,13 @@ class Engine:
                     ev.record(side)
                     events[args[0]] = ev
                 elif name == "@main_wait_side":
-                    ev = events.get(args[0])
-                    if ev is not None:
-                        main.wait_event(ev)
+                    if args[0] == "all":
+                        if used_side:
+                            main.wait_stream(side)
+                    else:
+                        ev = events.get(args[0])
+                        if ev is not None:
+                            main.wait_event(ev)
                 continue
             s = s_main
             if name.startswith("side:"):

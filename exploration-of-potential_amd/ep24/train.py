@@ -118,6 +118,11 @@ class TrainStep:
             rc = self.reducer.cuts(self.eng)
             cuts |= set(rc)
             ready = {c: i for i, c in enumerate(rc[1:])}          # cut index -> reducer segment that ends there
+        join = self.eng.bwd_join
+        if join is not None:                                   # head levels 1, 2 run on the side lane up to here
+            cuts.add(join)
+            if self.eng.bwd_par_end:
+                cuts.add(self.eng.bwd_par_end)
         cuts = sorted(cuts)
         return list(zip(cuts[:-1], cuts[1:])), ready
 
@@ -158,7 +163,7 @@ class TrainStep:
                 main, side = eng.lane_lists(lo, hi)
                 gm = capture(lambda: eng.run_lane(main)) if main else None
                 gs = capture(lambda: eng.run_lane(side)) if side else None
-                self.g_bwd.append((gm, gs, ready.get(hi)))
+                self.g_bwd.append((gm, gs, ready.get(hi), lo == eng.bwd_join))
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
         self.graphs = True
@@ -181,7 +186,9 @@ class TrainStep:
         self.g_fwd.replay()
         if self.g_bwd is not None:
             main, side = torch.cuda.current_stream(), self._side
-            for gm, gs, ready in self.g_bwd:
+            for gm, gs, ready, join in self.g_bwd:
+                if join:
+                    main.wait_stream(side)                 # the head levels that ran on the side lane
                 if gm is not None:
                     gm.replay()
                 ev = torch.cuda.Event()
