@@ -319,6 +319,7 @@ class Engine:
         self._bwd_units = 0
         self._cur_tag = None
         self._force_side = False
+        self._deferred = []
         self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
         self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
         self.parallel_head = os.environ.get("EP24_NO_PAR_HEAD") != "1"
@@ -427,10 +428,17 @@ class Engine:
                     self._b("@side_wait_main", ())
                 if self._force_side and not want:
                     self.bwd_par_end = len(self.bwd)
+                    self._force_side = False
+                    for f in self._deferred:              # the weight gradients of the side-lane chains: after the chains
+                        f()
+                    self._deferred = []
                 self._force_side = want
             in_head = is_head
             b()
         self._force_side = False
+        for f in self._deferred:
+            f()
+        self._deferred = []
         self._flush_reduce()
         del _PENDING_GW[:]
         self.bn_reduce_fused = 0
@@ -562,19 +570,28 @@ class Engine:
                                              dz, cout, M, cout, 1), writes=(gam, bet))
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
-            self._b("@side_wait_main", ())
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
             # few layers folds them into the flat gradient in a fixed order (no atomics: bitwise reproducible)
             splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k_, s)
             assert splits >= 1, splits
             soff = self._slab_floats
             self._slab_floats += splits * seg.numel
-            self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, cout, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
-                                                  splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k_, s))
-            self._b("@side_record", (k,))
-            self._pending_reduce.append((seg, splits, soff))
-            if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
-                self._flush_reduce()
+
+            def emit_wgrad():
+                self._b("@side_wait_main", ())
+                self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, cout, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
+                                                      splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k_, s))
+                self._b("@side_record", (k,))
+                self._pending_reduce.append((seg, splits, soff))
+                if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
+                    self._flush_reduce()
+
+            # inside the head levels that run on the side lane the weight gradients wait until the chain is through, so
+            # that the main lane's join is not held up by work nothing depends on (every layer owns its dz)
+            if self._force_side:
+                self._deferred.append(emit_wgrad)
+            else:
+                emit_wgrad()
             if x.needs_grad:
                 acc = x.gwrite()
                 self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
@@ -658,21 +675,28 @@ class Engine:
             self._b("head_decode_bwd", (dout, ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols))
             # bias and weight gradients of the prediction convs: side lane, slab partials folded by the next reduce launch
             fn = _lib.lib().fn
-            self._b("@side_wait_main", ())
-            for dsrc, ld_d, bseg, n in ((d_ro, 32, ro_b, 27), (d_cl, ldc, cl_b, C)):
-                sp = fn["ep24_colsum_splits"](M)
-                soff = self._slab_floats
-                self._slab_floats += sp * n + (-(sp * n)) % 4
-                self._b("side:colsum_slab", (ptr(dsrc), ld_d, (lambda soff=soff: self.slab.data_ptr() + 4 * soff), M, n))
-                self._pending_reduce.append((bseg, sp, soff))
-            for feat_in, dsrc, ld_d, wseg, n, npad in ((rf, d_ro, 32, ro_seg, 27, 32), (cf, d_cl, ldc, cl_seg, C, ldc)):
-                sp = fn["ep24_conv_wgrad_splits"](B, H, W, hch, npad, 1, 1)
-                soff = self._slab_floats
-                self._slab_floats += sp * wseg.numel
-                self._b("side:conv_wgrad_slab_bf16", (feat_in.ptr(), feat_in.ld, ptr(dsrc), ld_d,
-                                                      (lambda soff=soff: self.slab.data_ptr() + 4 * soff), sp * wseg.numel, hch, n, hch,
-                                                      B, H, W, hch, npad, 1, 1))
-                self._pending_reduce.append((wseg, sp, soff))
+
+            def emit_pred_grads():
+                self._b("@side_wait_main", ())
+                for dsrc, ld_d, bseg, n in ((d_ro, 32, ro_b, 27), (d_cl, ldc, cl_b, C)):
+                    sp = fn["ep24_colsum_splits"](M)
+                    soff = self._slab_floats
+                    self._slab_floats += sp * n + (-(sp * n)) % 4
+                    self._b("side:colsum_slab", (ptr(dsrc), ld_d, (lambda soff=soff: self.slab.data_ptr() + 4 * soff), M, n))
+                    self._pending_reduce.append((bseg, sp, soff))
+                for feat_in, dsrc, ld_d, wseg, n, npad in ((rf, d_ro, 32, ro_seg, 27, 32), (cf, d_cl, ldc, cl_seg, C, ldc)):
+                    sp = fn["ep24_conv_wgrad_splits"](B, H, W, hch, npad, 1, 1)
+                    soff = self._slab_floats
+                    self._slab_floats += sp * wseg.numel
+                    self._b("side:conv_wgrad_slab_bf16", (feat_in.ptr(), feat_in.ld, ptr(dsrc), ld_d,
+                                                          (lambda soff=soff: self.slab.data_ptr() + 4 * soff), sp * wseg.numel, hch, n, hch,
+                                                          B, H, W, hch, npad, 1, 1))
+                    self._pending_reduce.append((wseg, sp, soff))
+
+            if self._force_side:
+                self._deferred.append(emit_pred_grads)
+            else:
+                emit_pred_grads()
             self._b("conv_dgrad_bf16", (ptr(d_ro), 32, ptr(home.wd, ro_seg.wd_off), rf.gptr(), rf.gld, rf.gwrite(), B, H,
                                         W, hch, 32, 1, 1))
             self._b("conv_dgrad_bf16", (ptr(d_cl), ldc, ptr(home.wd, cl_seg.wd_off), cf.gptr(), cf.gld, cf.gwrite(), B, H,

@@ -107,7 +107,7 @@ class TrainStep:
         segments are short (what is left of the lane after the main lane has finished is exposed); with a reducer its
         bucket boundaries are cut points too."""
         n = len(self.eng.bwd)
-        fr = (0.12, 0.24, 0.36, 0.48, 0.58, 0.68, 0.76, 0.83, 0.89, 0.93, 0.96, 0.98)
+        fr = (0.12, 0.24, 0.36, 0.48, 0.58, 0.68, 0.76, 0.83, 0.89, 0.93, 0.96, 0.98, 0.99, 0.995)
         import os
         if os.environ.get("EP24_BWD_CUTS"):
             e = os.environ["EP24_BWD_CUTS"]
@@ -163,7 +163,8 @@ class TrainStep:
                 main, side = eng.lane_lists(lo, hi)
                 gm = capture(lambda: eng.run_lane(main)) if main else None
                 gs = capture(lambda: eng.run_lane(side)) if side else None
-                self.g_bwd.append((gm, gs, ready.get(hi), lo == eng.bwd_join))
+                par = eng.bwd_par_end is not None and hi <= eng.bwd_par_end      # a segment that runs on the side lane only
+                self.g_bwd.append((gm, gs, ready.get(hi), lo == eng.bwd_join, par))
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
         self.graphs = True
@@ -186,19 +187,40 @@ class TrainStep:
         self.g_fwd.replay()
         if self.g_bwd is not None:
             main, side = torch.cuda.current_stream(), self._side
-            for gm, gs, ready, join in self.g_bwd:
-                if join:
-                    main.wait_stream(side)                 # the head levels that ran on the side lane
-                if gm is not None:
-                    gm.replay()
-                ev = torch.cuda.Event()
-                ev.record(main)
+            # Host order matters: a graph launch into a stream that is still waiting on an event can hold the host, so
+            # the main lane's graph of segment i+1 is enqueued BEFORE the side lane's graph of segment i.
+            pending, par_done = None, None
+
+            def launch_side(p):
+                gs, ready, ev, par = p
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     if gs is not None:
                         gs.replay()
                     if ready is not None:
                         self.reducer.bucket_ready(ready)      # recorded on the side lane: it has waited for the main one
+                if par:
+                    e2 = torch.cuda.Event()
+                    e2.record(side)
+                    return e2
+                return None
+
+            for gm, gs, ready, join, par in self.g_bwd:
+                if join:
+                    if pending is not None:
+                        par_done = launch_side(pending) or par_done
+                        pending = None
+                    if par_done is not None:
+                        main.wait_event(par_done)          # the head levels that ran on the side lane (not its later work)
+                if gm is not None:
+                    gm.replay()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                if pending is not None:
+                    par_done = launch_side(pending) or par_done
+                pending = (gs, ready, ev, par)
+            if pending is not None:
+                launch_side(pending)
             main.wait_stream(side)
         else:
             for i, (lo, hi) in enumerate(zip(self._cuts[:-1], self._cuts[1:])):
