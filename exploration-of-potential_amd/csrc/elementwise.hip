@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const bf16* src, long ld
 
 // ---------------------------------------------------------------------------------------- head decode
 __global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int A, int a0, int H, int W, float s,
-                                                         int ncols) {
+                                                         int ncols, float* origin) {
     const long total = (long)B * H * W * 26;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % 26);
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int 
         const int hw = (int)(cell - (long)n * H * W);
         float* p = out + ((long)n * A + a0 + hw) * ncols + c;
         const float t = *p;
+        if (origin) origin[((long)n * A + a0 + hw) * 26 + c] = t;
         float v;
         if (c == 0) v = (t + (float)(hw % W)) * s;
         else if (c == 1) v = (t + (float)(hw / W)) * s;
@@ -693,7 +694,8 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int 
 }
 
 __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* dout, const float* out, bf16* d_regobj, bf16* d_cls,
-                                                         int B, int A, int a0, int H, int W, float s, int ncols) {
+                                                         int B, int A, int a0, int H, int W, float s, int ncols,
+                                                         const float* d_origin) {
     // one thread per (cell, 8-column chunk): 4 chunks of the 32-wide reg+obj gradient, then ceil(C/8) class chunks
     const int C = ncols - 27;
     const int ld_cls = (C + 7) & ~7;
@@ -714,6 +716,7 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* dout, cons
                 if (c < 2) g = dout[row + c] * s;
                 else if (c < 26) g = dout[row + c] * out[row + c];      // d exp(t)*s / dt = r
                 else if (c == 26) g = dout[row + 26];
+                if (d_origin && c < 26) g += d_origin[((long)n * A + a0 + hw) * 26 + c];
                 o[j] = (bf16)g;
             }
             *reinterpret_cast<bf16x8*>(d_regobj + cell * 32 + chunk * 8) = o;
@@ -884,9 +887,16 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* flat, 
     }
 }
 
+// ModelEMA.update on one element (utils/ema.py:57-60): v *= d; v += (1 - d) * p - two rounded products and a rounded sum
+__device__ __forceinline__ float ema_step(float e, float pnew, float d, float omd) {
+    return __fadd_rn(__fmul_rn(e, d), __fmul_rn(omd, pnew));
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float mom,
-                                                  float gscale, const int* first_flag) {
+                                                  float gscale, const int* first_flag, const float* hp, float* ema) {
     const int first = *first_flag;
+    float d = 0.f, omd = 0.f;
+    if (hp) { lr = hp[0]; mom = hp[1]; gscale = hp[2]; d = hp[3]; omd = hp[4]; }
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 3 < n) {
             f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
@@ -900,15 +910,31 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
             }
             *reinterpret_cast<f32x4*>(buf + i) = bv;
             *reinterpret_cast<f32x4*>(p + i) = pv;
+            if (ema) {
+                f32x4 ev = *reinterpret_cast<const f32x4*>(ema + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ev[j] = ema_step(ev[j], pv[j], d, omd);
+                *reinterpret_cast<f32x4*>(ema + i) = ev;
+            }
         } else {
             for (long k = i; k < n; ++k) {
                 const float gg = g[k] * gscale;
                 const float b = first ? gg : mom * buf[k] + gg;
                 buf[k] = b;
                 p[k] -= lr * (gg + mom * b);
+                if (ema) ema[k] = ema_step(ema[k], p[k], d, omd);
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* ema, const float* src, long n, float d, float omd, const float* hp) {
+    if (hp) { d = hp[3]; omd = hp[4]; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) ema[i] = ema_step(ema[i], src[i], d, omd);
+}
+
+__global__ void set_hparams_kernel(float* hp, float lr, float mom, float gscale, float d, float omd) {
+    hp[0] = lr; hp[1] = mom; hp[2] = gscale; hp[3] = d; hp[4] = omd;
 }
 __global__ void clear_flag_kernel(int* f) { *f = 0; }
 
@@ -1055,19 +1081,20 @@ extern "C" int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_
     return EP24_OK;
 }
 
-extern "C" int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream) {
+extern "C" int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, float* origin,
+                                    void* stream) {
     EP24_REQUIRE(out && a0 >= 0 && a0 + H * W <= A && ncols >= 27, EP24_E_ARG, "head_decode_fwd: bad arguments");
-    hipLaunchKernelGGL(decode_fwd_kernel, dim3(cap_grid((long)B * H * W * 26)), dim3(256), 0, S_, out, B, A, a0, H, W, stride, ncols);
+    hipLaunchKernelGGL(decode_fwd_kernel, dim3(cap_grid((long)B * H * W * 26)), dim3(256), 0, S_, out, B, A, a0, H, W, stride, ncols, origin);
     EP24_LAUNCH_CHECK("ep24_head_decode_fwd");
     return EP24_OK;
 }
 
 extern "C" int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
-                                    int H, int W, float stride, int ncols, void* stream) {
+                                    int H, int W, float stride, int ncols, const float* d_origin, void* stream) {
     EP24_REQUIRE(dout && out && d_regobj && d_cls && a0 >= 0 && a0 + H * W <= A && ncols > 27, EP24_E_ARG,
                  "head_decode_bwd: bad arguments");
     hipLaunchKernelGGL(decode_bwd_kernel, dim3(cap_grid((long)B * H * W * (4 + (ncols - 27 + 7) / 8))), dim3(256), 0, S_, dout, out, (bf16*)d_regobj,
-                       (bf16*)d_cls, B, A, a0, H, W, stride, ncols);
+                       (bf16*)d_cls, B, A, a0, H, W, stride, ncols, d_origin);
     EP24_LAUNCH_CHECK("ep24_head_decode_bwd");
     return EP24_OK;
 }
@@ -1108,9 +1135,36 @@ extern "C" int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n
                                  int32_t* first_flag, void* stream) {
     EP24_REQUIRE(p && g && buf && first_flag && n > 0, EP24_E_ARG, "sgd_nesterov: bad arguments");
     EP24_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) % 16 == 0, EP24_E_ARG, "sgd_nesterov: 16-byte alignment");
-    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p, g, buf, n, lr, momentum, grad_scale, first_flag);
+    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p, g, buf, n, lr, momentum, grad_scale, first_flag,
+                       (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
     EP24_LAUNCH_CHECK("ep24_sgd_nesterov");
+    return EP24_OK;
+}
+
+extern "C" int ep24_sgd_nesterov_hp(float* p, const float* g, float* buf, int64_t n, const float* hp, int32_t* first_flag,
+                                    float* ema, void* stream) {
+    EP24_REQUIRE(p && g && buf && hp && first_flag && n > 0, EP24_E_ARG, "sgd_nesterov_hp: bad arguments");
+    EP24_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf | (uintptr_t)ema) % 16 == 0, EP24_E_ARG, "sgd_nesterov_hp: 16-byte alignment");
+    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p, g, buf, n, 0.f, 0.f, 0.f, first_flag, hp, ema);
+    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
+    EP24_LAUNCH_CHECK("ep24_sgd_nesterov_hp");
+    return EP24_OK;
+}
+
+extern "C" int ep24_ema_update(float* ema, const float* src, int64_t n, float decay, float one_minus_decay, const float* hp,
+                               void* stream) {
+    EP24_REQUIRE(ema && src && n > 0, EP24_E_ARG, "ema_update: bad arguments");
+    hipLaunchKernelGGL(ema_kernel, dim3(cap_grid(n)), dim3(256), 0, S_, ema, src, n, decay, one_minus_decay, hp);
+    EP24_LAUNCH_CHECK("ep24_ema_update");
+    return EP24_OK;
+}
+
+extern "C" int ep24_set_hparams(float* hp, float lr, float momentum, float grad_scale, float ema_decay, float one_minus_decay,
+                                void* stream) {
+    EP24_REQUIRE(hp, EP24_E_ARG, "set_hparams: null pointer");
+    hipLaunchKernelGGL(set_hparams_kernel, dim3(1), dim3(1), 0, S_, hp, lr, momentum, grad_scale, ema_decay, one_minus_decay);
+    EP24_LAUNCH_CHECK("ep24_set_hparams");
     return EP24_OK;
 }
 

@@ -11,21 +11,32 @@ namespace {
 
 constexpr int G_MAX = EP24_MAX_GT;
 constexpr int LCOLS = EP24_LABEL_COLS;
-constexpr int NS = EP24_NUM_SUMS;          // 0..23 iou, 24 obj, 25 cls, 26 num_fg
+constexpr int NS = EP24_NUM_SUMS;          // 0..23 iou, 24 obj, 25 cls, 26 num_fg, 27 l1 (use_l1 only)
+constexpr int NACC = 28;
 
 __device__ __forceinline__ float bce_logits(float x, float y) {
     return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
 }
 
+// get_l1_target (losses.py:594-604) for one matched anchor: [cx/s - x_shift, cy/s - y_shift, log(|p_k|/s + 1e-8)]
+// where p_k is the k-th contour POINT (absolute image coordinates, gt[:, 2::2] / gt[:, 3::2]) - as the reference has it.
+__device__ __forceinline__ float l1_target(const float* lab, int c, float s, float xsh, float ysh) {
+    if (c == 0) return lab[1] / s - xsh;
+    if (c == 1) return lab[2] / s - ysh;
+    const float px = lab[3 + 2 * (c - 2)], py = lab[4 + 2 * (c - 2)];
+    return logf(sqrtf(px * px + py * py) / s + 1e-8f);
+}
+
 __global__ __launch_bounds__(256) void loss_terms_kernel(const float* outputs, int ncols, const float* labels,
                                                          const int* matched_gt, const float* matched_iou, float* partials,
-                                                         int A, int C) {
+                                                         int A, int C, const float* origin, const float* xs,
+                                                         const float* ys, const float* strides) {
     __shared__ float red[4][NS];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
-    float acc[27];
+    float acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
     if (a < A) {
         const float* o = outputs + ((long)b * A + a) * ncols;
         const int g = matched_gt[(long)b * A + a];
@@ -46,18 +57,25 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(const float* outputs, i
             for (int c = 0; c < C; ++c) s += bce_logits(o[27 + c], c == cls ? piou : 0.f);
             acc[25] = s;
             acc[26] = 1.f;
+            if (origin) {                                     // losses.py:304-307: |origin_preds - l1_target| over 26 columns
+                const float* og = origin + ((long)b * A + a) * 26;
+                const float st = strides[a], xsh = xs[a], ysh = ys[a];
+                float l1 = 0.f;
+                for (int c = 0; c < 26; ++c) l1 += fabsf(og[c] - l1_target(lab, c, st, xsh, ysh));
+                acc[27] = l1;
+            }
         }
     }
     const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 27; ++i) {
+    for (int i = 0; i < NACC; ++i) {
         const float v = wave_sum(acc[i]);
         if ((threadIdx.x & 63) == 0) red[w][i] = v;
     }
     __syncthreads();
     if (threadIdx.x < NS) {
         float v = 0.f;
-        if (threadIdx.x < 27) v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < NACC) v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         partials[((long)b * gridDim.x + blockIdx.x) * NS + threadIdx.x] = v;
     }
 }
@@ -112,8 +130,10 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
         loss += w * l[k];
     }
     const float ow = 26.0f * e[24] / den, cw = 26.0f * e[25] / den;
-    loss = loss + ow * l[24] + cw * l[25] + 0.0f;
+    const float l1 = sums[27] / nfg;                                // losses.py:304-309 (0 without use_l1)
+    loss = loss + ow * l[24] + cw * l[25] + l1;
     result[0] = loss;
+    result[56] = l1;
     result[25] = l[24];
     result[26] = l[25];
     result[27] = nfg;
@@ -126,7 +146,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* outputs, int ncols, const float* labels,
                                                         const int* matched_gt, const float* matched_iou, const float* result,
-                                                        const float* grad_scale, float* dout, int A, int C) {
+                                                        const float* grad_scale, float* dout, int A, int C,
+                                                        const float* origin, const float* xs, const float* ys,
+                                                        const float* strides, float* d_origin) {
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     if (a >= A) return;
@@ -139,9 +161,19 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* outputs, in
     if (g < 0) {
         for (int c = 0; c < 26; ++c) d_o[c] = 0.f;
         for (int c = 27; c < ncols; ++c) d_o[c] = 0.f;
+        if (d_origin)
+            for (int c = 0; c < 26; ++c) d_origin[((long)b * A + a) * 26 + c] = 0.f;
         return;
     }
     const float* lab = labels + ((long)b * G_MAX + g) * LCOLS;
+    if (d_origin) {                                                    // d |x - t| = sign(x - t), unweighted, / num_fg
+        const float* og = origin + ((long)b * A + a) * 26;
+        const float st = strides[a], xsh = xs[a], ysh = ys[a];
+        for (int c = 0; c < 26; ++c) {
+            const float e = og[c] - l1_target(lab, c, st, xsh, ysh);
+            d_origin[((long)b * A + a) * 26 + c] = e > 0.f ? gs : (e < 0.f ? -gs : 0.f);
+        }
+    }
     const float gcx = lab[1], gcy = lab[2];
     const float ddx = gcx - o[0], ddy = gcy - o[1];
     const float d = sqrtf(ddx * ddx + ddy * ddy);
@@ -221,11 +253,13 @@ __global__ __launch_bounds__(256) void matched_bwd_kernel(const float* pred26, c
 extern "C" int ep24_loss_blocks(int B, int A) { return B * ep24_cdiv(A, 256); }
 
 extern "C" int ep24_loss_terms(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
-                               const float* matched_iou, float* partials, int B, int A, int num_classes, void* stream) {
+                               const float* matched_iou, float* partials, int B, int A, int num_classes, const float* origin,
+                               const float* xs, const float* ys, const float* strides, void* stream) {
     EP24_REQUIRE(outputs && labels && matched_gt && matched_iou && partials, EP24_E_ARG, "loss_terms: null pointer");
     EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "loss_terms: ncols=%d != 27+%d", ncols, num_classes);
+    EP24_REQUIRE(!origin || (xs && ys && strides), EP24_E_ARG, "loss_terms: the L1 branch needs the anchor grid");
     hipLaunchKernelGGL(loss_terms_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
-                       matched_gt, matched_iou, partials, A, num_classes);
+                       matched_gt, matched_iou, partials, A, num_classes, origin, xs, ys, strides);
     EP24_LAUNCH_CHECK("ep24_loss_terms");
     return EP24_OK;
 }
@@ -240,11 +274,13 @@ extern "C" int ep24_loss_finalize(const float* partials, int nblocks, const int3
 
 extern "C" int ep24_loss_grad(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
                               const float* matched_iou, const float* result, const float* grad_scale, float* dout, int B, int A,
-                              int num_classes, void* stream) {
+                              int num_classes, const float* origin, const float* xs, const float* ys, const float* strides,
+                              float* d_origin, void* stream) {
     EP24_REQUIRE(outputs && labels && matched_gt && matched_iou && result && dout, EP24_E_ARG, "loss_grad: null pointer");
     EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "loss_grad: ncols=%d != 27+%d", ncols, num_classes);
+    EP24_REQUIRE(!d_origin || (origin && xs && ys && strides), EP24_E_ARG, "loss_grad: the L1 branch needs origin and the anchor grid");
     hipLaunchKernelGGL(loss_grad_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
-                       matched_gt, matched_iou, result, grad_scale, dout, A, num_classes);
+                       matched_gt, matched_iou, result, grad_scale, dout, A, num_classes, origin, xs, ys, strides, d_origin);
     EP24_LAUNCH_CHECK("ep24_loss_grad");
     return EP24_OK;
 }

@@ -195,6 +195,21 @@ class ParamHome:
         self.wf = torch.zeros(max(wf, 8), dtype=BF16, device=dev)
         self.wd = torch.zeros(max(wd, 8), dtype=BF16, device=dev)
         self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
+        # BatchNorm running statistics in one flat buffer too (module buffers become views): ModelEMA averages every
+        # floating-point state_dict entry (utils/ema.py:55-60), i.e. these next to the parameters, in two launches
+        bns = [m.bn for m in exec_order(model) if isinstance(m, enn.BaseConv)]
+        nb = sum((b.num_features + 3) // 4 * 8 for b in bns)
+        self.bflat = torch.zeros(max(nb, 4), dtype=torch.float32, device=dev)
+        self.bnumel = nb
+        o = 0
+        with torch.no_grad():
+            for b in bns:
+                c = b.num_features
+                for name in ("running_mean", "running_var"):
+                    v = self.bflat[o:o + c]
+                    v.copy_(getattr(b, name))
+                    setattr(b, name, v)
+                    o += (c + 3) // 4 * 4
         rows, pref, tpref = [], [0], [0]
         for seg in self.convs:
             rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
@@ -248,6 +263,16 @@ class ParamHome:
     def sgd(self, lr, momentum, grad_scale=1.0):
         call("sgd_nesterov", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), self.numel, float(lr), float(momentum),
              float(grad_scale), ptr(self.first_flag), stream_ptr())
+
+    def sgd_hp(self, hp, ema_home=None):
+        """The same update with lr / momentum / grad_scale (and the EMA decay) read from the device block ``hp``; with
+        ``ema_home`` the EMA copy of the parameters and of the BatchNorm running statistics is advanced as well."""
+        if ema_home is not None and (ema_home.numel, ema_home.bnumel) != (self.numel, self.bnumel):
+            raise _lib.Ep24Error("ep24: the EMA model's parameter layout differs from the trained model's")
+        call("sgd_nesterov_hp", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), self.numel, ptr(hp), ptr(self.first_flag),
+             ptr(ema_home.flat) if ema_home is not None else None, stream_ptr())
+        if ema_home is not None and self.bnumel:
+            call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
 
 
 def exec_order(model):
@@ -333,7 +358,8 @@ class Engine:
         self.fuse_bn_bwd = os.environ.get("EP24_FUSED_BN") == "1"
         self._events = []
         self._bwd_builders = []
-        self.dyn = {}                            # run-time pointers (input images, incoming gradient)
+        self.dyn = {"origin": None, "d_origin": None}   # run-time pointers (incoming gradient, L1-branch buffers)
+        self.origin = None                       # [B,A,26] raw regression outputs, filled while use_l1 is on
         self._stats_specs, self._sum_specs = [], []
         self.max_dz = 0
         self._build()
@@ -664,7 +690,7 @@ class Engine:
                 ptr(flat, ro_b.off), None, 1, B, H, W, hch, 27, 1, 1)
         self._f("conv_fwd_bf16", cf.ptr(), cf.ld, ptr(home.wf, cl_seg.wf_off), ptr(out, 27), self.ncols, 1, self.A, a0,
                 ptr(flat, cl_b.off), None, 1, B, H, W, hch, C, 1, 1)
-        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols,
+        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols, Dyn(self.dyn, "origin"),
                 ev=("head_decode_eval", (ptr(out), B, self.A, a0, H, W, s, self.ncols)))
         ldc = _r8(C)
         d_ro = torch.zeros(M * 32, dtype=BF16, device=self.dev)
@@ -672,7 +698,8 @@ class Engine:
 
         def build_bwd():
             dout = Dyn(self.dyn, "dout")
-            self._b("head_decode_bwd", (dout, ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols))
+            self._b("head_decode_bwd", (dout, ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols,
+                                        Dyn(self.dyn, "d_origin")))
             # bias and weight gradients of the prediction convs: side lane, slab partials folded by the next reduce launch
             fn = _lib.lib().fn
 
@@ -784,6 +811,16 @@ class Engine:
         call("memset_zero", ptr(self.stats), self.stats.numel() * 8, s)
         call("memset_zero", ptr(self.bnsums), self.bnsums.numel() * 8, s)
 
+    def set_use_l1(self, on):
+        """use_l1 of the head (yolo_head_24p.py:179-188): the decode launches also keep the raw regression outputs in
+        self.origin.  Launch lists are unchanged (the pointers are run-time arguments); captured graphs hold the
+        pointer values, so ep24.train re-captures when this flips."""
+        if on and self.origin is None:
+            self.origin = torch.zeros(self.B, self.A, 26, dtype=torch.float32, device=self.dev)
+        self.dyn["origin"] = self.origin.data_ptr() if on else None
+        if not on:
+            self.dyn["d_origin"] = None
+
     def forward(self, images=None):
         """Train-mode forward into self.outputs ([B,A,27+C] fp32, decoded)."""
         if images is not None:
@@ -802,9 +839,11 @@ class Engine:
         self._run(self.fwd_eval)
         return self.outputs
 
-    def backward(self, dout):
-        """Accumulates parameter gradients into the flat gradient buffer; dout [B,A,27+C] fp32 contiguous."""
+    def backward(self, dout, d_origin=None):
+        """Accumulates parameter gradients into the flat gradient buffer; dout [B,A,27+C] fp32 contiguous, d_origin
+        [B,A,26] the gradient of the L1 branch with respect to the raw regression outputs (or None)."""
         self.dyn["dout"] = dout.data_ptr()
+        self.dyn["d_origin"] = None if d_origin is None else d_origin.data_ptr()
         self._run(self.bwd)
 
     # ---- nn.Module / autograd entry -----------------------------------------------------------------
@@ -816,22 +855,33 @@ class Engine:
                                           "the eval head) is not implemented - call model.eval() first, as show_24p.py does")
             with torch.no_grad():
                 return self.forward_eval(x).clone()
-        out = _NetFn.apply(x, self, *list(self.home.views.keys()))
-        return self.x_shifts, self.y_shifts, self.exp_strides, out, []
+        use_l1 = bool(getattr(self.model.head, "use_l1", False))
+        self.set_use_l1(use_l1)
+        out, origin = _NetFn.apply(x, self, use_l1, *list(self.home.views.keys()))
+        origin_preds, a0 = [], 0
+        if use_l1:                                   # per-level [B, H*W, 26] slices, yolo_head_24p.py:179-188
+            for H, W, _ in self.levels:
+                origin_preds.append(origin[:, a0:a0 + H * W])
+                a0 += H * W
+        return self.x_shifts, self.y_shifts, self.exp_strides, out, origin_preds
 
 
 class _NetFn(torch.autograd.Function):
     """The whole network as ONE autograd node: forward / backward are the engine's launch lists."""
 
     @staticmethod
-    def forward(ctx, x, eng, *params):
-        ctx.eng = eng
-        return eng.forward(x.float().contiguous()).clone()
+    def forward(ctx, x, eng, use_l1, *params):
+        ctx.eng, ctx.use_l1 = eng, use_l1
+        out = eng.forward(x.float().contiguous()).clone()
+        origin = eng.origin.clone() if use_l1 else out.new_zeros(0)
+        if not use_l1:
+            ctx.mark_non_differentiable(origin)
+        return out, origin
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, d_origin):
         eng = ctx.eng
         eng.home.bind_grads()
-        eng.backward(dout.contiguous())
+        eng.backward(dout.contiguous(), d_origin.contiguous() if ctx.use_l1 and d_origin is not None else None)
         # parameter gradients were accumulated in place into the flat buffer that every p.grad views
-        return (None, None) + (None,) * len(eng.home.views)
+        return (None, None, None) + (None,) * len(eng.home.views)

@@ -33,10 +33,17 @@ class LossWorkspace:
         self.partials = torch.zeros(self.nblocks, 32, dtype=torch.float32, **z)
         self.result = torch.zeros(RESULT, dtype=torch.float32, **z)
         self.dout = torch.zeros(B, A, NCOLS_BASE + num_classes, dtype=torch.float32, **z)
+        self.d_origin = None                                              # [B,A,26], allocated by the L1 branch
+
+    def l1_grad_buffer(self):
+        if self.d_origin is None:
+            self.d_origin = torch.zeros(self.B, self.A, 26, dtype=torch.float32, device=self.dout.device)
+        return self.d_origin
 
 
-def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state):
-    """Kernels a4..a10 forward: fills ws.matched_* and ws.result; updates `state` (device [26])."""
+def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin=None):
+    """Kernels a4..a10 forward: fills ws.matched_* and ws.result; updates `state` (device [26]).  ``origin`` [B,A,26]
+    (the head's raw regression outputs) switches the L1 branch on (losses.py:197-198, 304-309)."""
     B, A, C = ws.B, ws.A, ws.C
     ncols = NCOLS_BASE + C
     s = stream_ptr()
@@ -49,31 +56,35 @@ def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state):
     call("assign_resolve", ptr(match), ptr(ws.pw), ptr(ws.cost), ptr(ws.num_gt), ptr(ws.matched_gt), ptr(ws.matched_iou),
          B, A, s)
     call("loss_terms", ptr(outputs), ncols, ptr(labels), ptr(ws.matched_gt), ptr(ws.matched_iou), ptr(ws.partials),
-         B, A, C, s)
+         B, A, C, ptr(origin), ptr(xs), ptr(ys), ptr(strides), s)
     call("loss_finalize", ptr(ws.partials), ws.nblocks, ptr(ws.num_gt), B, ptr(state), ptr(ws.result), s)
 
 
-def loss_grad(ws, outputs, labels, grad_scale=None):
-    """d loss / d outputs into ws.dout (fully overwritten)."""
+def loss_grad(ws, outputs, labels, grad_scale=None, origin=None, grid=None):
+    """d loss / d outputs into ws.dout (fully overwritten); with ``origin`` also d loss / d origin into ws.d_origin."""
+    d_origin = ws.l1_grad_buffer() if origin is not None else None
+    xs, ys, strides = grid if grid is not None else (None, None, None)
     call("loss_grad", ptr(outputs), NCOLS_BASE + ws.C, ptr(labels), ptr(ws.matched_gt), ptr(ws.matched_iou),
-         ptr(ws.result), ptr(grad_scale), ptr(ws.dout), ws.B, ws.A, ws.C, stream_ptr())
+         ptr(ws.result), ptr(grad_scale), ptr(ws.dout), ws.B, ws.A, ws.C, ptr(origin), ptr(xs), ptr(ys), ptr(strides),
+         ptr(d_origin), stream_ptr())
     return ws.dout
 
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, labels, xs, ys, strides, ws, state):
-        assign_and_reduce(ws, outputs, labels, xs, ys, strides, state)
+    def forward(ctx, outputs, labels, xs, ys, strides, ws, state, origin):
+        assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin)
         ctx.ws = ws
-        ctx.save_for_backward(outputs, labels)
+        ctx.l1 = origin is not None
+        ctx.save_for_backward(outputs, labels, xs, ys, strides, origin)
         return ws.result.clone()
 
     @staticmethod
     def backward(ctx, g):
-        outputs, labels = ctx.saved_tensors
+        outputs, labels, xs, ys, strides, origin = ctx.saved_tensors
         # only element 0 (the weighted total) carries gradient; 1..3 are reported values
-        dout = loss_grad(ctx.ws, outputs, labels, g[0:1].contiguous())
-        return dout, None, None, None, None, None, None
+        dout = loss_grad(ctx.ws, outputs, labels, g[0:1].contiguous(), origin, (xs, ys, strides))
+        return dout, None, None, None, None, None, None, (ctx.ws.d_origin if ctx.l1 else None)
 
 
 def _check_cuda(t, name):
@@ -85,7 +96,9 @@ class Loss_Function(nn.Module):
     """Drop-in for the reference ``Loss_Function(num_classes)`` (yolox_24p/models/losses.py:159-357).
 
     ``forward(outputs_train, labels)`` takes the head's train-mode 5-tuple and ``labels [B,50,51]`` and returns
-    ``(loss, reg_w*loss_iou[24], loss_obj, loss_cls, loss_l1=0.0, num_fg/num_gts, draw_content)``.
+    ``(loss, reg_w*loss_iou[24], loss_obj, loss_cls, loss_l1, num_fg/num_gts, draw_content)``; ``loss_l1`` is the python
+    float 0.0 unless ``use_l1`` is set (then a 0-dim tensor, losses.py:304-309, and the head must have produced
+    ``origin_preds``).
     Differences, all about avoiding host syncs: position 5 is a 0-dim device tensor (float()-able) instead of
     a python float, and draw_content[0:3] (matched cx / cy / radii, dynamic length) are only materialised when
     ``self.draw`` is True.
@@ -130,7 +143,7 @@ class Loss_Function(nn.Module):
 
     def forward(self, outputs_train, labels):
         _lib.require_gpu()
-        x_shifts, y_shifts, expanded_strides, outputs, _origin = outputs_train
+        x_shifts, y_shifts, expanded_strides, outputs, origin_preds = outputs_train
         _check_cuda(outputs, "outputs")
         if outputs.shape[2] != NCOLS_BASE + self.num_classes or labels.shape[1:] != (MAX_GT, 51):
             raise IndexError
@@ -139,7 +152,12 @@ class Loss_Function(nn.Module):
         xs, ys, st = self._anchors(x_shifts, y_shifts, expanded_strides)
         labels = labels.to(device=outputs.device, dtype=torch.float32).contiguous()
         outputs_c = outputs if outputs.is_contiguous() else outputs.contiguous()
-        res = _LossFn.apply(outputs_c, labels, xs, ys, st, ws, self._state)
+        origin = None
+        if self.use_l1:                                                       # losses.py:197-198
+            origin = torch.cat(origin_preds, 1).float().contiguous()
+            if origin.shape != (B, A, 26):
+                raise IndexError
+        res = _LossFn.apply(outputs_c, labels, xs, ys, st, ws, self._state, origin)
         reg_w, obj_w, cls_w = res[29:53], res[53], res[54]
         if self.draw:
             fg = ws.matched_gt.reshape(-1) >= 0
@@ -148,7 +166,8 @@ class Loss_Function(nn.Module):
         else:
             draw = [None, None, None]
         draw += [reg_w, obj_w, cls_w]
-        return res[0], res[1:25], res[25], res[26], 0.0, res[55] / torch.clamp(res[28], min=1.0), draw
+        loss_l1 = res[56] if self.use_l1 else 0.0
+        return res[0], res[1:25], res[25], res[26], loss_l1, res[55] / torch.clamp(res[28], min=1.0), draw
 
     # --- reference helper kept for API parity (losses.py:360-442): assignment of one image of the last call
     def assignment_of(self, labels, b):

@@ -61,13 +61,20 @@ class TrainStep:
     """
 
     def __init__(self, model, loss_fn, lr, momentum=0.9, batch=None, size=640, reducer=None, use_graph=True,
-                 graph_backward=True):
+                 graph_backward=True, ema=None, use_l1=False):
         _lib.require_gpu()
         self.model, self.loss_fn = model, loss_fn
         self.eng = model.engine(batch, size)
         self.home = self.eng.home
         self.lr, self.momentum = lr, momentum
         self.reducer = reducer
+        # the schedule / EMA / L1 pieces the reference carries for long runs.  lr, momentum, 1/world and
+        # the EMA decay of the step sit in a device block the captured update reads, so none of them re-captures a graph
+        self.ema = ema                                   # ep24.ema.ModelEMA or None: fused into the SGD launch
+        self.ema_home = ema.homes(model)[1] if ema is not None else None
+        self.hp = torch.zeros(8, dtype=torch.float32, device=self.eng.dev)
+        self._hp_dirty = True
+        self.use_l1 = False
         eng = self.eng
         self.ws = loss_fn.workspace(eng.B, eng.A, eng.dev)
         self.state = loss_fn._state
@@ -85,22 +92,53 @@ class TrainStep:
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
             reducer.attach(self.home, eng)
+        if use_l1:
+            self.set_use_l1(True)
+
+    def set_lr(self, lr):
+        """Learning rate of the following steps (``LRScheduler.update_lr(iter)``); no graph is re-captured."""
+        if lr != self.lr:
+            self.lr = lr
+            self._hp_dirty = True
+
+    def set_use_l1(self, on):
+        """The reference's ``use_l1`` switch on head and loss (yolo_head_24p.py:128, losses.py:163; its yolox ancestor
+        turns it on for the last no-aug epochs).  The L1 buffers become launch arguments, so the graphs are captured
+        again on the next step."""
+        on = bool(on)
+        if on == self.use_l1:
+            return
+        self.use_l1 = on
+        self.eng.set_use_l1(on)
+        self.loss_fn.use_l1 = on
+        if getattr(self.model, "head", None) is not None:
+            self.model.head.use_l1 = on
+        self.graphs = None
+
+    def _push_hparams(self):
+        d, omd = self.ema.next_decay() if self.ema is not None else (0.0, 0.0)
+        if self._hp_dirty or self.ema is not None:
+            _lib.call("set_hparams", _lib.ptr(self.hp), float(self.lr), float(self.momentum), 1.0 / self.world, float(d),
+                      float(omd), _lib.stream_ptr())
+            self._hp_dirty = False
 
     # the three phases, each a pure launch sequence on the current stream
     def _phase_forward(self):
         eng = self.eng
         self.home.zero_grad()
         eng.forward()
-        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state)
-        eloss.loss_grad(self.ws, eng.outputs, self.labels)
+        origin = eng.origin if self.use_l1 else None
+        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin)
+        eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
         eng.dyn["dout"] = self.ws.dout.data_ptr()
+        eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
 
     def _phase_backward(self, lo, hi):
         eng = self.eng
         eng._run(eng.bwd[lo:hi])
 
     def _phase_update(self):
-        self.home.sgd(self.lr, self.momentum, 1.0 / self.world)
+        self.home.sgd_hp(self.hp, self.ema_home)
 
     def _segments(self):
         """Cut points of the backward list.  The weight-gradient lane runs one segment behind the main lane, so the last
@@ -175,6 +213,9 @@ class TrainStep:
             eng.images.copy_(images, non_blocking=True)
         if labels is not None:
             self.labels.copy_(labels, non_blocking=True)
+        if self.graphs is None and self.use_graph:
+            self._capture()
+        self._push_hparams()
         if not self.use_graph:
             self._phase_forward()
             self._phase_backward(0, len(eng.bwd))
@@ -182,8 +223,6 @@ class TrainStep:
                 self.reducer.reduce_all()
             self._phase_update()
             return self.ws.result
-        if self.graphs is None:
-            self._capture()
         self.g_fwd.replay()
         if self.g_bwd is not None:
             main, side = torch.cuda.current_stream(), self._side

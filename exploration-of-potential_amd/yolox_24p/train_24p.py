@@ -9,6 +9,11 @@ as ONE captured hipGraph (``ep24.train.TrainStep``); ``--no-graph`` runs the sam
 eager API (model(...), loss_func.forward(...), loss.backward(), optimizer.step()).  Scalars are logged from a single
 packed device->host copy every ``--log-interval`` steps instead of ~54 per-step ``add_scalar`` syncs (:115-137).
 Under torch.distributed.run every rank trains on its own shard and gradients are averaged over RCCL (ep24.dp).
+
+The reference carries three more pieces that its 24p trainer never switches on; they are opt-in
+here and all of them run inside the captured step: ``--sched`` follows ``exp.get_lr_scheduler`` (yoloxwarmcos,
+exp/yolox_base.py:155-167) per iteration, ``--ema`` keeps a ``ModelEMA`` copy (utils/ema.py) that is saved with the
+checkpoint, ``--l1`` turns ``use_l1`` on for head and loss from epoch ``exp.L1_epoch`` on (exp/yolox_base.py:38).
 """
 import argparse
 import os
@@ -61,18 +66,33 @@ class Trainer:
         self.optimizer = exp.get_optimizer(args.learn_rate)
         self.max_iter = len(self.train_loader)
         self.tblogger = SummaryWriter(self.file_name) if (SummaryWriter and self.rank == 0) else None
+        self.lr_scheduler = exp.get_lr_scheduler(args.learn_rate, self.max_iter) if args.sched else None
+        self.ema_model = None
+        if args.ema:
+            from utils import ModelEMA
+            self.ema_model = ModelEMA(model, 0.9998)
         step_fn = None
         if not args.no_graph:
             step_fn = TrainStep(model, self.loss_func, lr=args.learn_rate, momentum=exp.momentum, batch=args.batch_size,
-                                size=self.input_size[0], reducer=reducer)
+                                size=self.input_size[0], reducer=reducer, ema=self.ema_model)
         print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "captured step" if step_fn else "eager API"))
         done = False
         for epoch in range(self.max_epoch):
             self.epoch = epoch
             model.train()
             t0, seen = time.time(), 0
+            if args.l1 and epoch == self.L1_epoch:
+                model.head.use_l1 = self.loss_func.use_l1 = True
+                if step_fn is not None:
+                    step_fn.set_use_l1(True)
             for images, labels, _info, _ids in self.train_loader:
                 self.current_step += 1
+                if self.lr_scheduler is not None:
+                    lr = self.lr_scheduler.update_lr(self.current_step)
+                    for group in self.optimizer.param_groups:
+                        group["lr"] = lr
+                    if step_fn is not None:
+                        step_fn.set_lr(lr)
                 images = images.to(self.device, non_blocking=True)
                 labels = labels.to(self.device, non_blocking=True)
                 images, labels = exp.preprocess(images, labels, self.input_size)
@@ -88,6 +108,8 @@ class Trainer:
                             reducer.attach(eng.home, eng)
                         reducer.reduce_all()
                     self.optimizer.step(grad_scale=1.0 / self.world)
+                    if self.ema_model is not None:
+                        self.ema_model.update(model)
                     res = self.loss_func._ws.result
                 seen += images.shape[0]
                 if self.current_step % args.log_interval == 0:
@@ -122,6 +144,8 @@ class Trainer:
 
     def save_ckpt(self, ckpt_name, update_best_ckpt=False):
         state = {"start_epoch": self.epoch + 1, "model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        if self.ema_model is not None:
+            state["ema_model"], state["ema_updates"] = self.ema_model.ema.state_dict(), self.ema_model.updates
         save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name)
 
 
@@ -140,6 +164,9 @@ def make_parser():
     p.add_argument("--steps", default=0, type=int, help="stop after this many steps (0 = run all epochs)")
     p.add_argument("--log-interval", default=10, type=int)
     p.add_argument("--no-graph", action="store_true", help="reference-style eager loop instead of the captured step")
+    p.add_argument("--sched", action="store_true", help="follow exp.get_lr_scheduler (yoloxwarmcos) instead of a constant rate")
+    p.add_argument("--ema", action="store_true", help="keep a ModelEMA copy of the model (saved as ema_model)")
+    p.add_argument("--l1", action="store_true", help="switch use_l1 on from epoch exp.L1_epoch")
     return p
 
 

@@ -1,8 +1,7 @@
 """The slice of the reference's ``utils`` package the 24p path uses: ``bboxes_iou`` (utils/boxes.py:166-243),
 ``postprocess`` (utils/boxes.py:29-99),
-``save_checkpoint`` / ``load_ckpt`` (utils/checkpoint.py:11-43) and the ``yoloxwarmcos`` schedule
-(utils/lr_scheduler.py:121-148)."""
-import math
+``save_checkpoint`` / ``load_ckpt`` (utils/checkpoint.py:11-43), the learning-rate schedules
+(utils/lr_scheduler.py:9-205) and ``ModelEMA`` (utils/ema.py:22-60)."""
 import os
 import shutil
 
@@ -10,6 +9,8 @@ import _path  # noqa: F401
 import torch
 from ep24.loss import bboxes_iou  # noqa: F401
 from ep24.infer import postprocess  # noqa: F401      (utils/boxes.py:29-99)
+from ep24.schedule import LRScheduler  # noqa: F401   (utils/lr_scheduler.py:9-92)
+from ep24.ema import ModelEMA, is_parallel  # noqa: F401   (utils/ema.py:13-60)
 
 
 def save_checkpoint(state, is_best, save_dir, model_name=""):
@@ -35,26 +36,3 @@ def load_ckpt(model, ckpt):
         keep[k] = ckpt[k]
     model.load_state_dict(keep, strict=False)
     return model
-
-
-class LRScheduler:
-    """``yoloxwarmcos``: quadratic warm-up, cosine decay, constant floor for the last no-aug epochs."""
-
-    def __init__(self, name, lr, iters_per_epoch, total_epochs, warmup_epochs=0, warmup_lr_start=0, no_aug_epochs=0,
-                 min_lr_ratio=0.05):
-        if name != "yoloxwarmcos":
-            raise ValueError("Scheduler version {} not supported.".format(name))
-        self.lr = lr
-        self.total_iters = iters_per_epoch * total_epochs
-        self.warmup_iters = iters_per_epoch * warmup_epochs
-        self.no_aug_iters = iters_per_epoch * no_aug_epochs
-        self.warmup_lr_start = warmup_lr_start
-        self.min_lr = lr * min_lr_ratio
-
-    def update_lr(self, iters):
-        if iters <= self.warmup_iters:
-            return (self.lr - self.warmup_lr_start) * pow(iters / float(max(self.warmup_iters, 1)), 2) + self.warmup_lr_start
-        if iters >= self.total_iters - self.no_aug_iters:
-            return self.min_lr
-        span = self.total_iters - self.warmup_iters - self.no_aug_iters
-        return self.min_lr + 0.5 * (self.lr - self.min_lr) * (1.0 + math.cos(math.pi * (iters - self.warmup_iters) / span))

@@ -163,12 +163,15 @@ int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, i
  * a3  head decode (yolox_24p/models/yolo_head_24p.py:212-237)
  * ------------------------------------------------------------------------------------------------ */
 /* in place on out[B,A,107] fp32 rows of one level (anchor offset a0, HxW cells, stride s):
- * xy=(t+grid)*s, r=exp(t)*s, obj/cls logits untouched. */
-int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream);
+ * xy=(t+grid)*s, r=exp(t)*s, obj/cls logits untouched.  origin [B,A,26] (nullable) receives the raw regression
+ * outputs first - the head's origin_preds under use_l1 (yolo_head_24p.py:179-188). */
+int ep24_head_decode_fwd(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, float* origin,
+                         void* stream);
 /* backward through the decode for one level + split into the padded bf16 gradients the prediction convs
- * consume: d_regobj [B*H*W][32] (26 reg + 1 obj + zeros), d_cls [B*H*W][round8(C)] (C classes + zeros). */
+ * consume: d_regobj [B*H*W][32] (26 reg + 1 obj + zeros), d_cls [B*H*W][round8(C)] (C classes + zeros).
+ * d_origin [B,A,26] (nullable) is added to the raw regression gradient (the L1 branch's path around the decode). */
 int ep24_head_decode_bwd(const float* dout, const float* out, void* d_regobj, void* d_cls, int B, int A, int a0,
-                         int H, int W, float stride, int ncols, void* stream);
+                         int H, int W, float stride, int ncols, const float* d_origin, void* stream);
 /* bias gradient: db[n] += sum_m g[m][n] for n < N (bf16 rows of stride ld). */
 int ep24_colsum(const void* g, int64_t ld, float* db, int64_t M, int N, void* stream);
 /* the same without atomics: ep24_colsum_splits(M) partial rows slab[s*N + n], folded in order by ep24_wgrad_reduce
@@ -204,18 +207,24 @@ int ep24_assign_resolve(const uint64_t* match, const float* pw, const float* cos
 /* per-block partial sums of the 24 circle-GIoU terms (matched rows), obj BCE (all anchors), cls BCE
  * (matched rows), num_fg; partials [nblocks][EP24_NUM_SUMS]; nblocks = ep24_loss_blocks(B, A). */
 int ep24_loss_blocks(int B, int A);
+/* L1 branch (use_l1, losses.py:197-198,255-262,304-309,594-604): origin [B,A,26] = the raw regression
+ * outputs before the decode (null = branch off), xs/ys/strides [A] the anchor grid; adds sum |origin - l1_target| of
+ * the matched rows as accumulator 27. */
 int ep24_loss_terms(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
-                    const float* matched_iou, float* partials, int B, int A, int num_classes, void* stream);
+                    const float* matched_iou, float* partials, int B, int A, int num_classes, const float* origin,
+                    const float* xs, const float* ys, const float* strides, void* stream);
 /* fixed-order reduction of the partials, dynamic task weights and state update (losses.py:286-345).
  * state[26] = last_{iou[24],obj,cls} (initialise to 1.0).  result[64]:
  *   [0] loss  [1..24] reg_w*loss_iou  [25] loss_obj  [26] loss_cls  [27] num_fg (clamped >= 1)
- *   [28] num_gts  [29..52] reg_w  [53] obj_w  [54] cls_w  [55] num_fg raw */
+ *   [28] num_gts  [29..52] reg_w  [53] obj_w  [54] cls_w  [55] num_fg raw  [56] loss_l1 (added to [0] unweighted) */
 int ep24_loss_finalize(const float* partials, int nblocks, const int32_t* num_gt, int B, float* state, float* result,
                        void* stream);
-/* d loss / d outputs [B,A,ncols] fp32, scaled by *grad_scale (device scalar, may be null = 1). */
+/* d loss / d outputs [B,A,ncols] fp32, scaled by *grad_scale (device scalar, may be null = 1).  With the L1 branch
+ * (d_origin non-null) also d loss / d origin [B,A,26] = sign(origin - l1_target) / num_fg on matched rows, 0 elsewhere. */
 int ep24_loss_grad(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt,
                    const float* matched_iou, const float* result, const float* grad_scale, float* dout, int B, int A,
-                   int num_classes, void* stream);
+                   int num_classes, const float* origin, const float* xs, const float* ys, const float* strides,
+                   float* d_origin, void* stream);
 
 /* stand-alone forms behind utils.bboxes_iou (boxes.py:166-243) and IOUloss.forward (losses.py:80-157) */
 int ep24_circle_pairwise(const float* gt50, const float* pred26, float* out, int G, int P, void* stream);
@@ -231,6 +240,19 @@ int ep24_circle_matched_bwd(const float* pred26, const float* target50, const fl
  * which is cleared afterwards. */
 int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float grad_scale,
                       int32_t* first_flag, void* stream);
+/* The same update with its hyper-parameters read from DEVICE memory, hp[8] = {lr, momentum, grad_scale, ema decay d,
+ * 1 - d, ...}: a captured step follows an LRScheduler (utils/lr_scheduler.py:33-34) without being
+ * re-captured.  ema (nullable, same layout as p) receives ModelEMA.update of the freshly written parameters in the
+ * same pass: ema = ema*d + (1-d)*p, each product and the sum rounded to fp32 (utils/ema.py:47-60). */
+int ep24_sgd_nesterov_hp(float* p, const float* g, float* buf, int64_t n, const float* hp, int32_t* first_flag, float* ema,
+                         void* stream);
+/* ModelEMA.update over one flat buffer (parameters, or the BatchNorm running statistics); hp non-null overrides
+ * decay / one_minus_decay with hp[3] / hp[4]. */
+int ep24_ema_update(float* ema, const float* src, int64_t n, float decay, float one_minus_decay, const float* hp,
+                    void* stream);
+/* writes hp[0..4] on the stream (by-value arguments: no host buffer has to outlive the call). */
+int ep24_set_hparams(float* hp, float lr, float momentum, float grad_scale, float ema_decay, float one_minus_decay,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a13  fisheye sector warp (yolox/demo_featuremap.py:244-328)

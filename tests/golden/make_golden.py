@@ -433,10 +433,88 @@ def gen_post(utils, models):
         save("g9_postprocess_" + tag, **store)
 
 
+# --------------------------------------------------------------------------- G10..G12 the "long run" pieces
+LR_CASES = [
+    ("cos", dict(), 0.01, 37, 6),
+    ("warmcos", dict(warmup_epochs=2), 0.02, 25, 8),
+    ("warmcos", dict(warmup_epochs=1, warmup_lr_start=1e-4), 0.02, 25, 8),
+    ("yoloxwarmcos", dict(warmup_epochs=5, warmup_lr_start=0, no_aug_epochs=100, min_lr_ratio=0.05), 0.01 / 64.0 * 20, 50, 300),
+    ("yoloxwarmcos", dict(warmup_epochs=1, no_aug_epochs=2), 0.005, 40, 10),
+    ("yoloxsemiwarmcos", dict(warmup_epochs=1, no_aug_epochs=2, semi_epoch=5, iters_per_epoch_semi=17), 0.01, 30, 12),
+    ("multistep", dict(milestones=[3, 7]), 0.1, 20, 10),
+    ("multistep", dict(milestones=[2, 4, 6], gamma=0.5), 0.1, 20, 8),
+]
+
+
+def gen_n2(utils, models):
+    # G10: learning-rate schedules (utils/lr_scheduler.py) sampled over whole runs
+    store = {"n_cases": len(LR_CASES)}
+    for i, (name, kw, lr, ipe, epochs) in enumerate(LR_CASES):
+        sch = utils.LRScheduler(name, lr, ipe, epochs, **kw)
+        total = ipe * epochs
+        its = np.unique(np.concatenate([np.arange(0, total + 1, max(total // 400, 1)), np.arange(0, min(total, 3 * ipe) + 1),
+                                        np.arange(max(total - 3 * ipe, 0), total + 1)]))
+        store["c%d_iters" % i] = its
+        store["c%d_lr" % i] = np.array([sch.update_lr(int(t)) for t in its], dtype=np.float64)
+    save("g10_lr", **store)
+
+    # G11: ModelEMA (utils/ema.py) over a parameter, a float buffer and an integer buffer, four updates
+    class Toy(torch.nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            g = torch.Generator().manual_seed(110)
+            self.w = torch.nn.Parameter(torch.randn(n, generator=g))
+            self.register_buffer("stat", torch.rand(n // 4, generator=g))
+            self.register_buffer("count", torch.tensor(7, dtype=torch.long))
+
+    toy = Toy(4099)
+    for start in (0, 1500):
+        toy.load_state_dict(Toy(4099).state_dict())
+        ema = utils.ModelEMA(toy, decay=0.9998 if start else 0.9999, updates=start)
+        store = {"start": start, "decay": 0.9998 if start else 0.9999, "w0": toy.w.detach().clone(), "stat0": toy.stat.clone()}
+        g = torch.Generator().manual_seed(111 + start)
+        for step in range(4):
+            with torch.no_grad():
+                toy.w.add_(torch.randn(toy.w.shape, generator=g) * 0.05)
+                toy.stat.mul_(0.9).add_(torch.rand(toy.stat.shape, generator=g) * 0.1)
+                toy.count.add_(1)
+            ema.update(toy)
+            store["w_model%d" % step] = toy.w.detach().clone()
+            store["stat_model%d" % step] = toy.stat.clone()
+            store["w_ema%d" % step] = ema.ema.w.detach().clone()
+            store["stat_ema%d" % step] = ema.ema.stat.clone()
+        store["count_ema"] = int(ema.ema.count)
+        store["updates"] = ema.updates
+        save("g11_ema_%d" % start, **store)
+
+    # G12: the loss with use_l1 (losses.py:197-198, 255-262, 304-309): totals and the gradient wrt origin_preds
+    lf = models.Loss_Function(80)
+    lf.use_l1 = True
+    B, counts = 3, [10, 3, 25]
+    labels = synth.make_labels(B, counts, seed=121)
+    raw = synth.make_raw_head(B, seed=122)
+    outputs = synth.decode_head(raw).requires_grad_(True)
+    tup5 = list(synth.outputs_train_tuple(outputs))
+    origin, a0 = [], 0
+    for s in synth.STRIDES:
+        n = (640 // s) ** 2
+        origin.append(raw[:, a0:a0 + n, :26].clone().requires_grad_(True))
+        a0 += n
+    tup5[4] = origin
+    tup = lf.forward(tuple(tup5), labels)
+    tup[0].backward()
+    g_or = torch.cat([o.grad for o in origin], 1)
+    rows = g_or.abs().sum(-1).reshape(-1).nonzero().reshape(-1)
+    g_out = outputs.grad
+    save("g12_loss_l1", B=B, counts=np.array(counts), label_seed=121, head_seed=122, loss=tup[0], loss_iou_w=tup[1],
+         loss_obj=tup[2], loss_cls=tup[3], loss_l1=tup[4], fg_per_gt=float(tup[5]), d_origin_rows=rows,
+         d_origin_vals=g_or.reshape(-1, 26)[rows], d_origin_abs_sum=checksum(g_or.abs()), grad_abs_sum=checksum(g_out.abs()),
+         grad_obj=g_out[..., 26].reshape(-1)[::7])
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -448,3 +526,5 @@ if __name__ == "__main__":
         gen_sector()
     if "post" in which:
         gen_post(utils, models)
+    if "n2" in which:
+        gen_n2(utils, models)

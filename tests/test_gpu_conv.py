@@ -265,7 +265,7 @@ def test_upsample_stem_decode_sgd():
     Bz, A, a0, Hh, Ww, s, nc = 2, 30, 5, 4, 4, 16.0, 107
     raw = torch.randn(Bz, A, nc, generator=torch.Generator().manual_seed(54))
     out = raw.clone().to(DEV)
-    call("head_decode_fwd", ptr(out), Bz, A, a0, Hh, Ww, s, nc, sp())
+    call("head_decode_fwd", ptr(out), Bz, A, a0, Hh, Ww, s, nc, None, sp())
     yv, xv = torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij")
     ref = raw.clone()
     lvl = ref[:, a0:a0 + 16]
@@ -276,7 +276,7 @@ def test_upsample_stem_decode_sgd():
     dout = torch.randn(Bz, A, nc, generator=torch.Generator().manual_seed(55)).to(DEV)
     dro = torch.zeros(Bz * 16, 32, dtype=BF, device=DEV)
     dcl = torch.zeros(Bz * 16, 80, dtype=BF, device=DEV)
-    call("head_decode_bwd", ptr(dout), ptr(out), ptr(dro), ptr(dcl), Bz, A, a0, Hh, Ww, s, nc, sp())
+    call("head_decode_bwd", ptr(dout), ptr(out), ptr(dro), ptr(dcl), Bz, A, a0, Hh, Ww, s, nc, None, sp())
     d = dout.cpu()[:, a0:a0 + 16]
     o = out.cpu()[:, a0:a0 + 16]
     want = torch.cat([d[..., :2] * s, d[..., 2:26] * o[..., 2:26], d[..., 26:27]], -1).reshape(-1, 27)
