@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--gts", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--long-run", action="store_true", help="non-default: also run the SURVEY 8f N2 pieces inside the step (L1 "
+                    "branch on, ModelEMA fused into the update, a yoloxwarmcos rate pushed every step)")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     a = ap.parse_args()
 
@@ -220,8 +222,22 @@ def main():
     model.to(dev)
     lf = eloss.Loss_Function(80)
     reducer = dp.GradReducer() if world > 1 else None
+    ema, sched = None, None
+    if a.long_run:
+        from ep24.ema import ModelEMA
+        from ep24.schedule import LRScheduler
+        ema = ModelEMA(model, 0.9998)
+        sched = LRScheduler("yoloxwarmcos", 0.001, 100, 300, warmup_epochs=5, warmup_lr_start=0, no_aug_epochs=100, min_lr_ratio=0.05)
     ts = etrain.TrainStep(model, lf, lr=0.001, momentum=0.9, batch=a.batch, size=a.size, reducer=reducer,
-                          use_graph=not a.no_graph, graph_backward=not a.eager_backward)
+                          use_graph=not a.no_graph, graph_backward=not a.eager_backward, ema=ema, use_l1=a.long_run)
+    if sched is not None:
+        plain_step, it = ts.step, [0]
+
+        def step_with_schedule(*args):
+            it[0] += 1
+            ts.set_lr(sched.update_lr(it[0]))
+            return plain_step(*args)
+        ts.step = step_with_schedule
     # this rank's shard of the synthetic global batch (weak scaling: per-GPU work fixed)
     shard = 0 if rehearse else rank
     images = synth.make_images(a.batch, a.size, seed=1 + shard).to(dev)
@@ -262,7 +278,8 @@ def main():
             "config": {"workload": "YOLOX-l-24p (CSPDarknet53+PAFPN+24p head) train step, %dx%d, batch %d/GPU, %d GTs/img, "
                                    "SimOTA + 24-circle GIoU loss, SGD nesterov" % (a.size, a.size, a.batch, a.gts),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
-                                     else "fwd+loss, update, backward as two lanes of captured segments")},
+                                     else "fwd+loss, update, backward as two lanes of captured segments"),
+                       **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {})},
             "loss": round(loss, 4),
             "step_mfma_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE * (a.size / 640.0) ** 2 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
