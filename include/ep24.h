@@ -306,6 +306,20 @@ int ep24_post_nms(const float* score, const int32_t* cls, const float* rect, int
 int ep24_post_gather(const float* pred, int ncols, const float* conf, const int32_t* cls, const int32_t* keep, int n,
                      float* det, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N4  24-point label generation (yolox_24p/datasets/2+24_labels_create.py:61-116, :175-180)
+ * ------------------------------------------------------------------------------------------------ */
+/* rotation_for_24p for n objects (n <= 65535 per call).  masks: uint8 instance masks (non-zero = object) somewhere in
+ * one device buffer; desc[n][6] int64 = {byte offset of the mask, H, W, L = int(sqrt(H^2 + W^2)), number of ray samples
+ * = len(arange(0, L, 0.2)), row stride in bytes}; centre[n][2] double = box centre (x, y) as the reference forms it
+ * (:167-168); rot[24][2] double = cos / sin of k*15 degrees as numpy computes them.  H + W + L must stay below 32768
+ * (the reference holds the coordinates in int16).  Out: out_pts[n][24][2] int32 (x, y), out_r[n][24] double; a ray
+ * without any candidate pixel (np.argmin of an empty array in the reference) gives (-1,-1) and +inf. */
+int ep24_ray24(const uint8_t* masks, const int64_t* desc, const double* centre, const double* rot, int n,
+               int32_t* out_pts, double* out_r, void* stream);
+/* cv2.contourArea(cv2.convexHull(points)) of each object's 24 integer points (:175-176): area[n] double. */
+int ep24_hull_area24(const int32_t* pts, int n, double* area, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -511,10 +511,72 @@ def gen_n2(utils, models):
          d_origin_vals=g_or.reshape(-1, 26)[rows], d_origin_abs_sum=checksum(g_or.abs()), grad_abs_sum=checksum(g_out.abs()),
          grad_obj=g_out[..., 26].reshape(-1)[::7])
 
+# --------------------------------------------------------------------------- G13 label generation
+def label_masks():
+    """Synthetic instance masks: (tag, mask uint8 [H,W], centre x, centre y) - convex, star-shaped, concave with a hole,
+    cut by the image border, and a one-pixel object."""
+    out = []
+
+    def grid(H, W):
+        return np.mgrid[0:H, 0:W]
+
+    yy, xx = grid(97, 131)
+    m = (((xx - 60.3) / 40.0) ** 2 + ((yy - 45.2) / 22.0) ** 2 <= 1.0).astype(np.uint8)
+    out.append(("ellipse", m))
+    yy, xx = grid(240, 320)
+    ang = np.arctan2(yy - 118.0, xx - 171.0)
+    rr = np.hypot(yy - 118.0, xx - 171.0)
+    m = (rr <= 55.0 + 30.0 * np.cos(5 * ang)).astype(np.uint8)
+    out.append(("star", m))
+    yy, xx = grid(200, 260)
+    m = ((np.hypot(yy - 100.0, xx - 120.0) <= 70) & ~(np.hypot(yy - 100.0, xx - 150.0) <= 45)).astype(np.uint8)   # crescent: the centre is outside
+    m[95:106, 40:80] = 0                                                                                           # and a slit
+    out.append(("crescent", m))
+    yy, xx = grid(180, 240)
+    m = (((xx - 225.0) / 50.0) ** 2 + ((yy - 12.0) / 40.0) ** 2 <= 1.0).astype(np.uint8)                           # cut by two borders
+    out.append(("border", m))
+    m = np.zeros((64, 80), np.uint8)
+    m[31, 47] = 1
+    out.append(("pixel", m))
+    yy, xx = grid(480, 640)
+    g = np.random.RandomState(131)
+    m = np.zeros((480, 640), np.uint8)
+    for _ in range(14):                                                                                            # blobby union
+        cy, cx, r = g.uniform(150, 330), g.uniform(200, 440), g.uniform(25, 70)
+        m |= (np.hypot(yy - cy, xx - cx) <= r).astype(np.uint8)
+    out.append(("blobs", m))
+    res = []
+    for tag, m in out:
+        ys, xs = np.nonzero(m)
+        x0, y0, w, h = float(xs.min()), float(ys.min()), float(xs.max() - xs.min()) + 0.37, float(ys.max() - ys.min()) + 0.81
+        res.append((tag, m, x0 + w / 2, y0 + h / 2))                                                                # bbox centre as :167-168
+    return res
+
+
+def gen_labels():
+    import importlib.util
+    cv2 = sys.modules["cv2"]
+    # cv2 is not installed: zero padding is the one cv2 call rotation_for_24p makes (no arithmetic involved)
+    cv2.BORDER_CONSTANT = 0
+    cv2.copyMakeBorder = lambda img, t, b, l, r, kind, value=0: np.pad(img, ((t, b), (l, r)), constant_values=value)
+    spec = importlib.util.spec_from_file_location("labels_create_ref", os.path.join(REF, "yolox_24p", "datasets", "2+24_labels_create.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    poly = mod.Polygon_24.__new__(mod.Polygon_24)                     # __init__ opens the COCO json of the author's machine
+    store = {"tags": np.array([t for t, *_ in label_masks()])}
+    for tag, m, cx, cy in label_masks():
+        pts, rad = poly.rotation_for_24p(cx, cy, m)
+        store[tag + "_mask"] = np.packbits(m, axis=1)
+        store[tag + "_shape"] = np.array(m.shape)
+        store[tag + "_centre"] = np.array([cx, cy], dtype=np.float64)
+        store[tag + "_pts"] = pts.astype(np.int64)
+        store[tag + "_rad"] = rad.astype(np.float64)
+    save("g13_labels24", **store)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -528,3 +590,5 @@ if __name__ == "__main__":
         gen_post(utils, models)
     if "n2" in which:
         gen_n2(utils, models)
+    if "labels" in which:
+        gen_labels()
