@@ -9,6 +9,7 @@
 //   2. sector_gather: one thread per output pixel reads the winner and fetches the source texel (or 114).
 // Per image only step 2 runs: 4 B map + 3 B texel read + 3 B write per pixel - HBM bound, no MFMA.
 #include "common.h"
+#include "resize.h"
 
 namespace {
 
@@ -110,20 +111,8 @@ extern "C" int ep24_mask_bbox(const uint8_t* mask3, int out_h, int out_w, int32_
 // border clamping, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  cv2 is not installed in
 // this image, so this step is checked against a numpy restatement of the same published arithmetic only.
 namespace {
-__device__ __forceinline__ void lin_coef(int d, float scale, int ssize, int& s0, int& s1, int& a0, int& a1) {
-    float f = (float)((d + 0.5) * (double)scale - 0.5);
-    int s = (int)floorf(f);
-    f -= (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-    s0 = s;
-    s1 = s + 1 < ssize ? s + 1 : ssize - 1;
-    a0 = (int)rintf((1.f - f) * 2048.f);
-    a1 = (int)rintf(f * 2048.f);
-}
-
 __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw,
-                                                               float scale_x, float scale_y) {
+                                                               double scale_x, double scale_y) {
     const long total = (long)dh * dw;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int dy = (int)(i / dw), dx = (int)(i - (long)dy * dw);
@@ -149,7 +138,7 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* sr
 namespace {
 __global__ __launch_bounds__(256) void sector_warp_kernel(const uint8_t* src, int sh, int sw, const int* winner, int canvas_w,
                                                           int y0, int x0, int out_h, int out_w, int T, int n_ang, uint8_t* dst,
-                                                          int fill, float scale_x, float scale_y) {
+                                                          int fill, double scale_x, double scale_y) {
     // one output pixel per thread (four per thread with packed dword stores measured 1.4x slower: the gathers serialise)
     const long total = (long)out_h * out_w;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -183,8 +172,8 @@ extern "C" int ep24_sector_warp_u8(const uint8_t* src, int sh, int sw, const int
                  "sector_warp: bad arguments");
     long blocks = ((long)out_h * out_w + 255) / 256;
     hipLaunchKernelGGL(sector_warp_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, src, sh,
-                       sw, winner, canvas_w, y0, x0, out_h, out_w, T, n_ang, dst, fill, (float)((double)sw / n_ang),
-                       (float)((double)sh / T));
+                       sw, winner, canvas_w, y0, x0, out_h, out_w, T, n_ang, dst, fill, 1.0 / ((double)n_ang / sw),
+                       1.0 / ((double)T / sh));
     EP24_LAUNCH_CHECK("ep24_sector_warp_u8");
     return EP24_OK;
 }
@@ -193,7 +182,7 @@ extern "C" int ep24_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t
     EP24_REQUIRE(src && dst && sh > 0 && sw > 0 && dh > 0 && dw > 0, EP24_E_ARG, "resize_linear_u8: bad arguments");
     long blocks = ((long)dh * dw + 255) / 256;
     hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, src,
-                       sh, sw, dst, dh, dw, (float)((double)sw / dw), (float)((double)sh / dh));
+                       sh, sw, dst, dh, dw, 1.0 / ((double)dw / sw), 1.0 / ((double)dh / sh));
     EP24_LAUNCH_CHECK("ep24_resize_linear_u8");
     return EP24_OK;
 }

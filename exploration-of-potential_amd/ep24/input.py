@@ -1,0 +1,139 @@
+"""Input pipeline on the GPU: ``preproc`` / ``TrainTransform`` (yolox_24p/datasets/data_augment.py:109-174)
+for whole batches, and the side-stream ``DataPrefetcher`` (yolox_24p/data/data_prefetcher.py:8-51).
+
+The host hands over what the decoder produced - raw uint8 HWC images of any size and the label rows of the txt files
+(class + 50 normalised coordinates) - and gets the network input ``[n,3,S,S]`` fp32 and the label table ``[n,50,51]``
+fp32 on the device: one upload of the raw bytes (5x fewer than the fp32 canvas the reference ships) and two launches.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+
+def letterbox_geometry(h, w, input_size):
+    """r and the resized size exactly as ``preproc`` computes them (data_augment.py:117-121)."""
+    r = min(input_size[0] / h, input_size[1] / w)
+    return r, int(h * r), int(w * r)
+
+
+def preproc_batch(images, input_size, device="cuda:0", out=None):
+    """images: list of uint8 [h,w,3] arrays / tensors (host or device).  Returns (tensor [n,3,S_h,S_w] fp32 on the
+    device, list of r)."""
+    _lib.require_gpu()
+    dev = torch.device(device)
+    n = len(images)
+    S_h, S_w = int(input_size[0]), int(input_size[1])
+    if out is None:
+        out = torch.empty(n, 3, S_h, S_w, dtype=torch.float32, device=dev)
+    if n == 0:
+        return out, []
+    desc, scales, flat, rs, off = [], [], [], [], 0
+    for im in images:
+        im = im if isinstance(im, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(im))
+        if im.dim() != 3 or im.shape[2] != 3 or im.dtype != torch.uint8:
+            raise ValueError("preproc_batch takes uint8 [h,w,3] images")
+        h, w = int(im.shape[0]), int(im.shape[1])
+        r, rh, rw = letterbox_geometry(h, w, (S_h, S_w))
+        desc.append([off, h, w, 3 * w, rh, rw])
+        scales.append([1.0 / (rw / w) if rw else 1.0, 1.0 / (rh / h) if rh else 1.0])      # cv::resize: scale = 1/(dsize/ssize)
+        flat.append(im.reshape(-1))
+        rs.append(r)
+        off += h * w * 3
+    buf = torch.cat([f.to(dev, non_blocking=True) for f in flat])
+    desc_t = torch.tensor(desc, dtype=torch.int64, device=dev)
+    sc_t = torch.tensor(scales, dtype=torch.float64, device=dev)
+    for lo in range(0, n, 65535):
+        hi = min(n, lo + 65535)
+        call("preproc_u8", ptr(buf), ptr(desc_t, lo * 6), ptr(sc_t, lo * 2), hi - lo, ptr(out, lo * 3 * S_h * S_w), S_h, S_w,
+             stream_ptr())
+    return out, rs
+
+
+def labels_batch(targets, sizes, rs, max_labels=50, device="cuda:0", out=None):
+    """targets: list of [k_i,51] float arrays (normalised txt rows; ``[k,0]``-shaped or empty for an image without
+    labels); sizes: list of (h, w); rs: the r of every image.  Returns [n,max_labels,51] fp32 on the device."""
+    _lib.require_gpu()
+    dev = torch.device(device)
+    n = len(targets)
+    if out is None:
+        out = torch.empty(n, max_labels, 51, dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    rows, off = [], [0]
+    for t in targets:
+        t = np.asarray(t, dtype=np.float64)
+        t = t.reshape(-1, 51) if t.size else np.zeros((0, 51))
+        rows.append(t)
+        off.append(off[-1] + t.shape[0])
+    allrows = np.concatenate(rows, 0) if off[-1] else np.zeros((1, 51))
+    rows_t = torch.from_numpy(np.ascontiguousarray(allrows)).to(dev)
+    off_t = torch.tensor(off, dtype=torch.int64, device=dev)
+    whr = torch.tensor([[float(w), float(h), float(r)] for (h, w), r in zip(sizes, rs)], dtype=torch.float64, device=dev)
+    call("preproc_labels", ptr(rows_t), ptr(off_t), ptr(whr), n, ptr(out), max_labels, stream_ptr())
+    return out
+
+
+def preproc(img, input_size, swap=(2, 0, 1)):
+    """Drop-in for the reference ``preproc`` (one image): returns (CHW fp32 device tensor, r, None) - the third value
+    (the uint8 HWC canvas) is not materialised."""
+    if swap != (2, 0, 1):
+        raise NotImplementedError("ep24.input.preproc produces the network layout (2, 0, 1) only")
+    out, rs = preproc_batch([img], input_size)
+    return out[0], rs[0], None
+
+
+class TrainTransform:
+    """``TrainTransform(max_labels, flip_prob)`` of the reference (data_augment.py:131-174; the flip probability is
+    stored and unused there as well).  ``__call__(image, targets, input_dim)`` handles one image, ``batch`` many."""
+
+    def __init__(self, max_labels=50, flip_prob=0.5, hsv_prob=1.0):
+        self.max_labels, self.flip_prob = max_labels, flip_prob
+
+    def batch(self, images, targets, input_dim, out_images=None, out_labels=None):
+        imgs, rs = preproc_batch(images, input_dim, out=out_images)
+        labs = labels_batch(targets, [im.shape[:2] for im in images], rs, self.max_labels, out=out_labels)
+        return imgs, labs
+
+    def __call__(self, image, targets, input_dim):
+        imgs, labs = self.batch([image], [targets], input_dim)
+        return imgs[0], labs[0]
+
+
+class DataPrefetcher:
+    """The reference's prefetcher (data/data_prefetcher.py): the next batch is prepared on a side stream while the
+    current step runs; ``next()`` makes the compute stream wait for it.  ``loader`` yields either ready tensors
+    ``(images, labels, info, ids)`` (as the reference's loader does) or raw batches ``(list of uint8 HWC images, list of
+    label rows, info, ids)`` - then ``transform.batch`` (upload + the two preproc launches) runs on the side stream too."""
+
+    def __init__(self, loader, input_size=(640, 640), transform=None):
+        _lib.require_gpu()
+        self.loader = iter(loader)
+        self.stream = torch.cuda.Stream()
+        self.input_size = input_size
+        self.transform = transform or TrainTransform()
+        self.preload()
+
+    def preload(self):
+        try:
+            images, targets, _, _ = next(self.loader)
+        except StopIteration:
+            self.next_input = self.next_target = None
+            return
+        with torch.cuda.stream(self.stream):
+            if isinstance(images, torch.Tensor):
+                self.next_input = images.cuda(non_blocking=True)
+                self.next_target = targets.cuda(non_blocking=True)
+            else:
+                self.next_input, self.next_target = self.transform.batch(images, targets, self.input_size)
+
+    def next(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        inp, tgt = self.next_input, self.next_target
+        if inp is not None:
+            inp.record_stream(torch.cuda.current_stream())
+        if tgt is not None:
+            tgt.record_stream(torch.cuda.current_stream())
+        self.preload()
+        return inp, tgt

@@ -1,6 +1,7 @@
-"""Synthetic stand-in for ``COCO24PDataset`` + ``TrainTransform`` (datasets/coco24p.py, data_augment.py:131-174):
-items are ``(image [3,S,S] fp32 0..255, labels [50,51], img_info, img_id)`` exactly as the trainer unpacks them
-(train_24p.py:83).  The real loader (cv2 / pycocotools, CPU workers, hard-coded dataset paths) is outside the hot path."""
+"""Synthetic stand-in for ``COCO24PDataset`` (datasets/coco24p.py): items are ``(image [3,S,S] fp32 0..255, labels
+[50,51], img_info, img_id)`` exactly as the trainer unpacks them (train_24p.py:83).  The real dataset (cv2.imread of
+hard-coded paths) is outside the hot path; its ``TrainTransform`` / ``preproc`` half is ``ep24.input`` (GPU)
+and is re-exported here under the reference's names."""
 import _path  # noqa: F401
 import torch
 from ep24 import synth
@@ -26,8 +27,4 @@ class SyntheticDataset(torch.utils.data.Dataset):
 COCO24PDataset = SyntheticDataset        # name the reference's Exp imports (exp/yolox_base.py:76)
 
 
-class TrainTransform:
-    """Placeholder with the reference's constructor signature; synthetic items are already in network layout."""
-
-    def __init__(self, max_labels=50, flip_prob=0.5, hsv_prob=1.0):
-        self.max_labels = max_labels
+from ep24.input import TrainTransform, preproc  # noqa: E402,F401   (datasets/data_augment.py:109-174, on the GPU)

@@ -320,6 +320,21 @@ int ep24_ray24(const uint8_t* masks, const int64_t* desc, const double* centre, 
 /* cv2.contourArea(cv2.convexHull(points)) of each object's 24 integer points (:175-176): area[n] double. */
 int ep24_hull_area24(const int32_t* pts, int n, double* area, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N1  input pipeline (yolox_24p/datasets/data_augment.py:109-174)
+ * ------------------------------------------------------------------------------------------------ */
+/* preproc for n images (n <= 65535): images = raw uint8 HWC sources in one device buffer; desc[n][6] int64 =
+ * {byte offset, h, w, row stride in bytes, rh = int(h*r), rw = int(w*r)} with r = min(S_h/h, S_w/w) (:118-123);
+ * scales[n][2] double = {1/(rw/w), 1/(rh/h)} (OpenCV's scale_x, scale_y).  out [n,3,S_h,S_w] fp32: the image resized
+ * with cv2.resize's INTER_LINEAR fixed-point arithmetic in the top-left corner, 114 elsewhere, channels in source order. */
+int ep24_preproc_u8(const uint8_t* images, const int64_t* desc, const double* scales, int n, float* out, int S_h, int S_w,
+                    void* stream);
+/* TrainTransform's label half (:145-173): rows [total][51] double = (class, 50 normalised coordinates) of all images,
+ * row_off[n+1] int64, whr[n][3] double = (width, height, r).  out [n][max_labels][51] fp32: x columns (v*width)*r,
+ * y columns (v*height)*r, first max_labels rows, zero padded. */
+int ep24_preproc_labels(const double* rows, const int64_t* row_off, const double* whr, int n, float* out, int max_labels,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,7 @@ def resize_linear_u8(img, dw, dh):
     sh, sw = img.shape[:2]
 
     def coef(n, scale, ssize):
-        f = ((np.arange(n) + 0.5) * np.float64(np.float32(scale)) - 0.5).astype(np.float32)
+        f = ((np.arange(n) + 0.5) * scale - 0.5).astype(np.float32)             # scale stays a double (cv::hal::resize)
         s = np.floor(f).astype(np.int64)
         f = f - s.astype(np.float32)
         lo = s < 0
@@ -88,8 +88,8 @@ def resize_linear_u8(img, dw, dh):
         s1 = np.minimum(s + 1, ssize - 1)
         return s, s1, np.rint((1 - f) * np.float32(2048)).astype(np.int64), np.rint(f * np.float32(2048)).astype(np.int64)
 
-    x0, x1, ax0, ax1 = coef(dw, sw / dw, sw)
-    y0, y1, by0, by1 = coef(dh, sh / dh, sh)
+    x0, x1, ax0, ax1 = coef(dw, 1.0 / (dw / sw), sw)                             # inv_scale = dsize/ssize, scale = 1./inv_scale
+    y0, y1, by0, by1 = coef(dh, 1.0 / (dh / sh), sh)
     im = img.astype(np.int64)
     h = im[:, x0] * ax0[None, :, None] + im[:, x1] * ax1[None, :, None]
     v = (((by0[:, None, None] * (h[y0] >> 4)) >> 16) + ((by1[:, None, None] * (h[y1] >> 4)) >> 16) + 2) >> 2

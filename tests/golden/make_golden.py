@@ -573,10 +573,47 @@ def gen_labels():
         store[tag + "_rad"] = rad.astype(np.float64)
     save("g13_labels24", **store)
 
+# --------------------------------------------------------------------------- G14 input pipeline
+INPUT_CASES = [("wide", 97, 131, (160, 160), 3), ("tall", 211, 120, (160, 192), 0), ("up", 48, 64, (160, 160), 60),
+               ("exact", 160, 160, (160, 160), 1), ("vga", 480, 640, (640, 640), 7)]
+
+
+def input_case(tag, h, w, k, seed):
+    g = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 3 + yy) % 256, (xx + yy * 5) % 256, g.randint(0, 256, (h, w))], -1).astype(np.uint8)
+    targets = np.concatenate([g.randint(0, 80, (k, 1)).astype(np.float64), np.round(g.rand(k, 50), 4)], 1) if k else np.zeros((0, 0))
+    return img, targets
+
+
+def gen_input():
+    sys.path.insert(0, ROOT)
+    from oracle.sector import resize_linear_u8
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_LINEAR = 1
+    # cv2 is not installed: its INTER_LINEAR resize is stood in for by the oracle's restatement of OpenCV's fixed-point
+    # arithmetic (that step stays "parity unpinned"); everything else below is the reference's own code
+    cv2.resize = lambda img, dsize, interpolation=None: resize_linear_u8(img, dsize[0], dsize[1])
+    sys.path.insert(0, os.path.join(REF, "yolox_24p"))
+    da = importlib.import_module("datasets.data_augment")
+    tt = da.TrainTransform(max_labels=50)
+    store = {}
+    for i, (tag, h, w, size, k) in enumerate(INPUT_CASES):
+        img, targets = input_case(tag, h, w, k, 140 + i)
+        out, r, padded = da.preproc(img, size)
+        image_t, labels = tt(img, targets.copy(), size)
+        assert np.array_equal(out, image_t)
+        store[tag + "_r"] = float(r)
+        store[tag + "_crc"] = zlib.crc32(out.tobytes())
+        store[tag + "_sub"] = out[:, ::7, ::5]
+        store[tag + "_labels"] = labels
+        assert labels.dtype == np.float32 and out.dtype == np.float32
+    save("g14_input", **store)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -592,3 +629,5 @@ if __name__ == "__main__":
         gen_n2(utils, models)
     if "labels" in which:
         gen_labels()
+    if "input" in which:
+        gen_input()
