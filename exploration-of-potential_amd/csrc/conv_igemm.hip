@@ -1063,6 +1063,8 @@ int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t 
     }
     // stride 2: input pixels of parity (ph,pw) only see taps with (p + pad - k) even; one launch per class
     EP24_REQUIRE(H % 2 == 0 && W % 2 == 0, EP24_E_UNSUPPORTED, "conv_dgrad s2: odd spatial size %dx%d", H, W);
+    // a 1x1 stride-2 conv reaches only the even pixels: as first writer it would leave the other three quarters of dx stale
+    EP24_REQUIRE(ksize != 1 || accumulate, EP24_E_UNSUPPORTED, "conv_dgrad k=1 s=2 only accumulates (run it after another producer of dx)");
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             IgemmArgs c = a;

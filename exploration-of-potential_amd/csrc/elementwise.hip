@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
                 const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 8 + j];
                 const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 8 + j];
                 const float u = fmaf((float)v[k][j], a_, b_);
-                o[j] = (bf16)((act ? u * sigmoidf_(u) : u) + (res ? (float)r[k][j] : 0.f));
+                o[j] = (bf16)(act_fwd(u, act) + (res ? (float)r[k][j] : 0.f));
             }
             *reinterpret_cast<bf16x8*>(y + mm[k] * ld_y + gg[k] * 8) = o;
         }

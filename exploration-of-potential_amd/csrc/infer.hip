@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void bn_act_infer_kernel(const bf16* z, long l
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float u = fmaf((float)v[j], sc[g * 8 + j], sh[g * 8 + j]);
-            o[j] = (bf16)((act ? u * sigmoidf_(u) : u) + (res ? (float)r[j] : 0.f));
+            o[j] = (bf16)(act_fwd(u, act) + (res ? (float)r[j] : 0.f));
         }
         *reinterpret_cast<bf16x8*>(y + m * ld_y + g * 8) = o;
     }

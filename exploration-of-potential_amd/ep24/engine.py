@@ -160,7 +160,19 @@ class ParamHome:
         self.convs, self.vecs, self.order, self.by_param = [], [], [], {}
         stems = {m.conv for m in model.modules() if isinstance(m, enn.Focus)}
         for mod in exec_order(model):
-            if isinstance(mod, enn.BaseConv):
+            if isinstance(mod, tuple) and mod[0] == "unit":          # (conv, bn) pair of a swapped backbone
+                _, conv, bn_, stem = mod
+                w = conv.weight
+                k = w.shape[2]
+                if stem:                                             # im2col rows x [Cout][k*k*Cin]
+                    self._add(ConvSeg([w], w.shape[0], 1, k * k * w.shape[1], need_dgrad=False))
+                else:
+                    self._add(ConvSeg([w], w.shape[0], k * k, w.shape[1]))
+                self._add(VecSeg([bn_.weight]))
+                self._add(VecSeg([bn_.bias]))
+            elif isinstance(mod, tuple) and mod[0] == "unused":      # in the state dict, not in the graph: gradient stays 0
+                self._add(VecSeg([mod[1]]))
+            elif isinstance(mod, enn.BaseConv):
                 w = mod.conv.weight
                 k = w.shape[2]
                 if mod in stems:      # Focus stem runs as im2col x [Cout][108]: one "tap" of 108 (kh,kw,c) columns
@@ -197,7 +209,7 @@ class ParamHome:
         self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
         # BatchNorm running statistics in one flat buffer too (module buffers become views): ModelEMA averages every
         # floating-point state_dict entry (utils/ema.py:55-60), i.e. these next to the parameters, in two launches
-        bns = [m.bn for m in exec_order(model) if isinstance(m, enn.BaseConv)]
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         nb = sum((b.num_features + 3) // 4 * 8 for b in bns)
         self.bflat = torch.zeros(max(nb, 4), dtype=torch.float32, device=dev)
         self.bnumel = nb
@@ -279,7 +291,14 @@ def exec_order(model):
     """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
     any other container (tests build single blocks) falls back to registration order."""
     if not isinstance(model, enn.YOLOX):
-        yield from model.modules()
+        for m in model.modules():
+            if isinstance(m, enn.ResBottleneck):          # tests build stand-alone stages of the swapped backbone
+                if m.downsample is not None:
+                    yield ("unit", m.downsample[0], m.downsample[1], False)
+                for conv, bn in ((m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)):
+                    yield ("unit", conv, bn, False)
+            else:
+                yield m
         return
 
     def csp(m):
@@ -292,15 +311,21 @@ def exec_order(model):
 
     neck, head = model.backbone, model.head
     bb = neck.backbone
-    yield bb.stem.conv
-    for name in ("dark2", "dark3", "dark4"):
-        seq = getattr(bb, name)
-        yield seq[0]
-        yield from csp(seq[1])
-    yield bb.dark5[0]
-    yield bb.dark5[1].conv1
-    yield bb.dark5[1].conv2
-    yield from csp(bb.dark5[2])
+    if isinstance(bb, enn.ResNet):
+        first = True
+        for conv, bn in bb.used_units():
+            yield ("unit", conv, bn, first)
+            first = False
+    else:
+        yield bb.stem.conv
+        for name in ("dark2", "dark3", "dark4"):
+            seq = getattr(bb, name)
+            yield seq[0]
+            yield from csp(seq[1])
+        yield bb.dark5[0]
+        yield bb.dark5[1].conv1
+        yield bb.dark5[1].conv2
+        yield from csp(bb.dark5[2])
     yield neck.lateral_conv0
     yield from csp(neck.C3_p4)
     yield neck.reduce_conv1
@@ -314,6 +339,11 @@ def exec_order(model):
         yield from head.cls_convs[k]
         yield from head.reg_convs[k]
     yield head
+    if isinstance(bb, enn.ResNet):                     # fc / baseconv1..3: parameters the reference never runs (darknet.py:311-330)
+        used = {id(p) for conv, bn in bb.used_units() for p in (conv.weight, bn.weight, bn.bias)}
+        for p in bb.parameters():
+            if id(p) not in used:
+                yield ("unused", p)
 
 
 def param_home(model):
@@ -388,22 +418,27 @@ class Engine:
         bb, neck, head = m.backbone.backbone, m.backbone, m.head
         F = S // 2
         self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
-        # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
-        rows = self.new_act(112, F, F)
-        rows.needs_grad = False
-        self._f("stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
-        x = self.unit(bb.stem.conv, rows, stem=True)
-        c3, c4, c5 = (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels, bb.dark5[0].conv.out_channels)
+        swapped = isinstance(bb, enn.ResNet)
+        c3, c4, c5 = (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels,
+                                                       bb.dark5[0].conv.out_channels)
         H3, H4, H5 = S // 8, S // 16, S // 32
         # concat buffers of the neck; producers write straight into their slot (yolo_pafpn.py:100-124)
         cat_p4 = self.new_act(2 * c4, H4, H4)        # [up(fpn_out0) | dark4]
         cat_p3 = self.new_act(2 * c3, H3, H3)        # [up(fpn_out1) | dark3]
         cat_n3 = self.new_act(2 * c3, H4, H4)        # [bu_conv2(pan_out2) | fpn_out1]
         cat_n4 = self.new_act(2 * c4, H5, H5)        # [bu_conv1(pan_out1) | fpn_out0]
-        x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
-        x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=cat_p3.slice(c3, c3))
-        x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=cat_p4.slice(c4, c4))
-        x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
+        if swapped:                                       # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
+            x2, x1, x0 = self.resnet(bb, cat_p3.slice(c3, c3), cat_p4.slice(c4, c4))
+        else:
+            # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
+            rows = self.new_act(112, F, F)
+            rows.needs_grad = False
+            self._f("stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
+            x = self.unit(bb.stem.conv, rows, stem=True)
+            x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
+            x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=cat_p3.slice(c3, c3))
+            x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=cat_p4.slice(c4, c4))
+            x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
         fpn_out0 = self.unit(neck.lateral_conv0, x0, out=cat_n4.slice(c4, c4))
         self.up2(fpn_out0, cat_p4.slice(0, c4))
         f_out0 = self.csp(neck.C3_p4, cat_p4)
@@ -538,13 +573,16 @@ class Engine:
                 (lambda: self.bnsums.data_ptr() + 8 * (off + 2 * C)))
 
     # ---- ops ---------------------------------------------------------------------------------------
-    def unit(self, mod, x, out=None, residual=None, stem=False):
-        """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51)."""
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=1):
+        """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
+        name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none)."""
         home = self.home
-        seg = home.by_param[mod.conv.weight]
-        gam, bet = home.by_param[mod.bn.weight], home.by_param[mod.bn.bias]
-        k = k_ = 1 if stem else mod.conv.kernel_size[0]
-        s = 1 if stem else mod.conv.stride[0]
+        conv = mod.conv if conv is None else conv
+        bn = mod.bn if bn is None else bn
+        seg = home.by_param[conv.weight]
+        gam, bet = home.by_param[bn.weight], home.by_param[bn.bias]
+        k = k_ = 1 if stem else conv.kernel_size[0]
+        s = 1 if stem else conv.stride[0]
         cin = x.C                                  # stem: im2col width 112 (108 real columns)
         assert x.C == seg.cin_pad if stem else x.C == seg.cin, (x.C, seg.cin)
         cout = seg.cout
@@ -560,7 +598,6 @@ class Engine:
         save = torch.zeros(2 * cout, dtype=torch.float32, device=self.dev)
         stats = self._stats_slot(cout)
         sum_g, sum_b, bar_cnt = self._sums_slot(cout)
-        bn = mod.bn
         flat, gflat = home.flat, home.gflat
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
         self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s,
@@ -569,12 +606,12 @@ class Engine:
         res_ld = residual.ld if residual is not None else 0
         self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
                 ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld,
-                res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), 1,
+                res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), act,
                 ev=("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
-                                     ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), 1)))
+                                     ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), act)))
         if residual is not None:
             residual.alias_grad(out)
-        self.unit_acts[mod] = (x, z, out)
+        self.unit_acts[mod if mod is not None else conv] = (x, z, out)
 
         def build_bwd():
             assert out.gready(), "activation without a gradient producer"
@@ -586,14 +623,14 @@ class Engine:
             if self.fuse_bn_bwd and _lib.lib().fn["ep24_bn_act_bwd_fused_rows"](M, cout) > 0:
                 # both passes in one launch: dy and z are read once and stay in registers across a grid barrier
                 self._b("bn_act_bwd_fused", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
-                                             sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, 1,
+                                             sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, act,
                                              bar_cnt), writes=(gam, bet))
             else:
                 self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, 1), reads=out)
+                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, act), reads=out)
                 self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                              ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                             dz, cout, M, cout, 1), writes=(gam, bet))
+                                             dz, cout, M, cout, act), writes=(gam, bet))
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
@@ -638,6 +675,63 @@ class Engine:
             u = self.unit(blk.conv1, t)
             t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None)
         return self.unit(mod.conv3, cat, out=out)
+
+    def relu(self, y):
+        """In-place ReLU on an activation that is a sum ("out += identity; out = relu(out)", darknet.py:266-268): the
+        backward masks the incoming gradient in place with the stored output."""
+        self._f("relu_fwd", y.ptr(), y.ld, y.M, y.C)
+
+        def build_bwd():
+            assert y.gready(), "activation without a gradient producer"
+            _PENDING_GW.append(y.gregion())
+            self._b("relu_bwd", (y.gptr(), y.gld, y.ptr(), y.ld, y.M, y.C))
+
+        self._add_builder(build_bwd)
+        return y
+
+    def maxpool3s2(self, x):
+        """nn.MaxPool2d(3, 2, 1) (darknet.py:303)."""
+        OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        y = self.new_act(x.C, OH, OW)
+        idx = torch.zeros(y.M * x.C, dtype=torch.uint8, device=self.dev)
+        self._f("maxpool3s2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, ptr(idx), x.B, x.H, x.W, x.C)
+
+        def build_bwd():
+            assert y.gready()
+            acc = x.gwrite()
+            self._b("maxpool3s2_bwd", (y.gptr(), y.gld, ptr(idx), x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
+
+        self._add_builder(build_bwd)
+        return y
+
+    def res_block(self, blk, x, out=None):
+        """ResNet bottleneck (darknet.py:247-271).  The downsample unit is placed first so that, in backward, its 1x1
+        stride-2 input gradient (which reaches the even pixels only) accumulates onto conv1's complete one."""
+        idn = x
+        if blk.downsample is not None:
+            idn = self.unit(None, x, conv=blk.downsample[0], bn=blk.downsample[1], act=0)
+        t = self.unit(None, x, conv=blk.conv1, bn=blk.bn1, act=2)
+        t = self.unit(None, t, conv=blk.conv2, bn=blk.bn2, act=2)
+        y = self.unit(None, t, out=out, conv=blk.conv3, bn=blk.bn3, act=0, residual=idn)
+        return self.relu(y)
+
+    def resnet(self, bb, out3, out4):
+        """The swapped backbone (darknet.py:389-416): stem conv 7x7/2 as im2col rows x GEMM, BN + ReLU, max pool, four
+        stages; returns dark3 / dark4 / dark5 (layer2 / layer3 / layer4)."""
+        B, S = self.B, self.S
+        rows = self.new_act(152, S // 2, S // 2)             # 7*7*3 = 147 columns -> 152
+        rows.needs_grad = False
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, S, S, 7, 2, 3)
+        x = self.unit(None, rows, stem=True, conv=bb.conv1, bn=bb.bn1, act=2)
+        x = self.maxpool3s2(x)
+        feats = []
+        for li, layer in enumerate((bb.layer1, bb.layer2, bb.layer3, bb.layer4)):
+            for bi, blk in enumerate(layer):
+                last = bi == len(layer) - 1
+                out = out3 if (last and li == 1) else out4 if (last and li == 2) else None
+                x = self.res_block(blk, x, out)
+            feats.append(x)
+        return feats[1], feats[2], feats[3]
 
     def spp(self, mod, x):
         """SPPBottleneck: conv1 -> cat(x, pool5, pool9, pool13) -> conv2 (network_blocks.py:139-144)."""

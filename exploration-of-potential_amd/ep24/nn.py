@@ -101,11 +101,102 @@ class CSPDarknet(nn.Module):
         _no_eager(self)
 
 
-class YOLOPAFPN(nn.Module):
-    def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
-                 depthwise=False, act="silu"):
+class ResBottleneck(nn.Module):
+    """torchvision-style bottleneck of the swapped backbone (darknet.py:230-271): 1x1 -> 3x3 (stride) -> 1x1 (x4), each
+    followed by BatchNorm, ReLU after the first two and after ``out += identity``; attribute names as in the reference."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.backbone = CSPDarknet(depth, width, depthwise=depthwise, act=act)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, 1, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, 1, 0, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class ResNet(nn.Module):
+    """The reference's half-width ResNet-50 feature extractor (darknet.py:274-429, ``resnet50()``): 7x7/2 stem with 32
+    filters, 3x3/2 max pool, stages of [3, 4, 6, 3] bottlenecks with 32/64/128/256 planes; dark3/4/5 = the outputs of
+    layer2/3/4 (256/512/1024 channels at /8, /16, /32).  ``fc`` and ``baseconv1..3`` exist in the reference (and in its
+    checkpoints) but take no part in the forward pass; they are kept so state dicts match."""
+
+    def __init__(self, layers=(3, 4, 6, 3)):
+        super().__init__()
+        self.out_features = ("dark3", "dark4", "dark5")
+        self.inplanes = 32
+        self.conv1 = nn.Conv2d(3, 32, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(32, layers[0], 1)
+        self.layer2 = self._make_layer(64, layers[1], 2)
+        self.layer3 = self._make_layer(128, layers[2], 2)
+        self.layer4 = self._make_layer(256, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)                         # 512 * expansion, as written (never run)
+
+        def unused(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.SiLU())
+        self.baseconv1, self.baseconv2, self.baseconv3 = unused(512, 128), unused(1024, 256), unused(2048, 256)
+        for m in self.modules():                                       # darknet.py:332-338
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [ResBottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [ResBottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def used_units(self):
+        """(conv, bn) pairs in execution order - what the plan runs and the flat parameter buffers are ordered by."""
+        yield self.conv1, self.bn1
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                yield blk.conv1, blk.bn1
+                yield blk.conv2, blk.bn2
+                if blk.downsample is not None:
+                    yield blk.downsample[0], blk.downsample[1]
+                yield blk.conv3, blk.bn3
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+def resnet50():
+    return ResNet((3, 4, 6, 3))
+
+
+class YOLOPAFPN(nn.Module):
+    """``backbone_type`` is the switch of yolox/models/yolo_pafpn.py:31-38 ('darknet' | 'resnet'; the 24p tree's own
+    YOLOPAFPN hard-codes CSPDarknet, so it is a keyword here and the positional signature stays the 24p one)."""
+
+    def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
+                 depthwise=False, act="silu", backbone_type="darknet"):
+        super().__init__()
+        if backbone_type == "darknet":
+            self.backbone = CSPDarknet(depth, width, depthwise=depthwise, act=act)
+        elif backbone_type == "resnet":
+            if width != 1.0:
+                raise NotImplementedError("resnet50() emits 256/512/1024 channels: it pairs with width 1.0 (BASELINE config 4)")
+            self.backbone = resnet50()
+        else:
+            raise NotImplementedError("backbone_type %r: 'darknet' and 'resnet' are built ('densenet' / 'vgg' are not)" % backbone_type)
+        self.backbone_type = backbone_type
         self.in_features = in_features
         self.in_channels = in_channels
         c3, c4, c5 = [int(c * width) for c in in_channels]

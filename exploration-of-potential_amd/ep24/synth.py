@@ -98,3 +98,29 @@ def outputs_train_tuple(outputs, size=640):
         strides.append(ss[o:o + n][None].to(outputs.device))
         o += n
     return x_shifts, y_shifts, strides, outputs, []
+
+
+def fill_state(model, seed=0):
+    """Deterministic, name-keyed weights for models too large to ship in a fixture (the config-4 ResNet network): every
+    state-dict entry is drawn from a generator seeded by its own name, so the reference module, the oracle and the ep24
+    mirror - which share key names - receive identical values whatever their construction order."""
+    import zlib
+    sd = model.state_dict()
+    new = {}
+    for name in sorted(sd):
+        t = sd[name]
+        if not t.dtype.is_floating_point:
+            new[name] = t.clone()
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if t.dim() == 4:
+            v = torch.randn(t.shape, generator=g) * math.sqrt(2.0 / (t.shape[1] * t.shape[2] * t.shape[3]))
+        elif t.dim() == 2:
+            v = torch.randn(t.shape, generator=g) * 0.01
+        elif name.endswith("running_var") or (name.endswith("weight") and t.dim() == 1):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        else:
+            v = torch.randn(t.shape, generator=g) * 0.1
+        new[name] = v.to(t.dtype)
+    model.load_state_dict(new, strict=True)
+    return model

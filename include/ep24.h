@@ -335,6 +335,25 @@ int ep24_preproc_u8(const uint8_t* images, const int64_t* desc, const double* sc
 int ep24_preproc_labels(const double* rows, const int64_t* row_off, const double* whr, int n, float* out, int max_labels,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * C4  swapped backbones (yolox_24p/models/darknet.py:179-429, yolox/models/yolo_pafpn.py:31-38; BASELINE config 4)
+ *     The conv / BN+act entry points above carry them (act = 2 is ReLU); these are the remaining pieces.
+ * ------------------------------------------------------------------------------------------------ */
+/* im2col of fp32 NCHW images for a k x k / stride / pad conv (the ResNet stem: 7, 2, 3): rows [B*OH*OW][ld] bf16, column
+ * (kh*k + kw)*C + c, zero in the padding and in columns >= k*k*C; the conv itself is then a 1x1 GEMM over the rows. */
+int ep24_im2col_bf16(const float* images, void* rows, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad,
+                     void* stream);
+/* Bottleneck tail "out += identity; out = relu(out)" (darknet.py:266-268): the sum comes out of ep24_bn_act_fwd (act 0 +
+ * residual); relu_fwd clamps it in place, relu_bwd masks the incoming gradient in place with the stored output (y > 0). */
+int ep24_relu_fwd(void* y, int64_t ld, int64_t M, int C, void* stream);
+int ep24_relu_bwd(void* dy, int64_t ld_dy, const void* y, int64_t ld_y, int64_t M, int C, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (darknet.py:303) on NHWC bf16; idx [B*OH*OW*C] uint8 = winning tap
+ * (first maximum in scan order, as ATen); the backward gathers (no atomics), accumulate = 1 adds to dx. */
+int ep24_maxpool3s2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, uint8_t* idx, int B, int H, int W, int C,
+                        void* stream);
+int ep24_maxpool3s2_bwd(const void* dy, int64_t ld_dy, const uint8_t* idx, void* dx, int64_t ld_dx, int accumulate, int B,
+                        int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ load by name:
   PAFPN neck                                            yolox_24p/models/yolo_pafpn.py:27-124
   decoupled 24p head + train-mode decode                yolox_24p/models/yolo_head_24p.py:47-237
   factory (BN eps 1e-3 / momentum 0.03, prior bias)     yolox_24p/exp/yolox_base.py:55-72
+  swapped backbone resnet50() (BASELINE config 4)       yolox_24p/models/darknet.py:179-429, yolox/models/yolo_pafpn.py:31-38
 """
 import math
 
@@ -37,21 +38,30 @@ class Unit(nn.Module):
         self.bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.03)
 
     def forward(self, x):
-        if not EMULATE_BF16:
-            return F.silu(self.bn(self.conv(x)))
-        z = F.conv2d(_q(x), _q(self.conv.weight), None, self.conv.stride, self.conv.padding)
-        mean = z.mean((0, 2, 3))
-        var = z.var((0, 2, 3), unbiased=False)
-        if self.training:
-            with torch.no_grad():
-                n = z.numel() / z.shape[1]
-                m = self.bn.momentum
-                self.bn.running_mean.mul_(1 - m).add_(m * mean)
-                self.bn.running_var.mul_(1 - m).add_(m * var * n / max(n - 1, 1))
-                self.bn.num_batches_tracked += 1
-        scale = self.bn.weight / torch.sqrt(var + self.bn.eps)
-        u = _q(z) * scale.view(1, -1, 1, 1) + (self.bn.bias - mean * scale).view(1, -1, 1, 1)
-        return _q(F.silu(u))
+        return conv_bn_act(x, self.conv, self.bn, "silu", self.training)
+
+
+def conv_bn_act(x, conv, bn, act, training, residual=None):
+    """conv -> BatchNorm -> (+ residual) -> activation, plain or with the product's bf16 storage points emulated."""
+    fn = {"silu": F.silu, "relu": F.relu, None: lambda v: v}[act]
+    if not EMULATE_BF16:
+        u = bn(conv(x))
+        return fn(u if residual is None else u + residual)
+    z = F.conv2d(_q(x), _q(conv.weight), None, conv.stride, conv.padding)
+    mean = z.mean((0, 2, 3))
+    var = z.var((0, 2, 3), unbiased=False)
+    if training:
+        with torch.no_grad():
+            n = z.numel() / z.shape[1]
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(m * mean)
+            bn.running_var.mul_(1 - m).add_(m * var * n / max(n - 1, 1))
+            bn.num_batches_tracked += 1
+    scale = bn.weight / torch.sqrt(var + bn.eps)
+    u = _q(z) * scale.view(1, -1, 1, 1) + (bn.bias - mean * scale).view(1, -1, 1, 1)
+    if residual is not None:
+        u = _q(u + residual)                       # the sum is stored (bf16) before the in-place ReLU
+    return _q(fn(u))
 
 
 class Stem(nn.Module):
@@ -120,12 +130,69 @@ class Backbone(nn.Module):
         return c3, c4, self.dark5(c4)
 
 
+class ResBlock(nn.Module):
+    """Bottleneck of the swapped backbone (darknet.py:230-271)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idn = x
+        if self.downsample is not None:
+            idn = conv_bn_act(x, self.downsample[0], self.downsample[1], None, self.training)
+        t = conv_bn_act(x, self.conv1, self.bn1, "relu", self.training)
+        t = conv_bn_act(t, self.conv2, self.bn2, "relu", self.training)
+        return conv_bn_act(t, self.conv3, self.bn3, "relu", self.training, residual=idn)     # out += identity; relu (:266-268)
+
+
+class ResNetBackbone(nn.Module):
+    """resnet50() of darknet.py:274-429: inplanes 32, stages [3,4,6,3] x planes 32/64/128/256, outputs layer2/3/4.
+    fc / baseconv1..3 are constructed by the reference and never run; they are here so state dicts match."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.conv1 = nn.Conv2d(3, 32, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.layer1 = self._stage(32, 3, 1)
+        self.layer2 = self._stage(64, 4, 2)
+        self.layer3 = self._stage(128, 6, 2)
+        self.layer4 = self._stage(256, 3, 2)
+        self.fc = nn.Linear(2048, 1000)                         # 512 * expansion, as written (never run)
+        for i, (a, b) in enumerate(((512, 128), (1024, 256), (2048, 256))):
+            setattr(self, "baseconv%d" % (i + 1), nn.Sequential(nn.Conv2d(a, b, 1, bias=False), nn.BatchNorm2d(b), nn.SiLU()))
+
+    def _stage(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [ResBlock(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [ResBlock(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = conv_bn_act(x, self.conv1, self.bn1, "relu", self.training)
+        x = F.max_pool2d(x, 3, 2, 1)
+        x = self.layer1(x)
+        c3 = self.layer2(x)
+        c4 = self.layer3(c3)
+        return c3, c4, self.layer4(c4)
+
+
 class Neck(nn.Module):
-    def __init__(self, depth, width, in_channels=(256, 512, 1024)):
+    def __init__(self, depth, width, in_channels=(256, 512, 1024), backbone_type="darknet"):
         super().__init__()
         c3, c4, c5 = [int(c * width) for c in in_channels]
         n = round(3 * depth)
-        self.backbone = Backbone(depth, width)
+        self.backbone = Backbone(depth, width) if backbone_type == "darknet" else ResNetBackbone()
         self.lateral_conv0 = Unit(c5, c4, 1)
         self.C3_p4 = CSP(2 * c4, c4, n, add=False)
         self.reduce_conv1 = Unit(c4, c3, 1)
@@ -201,10 +268,13 @@ class Head(nn.Module):
 
 
 class Net(nn.Module):
-    def __init__(self, depth=1.0, width=1.0, num_classes=80):
+    def __init__(self, depth=1.0, width=1.0, num_classes=80, backbone_type="darknet"):
         super().__init__()
-        self.backbone = Neck(depth, width)
+        self.backbone = Neck(depth, width, backbone_type=backbone_type)
         self.head = Head(num_classes, width)
+        for m in self.modules():                         # init_yolo (yolox_base.py:58-62) reaches every BatchNorm2d
+            if isinstance(m, nn.BatchNorm2d):
+                m.eps, m.momentum = 1e-3, 0.03
 
     def forward(self, x, train=False):
         return self.head(self.backbone(x), train)

@@ -321,7 +321,7 @@ def gen_model(utils, models):
     store["after:stem_rv"] = model.state_dict()["backbone.backbone.stem.conv.bn.running_var"]
     model.eval()
     with torch.no_grad():
-        store["out_eval"] = model(x, train=False)
+        store["out_eval"] = model(x, train=False)[:, ::3]
     save("g7_model_tiny", **store)
 
     # -l: names / shapes / parameter count only
@@ -610,10 +610,51 @@ def gen_input():
         assert labels.dtype == np.float32 and out.dtype == np.float32
     save("g14_input", **store)
 
+# --------------------------------------------------------------------------- G15 swapped backbone (BASELINE config 4)
+def gen_resnet(utils, models):
+    """YOLOX with ``model.backbone.backbone = resnet50()`` (the switch of yolox/models/yolo_pafpn.py:31-38 applied to the
+    24p network): train-mode outputs, gradients of a fixed cotangent, BN running statistics, and the
+    eval-mode outputs - weights from synth.fill_state (name-keyed, 35 M values: not stored)."""
+    dk = importlib.import_module("models.darknet")
+    torch.manual_seed(0)
+    backbone = models.YOLOPAFPN(0.33, 1.0, in_channels=[256, 512, 1024], act="silu")
+    backbone.backbone = dk.resnet50()
+    head = models.YOLOXHead(80, 1.0, in_channels=[256, 512, 1024], act="silu")
+    model = models.YOLOX(backbone, head)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    synth.fill_state(model, seed=15)
+    model.train()
+    B, S = 2, 256
+    x = synth.make_images(B, S, seed=151)
+    out = model(x, train=True)[3]
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(152)) * torch.tensor([0.05] * 26 + [1.0] * 81)
+    (out * gy).sum().backward()
+    sd = dict(model.named_parameters())
+    store = {"B": B, "S": S, "out": out.detach()[:, ::3], "keys": np.array(sorted(model.state_dict().keys())),
+             "n_params": sum(p.numel() for p in model.parameters())}
+    for name in ("backbone.backbone.conv1.weight", "backbone.backbone.bn1.weight", "backbone.backbone.layer1.0.downsample.0.weight",
+                 "backbone.backbone.layer1.0.conv2.weight", "backbone.backbone.layer2.0.downsample.0.weight",
+                 "backbone.backbone.layer2.3.bn3.bias", "backbone.backbone.layer3.5.conv1.weight",
+                 "backbone.backbone.layer4.0.conv2.weight", "backbone.backbone.layer4.2.bn3.weight", "backbone.lateral_conv0.conv.weight",
+                 "head.stems.0.conv.weight"):
+        g = sd[name].grad
+        store["g:" + name] = g if g.numel() <= 40000 else g.reshape(-1)[:: g.numel() // 20000 + 1]
+        store["gn:" + name] = float(g.double().norm())
+    store["unused_grad_is_none"] = int(all(sd[n].grad is None for n in ("backbone.backbone.fc.weight", "backbone.backbone.baseconv1.0.weight")))
+    msd = model.state_dict()
+    for name in ("backbone.backbone.bn1.running_mean", "backbone.backbone.bn1.running_var", "backbone.backbone.layer3.0.downsample.1.running_var"):
+        store["b:" + name] = msd[name]
+    model.eval()
+    with torch.no_grad():
+        store["out_eval"] = model(x, train=False)[:, ::3]
+    save("g15_resnet", **store)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -631,3 +672,5 @@ if __name__ == "__main__":
         gen_labels()
     if "input" in which:
         gen_input()
+    if "resnet" in which:
+        gen_resnet(utils, models)
