@@ -30,11 +30,13 @@ struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by
 // Prologue: the block folds the fixed-point statistics into per-channel scale / shift in LDS (one channel per
 // thread, 2*reps loads).  Body: flat grid-stride over 16-byte chunks, consecutive lanes on consecutive
 // addresses whatever C is, 2 chunks in flight per lane.
+template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const long long* stats, int reps,
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, long* nbt, float* save, bf16* y, long ld_y,
                                                          const bf16* res, long ld_res, long M, int C, float eps,
-                                                         float momentum, int act) {
+                                                         float momentum) {
+    constexpr int act = ACT;                     // compile-time: the SiLU instantiation carries no trace of the other modes
     extern __shared__ float lds[];
     float* sc = lds;
     float* sh = lds + C;
@@ -122,11 +124,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
 // Every thread owns one 8-channel group for the whole kernel (constants in registers) and walks rows with
 // several 16-byte loads in flight.
 
-template <int UNROLL, int NT>
+template <int UNROLL, int NT, int ACT>
 __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma,
                                                                const float* beta, long long* dgamma, long long* dbeta,
-                                                               long M, int C, int act) {
+                                                               long M, int C) {
+    constexpr int act = ACT;
     // Wide blocks (NT threads) so that one batch of UNROLL rows per thread covers the tensor with few blocks: the
     // per-block cost is 2*C memory-side int64 atomics, and all of a thread's loads are in flight at once.
     __shared__ float red[NT][16 + 1];
@@ -194,11 +197,12 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
     }
 }
 
-template <int UNROLL>
+template <int UNROLL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma, const float* beta,
                                                                const long long* dgamma, const long long* dbeta, float* ggrad,
-                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C, int act) {
+                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C) {
+    constexpr int act = ACT;
     const RowMap rm(C);
     const int tid = threadIdx.x;
     const float invM = 1.f / (float)M;
@@ -957,9 +961,10 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
     int fw_per = 2;
     if (const char* e = getenv("EP24_DBG_BN_FWD")) sscanf(e, "%d", &fw_per);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
+    auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : bn_act_fwd_kernel<0>;
+    hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
-                       ld_res, M, C, eps, momentum, act);
+                       ld_res, M, C, eps, momentum);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
     return EP24_OK;
 }
@@ -972,8 +977,9 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
     int red_cap = 256;                                      // one 512-thread block per CU: tools/bn_probe.py sweep
     int red_rows = 4;
     if (const char* e = getenv("EP24_DBG_BN_RED")) sscanf(e, "%d,%d", &red_rows, &red_cap);
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<4, 512>), dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
-                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, act);
+    auto kfn = act == 1 ? bn_act_bwd_reduce_kernel<4, 512, 1> : act == 2 ? bn_act_bwd_reduce_kernel<4, 512, 2> : bn_act_bwd_reduce_kernel<4, 512, 0>;
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
 }
@@ -1011,9 +1017,10 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
     int ap_rows = 16, ap_cap = 2048;
     if (const char* e = getenv("EP24_DBG_BN_APPLY")) sscanf(e, "%d,%d", &ap_rows, &ap_cap);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+    auto kfn = act == 1 ? bn_act_bwd_apply_kernel<4, 1> : act == 2 ? bn_act_bwd_apply_kernel<4, 2> : bn_act_bwd_apply_kernel<4, 0>;
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
-                       (bf16*)dz, ld_dz, M, C, act);
+                       (bf16*)dz, ld_dz, M, C);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
     return EP24_OK;
 }
