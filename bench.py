@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--long-run", action="store_true", help="non-default: also run the SURVEY 8f N2 pieces inside the step (L1 "
                     "branch on, ModelEMA fused into the update, a yoloxwarmcos rate pushed every step)")
-    ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet"], help="non-default: BASELINE config 4 (backbone swap)")
+    ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet"], help="non-default: BASELINE config 4 (backbone swap)")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     a = ap.parse_args()
 
@@ -280,14 +280,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "YOLOX-l-24p (%s+PAFPN+24p head) train step, %dx%d, batch %d/GPU, %d GTs/img, "
-                                   "SimOTA + 24-circle GIoU loss, SGD nesterov" % ("CSPDarknet53" if a.backbone == "darknet" else "resnet50 backbone swap",
+                                   "SimOTA + 24-circle GIoU loss, SGD nesterov" % ({"darknet": "CSPDarknet53", "resnet": "resnet50 backbone swap", "densenet": "densenet121 backbone swap"}[a.backbone],
                                                                                    a.size, a.size, a.batch, a.gts),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
                                      else "fwd+loss, update, backward as two lanes of captured segments"),
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {})},
             "loss": round(loss, 4),
-            "step_mfma_frac": round(ips / world * (TRAIN_GFLOP_PER_IMAGE if a.backbone == "darknet" else 290.7) * (a.size / 640.0) ** 2 / 1e3
-                                    / MFMA_BF16_PEAK_TFLOPS, 4),      # resnet50 swap: 3 x 2 x 48.45 GMAC
+            "step_mfma_frac": round(ips / world * {"darknet": TRAIN_GFLOP_PER_IMAGE, "resnet": 290.7, "densenet": 388.0}[a.backbone] * (a.size / 640.0) ** 2 / 1e3
+                                    / MFMA_BF16_PEAK_TFLOPS, 4),      # swaps: 3 x 2 x 48.45 / 64.67 GMAC
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src,

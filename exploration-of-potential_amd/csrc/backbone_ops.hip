@@ -158,9 +158,152 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16* dy, lon
     }
 }
 
+// Per-channel batch statistics of a stored tensor (sum and sum of squares in the conv epilogue's fixed-point layout
+// stats[rep][2][ld_stats]): the pre-activation BatchNorms of a dense block normalise tensors that no conv epilogue saw in
+// their final form (pooled block inputs, feature maps after Dropout2d).  Added into replica 0 at channel offset c0.
+__global__ __launch_bounds__(256) void colstats_kernel(const bf16* x, long ld, long long* stats, long ld_stats, long M, int C) {
+    __shared__ float red[2][256][8 + 1];
+    const int chunks = C >> 3;
+    const int rpp = 256 / chunks;
+    const int r = threadIdx.x / chunks, c = threadIdx.x - r * chunks;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < rpp) {
+        for (long m = (long)blockIdx.x * rpp + r; m < M; m += (long)gridDim.x * rpp) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + m * ld + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s1[j] += f; s2[j] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    for (int n = threadIdx.x; n < 2 * C; n += 256) {
+        const int which = n / C, ch = n - which * C;
+        float s = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) s += red[which][rr * chunks + (ch >> 3)][ch & 7];
+        atomicAdd((unsigned long long*)(stats + (long)which * ld_stats + ch), (unsigned long long)to_fix(s));
+    }
+}
+
+// layer view of the block statistics: dst[rep][2][C] <- src[rep][2][ld_src] first C channels
+__global__ __launch_bounds__(256) void stats_gather_kernel(const long long* src, long ld_src, long long* dst, int C, int reps) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < reps * 2 * C; i += gridDim.x * 256) {
+        const int c = i % C, w = (i / C) & 1, r = i / (2 * C);
+        dst[i] = src[((long)r * 2 + w) * ld_src + c];
+    }
+}
+
+// nn.AvgPool2d(2, 2) on NHWC bf16 (Transition, darknet.py:551-553)
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* x, long ld_x, bf16* y, long ld_y, int B, int H, int W, int C) {
+    const int cgs = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)B * OH * OW * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long op = i / cgs;
+        const int n = (int)(op / ((long)OH * OW));
+        const int rem = (int)(op - (long)n * OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(n * H + 2 * oy + (t >> 1)) * W + 2 * ox + (t & 1)) * ld_x + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(acc[j] * 0.25f);
+        *reinterpret_cast<bf16x8*>(y + op * ld_y + cg * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* dy, long ld_dy, bf16* dx, long ld_dx, int accumulate, int B,
+                                                           int H, int W, int C) {
+    const int cgs = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)B * H * W * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / ((long)H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int py = rem / W, px = rem - py * W;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + ((long)(n * OH + (py >> 1)) * OW + (px >> 1)) * ld_dy + cg * 8);
+        bf16x8* d = reinterpret_cast<bf16x8*>(dx + pix * ld_dx + cg * 8);
+        bf16x8 o;
+        if (accumulate) {
+            const bf16x8 old = *d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)old[j] + (float)g[j] * 0.25f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)g[j] * 0.25f);
+        }
+        *d = o;
+    }
+}
+
+// nn.Dropout2d: every (sample, channel) plane is kept or zeroed as a whole; keep[n*C + c] holds 0 or 1/(1-p) (the host draws
+// it once per step).  In place; the same launch is the backward (the gradient takes the same factors).
+__global__ __launch_bounds__(256) void chanscale_kernel(bf16* x, long ld, const float* keep, int B, long HW, int C) {
+    const int cgs = C >> 3;
+    const long total = (long)B * HW * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / HW);
+        bf16x8* p = reinterpret_cast<bf16x8*>(x + pix * ld + cg * 8);
+        bf16x8 v = *p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * keep[(long)n * C + cg * 8 + j]);
+        *p = v;
+    }
+}
+
 }  // namespace
 
 #define S_ (hipStream_t) stream
+
+extern "C" int ep24_colstats(const void* x, int64_t ld, int64_t* stats, int64_t ld_stats, int64_t M, int C, void* stream) {
+    EP24_REQUIRE(x && stats && C % 8 == 0 && C <= 2048 && ld % 8 == 0 && M > 0 && ld_stats >= C, EP24_E_ARG, "colstats: bad arguments");
+    long blocks = (M + 15) / 16;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(colstats_kernel, dim3((unsigned)blocks), dim3(256), 0, S_, (const bf16*)x, (long)ld, (long long*)stats, (long)ld_stats,
+                       (long)M, C);
+    EP24_LAUNCH_CHECK("ep24_colstats");
+    return EP24_OK;
+}
+
+extern "C" int ep24_stats_gather(const int64_t* src, int64_t ld_src, int64_t* dst, int C, int reps, void* stream) {
+    EP24_REQUIRE(src && dst && C > 0 && reps > 0 && ld_src >= C, EP24_E_ARG, "stats_gather: bad arguments");
+    hipLaunchKernelGGL(stats_gather_kernel, dim3(cap_grid((long)reps * 2 * C)), dim3(256), 0, S_, (const long long*)src, (long)ld_src,
+                       (long long*)dst, C, reps);
+    EP24_LAUNCH_CHECK("ep24_stats_gather");
+    return EP24_OK;
+}
+
+extern "C" int ep24_avgpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream) {
+    EP24_REQUIRE(x && y && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0 && H % 2 == 0 && W % 2 == 0, EP24_E_ARG, "avgpool2_fwd: bad arguments");
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(cap_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, S_, (const bf16*)x, (long)ld_x,
+                       (bf16*)y, (long)ld_y, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_avgpool2_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_avgpool2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C,
+                                 void* stream) {
+    EP24_REQUIRE(dy && dx && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && H % 2 == 0 && W % 2 == 0, EP24_E_ARG, "avgpool2_bwd: bad arguments");
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy, (long)ld_dy, (bf16*)dx,
+                       (long)ld_dx, accumulate, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_avgpool2_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_chanscale(void* x, int64_t ld, const float* keep, int B, int64_t HW, int C, void* stream) {
+    EP24_REQUIRE(x && keep && C % 8 == 0 && ld % 8 == 0 && B > 0 && HW > 0, EP24_E_ARG, "chanscale: bad arguments");
+    hipLaunchKernelGGL(chanscale_kernel, dim3(cap_grid((long)B * HW * (C / 8))), dim3(256), 0, S_, (bf16*)x, (long)ld, keep, B, (long)HW, C);
+    EP24_LAUNCH_CHECK("ep24_chanscale");
+    return EP24_OK;
+}
 
 extern "C" int ep24_im2col_bf16(const float* images, void* rows, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad,
                                 void* stream) {

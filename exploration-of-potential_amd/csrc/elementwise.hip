@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
     }
 }
 
-template <int UNROLL, int ACT>
+template <int UNROLL, int ACT, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma, const float* beta,
                                                                const long long* dgamma, const long long* dbeta, float* ggrad,
@@ -245,6 +245,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
                     const float zz = (float)vz[k][j];
                     const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
                     o[j] = (bf16)fmaf(-k3[j], zz, fmaf(k1[j], du, -k2[j]));
+                }
+                if (ACC) {                        // pre-activation BN over a shared input (DenseNet): dz collects every consumer
+                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dz + mm * ld_dz + cg * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)old[j] + (float)o[j]);
                 }
                 *reinterpret_cast<bf16x8*>(dz + mm * ld_dz + cg * 8) = o;
             }
@@ -1022,6 +1027,19 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
                        (bf16*)dz, ld_dz, M, C);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
+    return EP24_OK;
+}
+
+extern "C" int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                                         const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                                         float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                                         void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply_acc: null pointer");
+    EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply_acc: alignment");
+    auto kfn = act == 1 ? bn_act_bwd_apply_kernel<4, 1, true> : act == 2 ? bn_act_bwd_apply_kernel<4, 2, true> : bn_act_bwd_apply_kernel<4, 0, true>;
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, 16, 2048)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z, save, gamma, beta,
+                       (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad, (bf16*)dz, ld_dz, M, C);
+    EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply_acc");
     return EP24_OK;
 }
 

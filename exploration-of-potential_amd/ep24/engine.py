@@ -172,6 +172,14 @@ class ParamHome:
                 self._add(VecSeg([bn_.bias]))
             elif isinstance(mod, tuple) and mod[0] == "unused":      # in the state dict, not in the graph: gradient stays 0
                 self._add(VecSeg([mod[1]]))
+            elif isinstance(mod, tuple) and mod[0] == "conv":        # a conv on its own (DenseNet: BN sits in front of it)
+                w = mod[1].weight
+                k = w.shape[2]
+                self._add(ConvSeg([w], w.shape[0], 1, k * k * w.shape[1], need_dgrad=False) if mod[2] else
+                          ConvSeg([w], w.shape[0], k * k, w.shape[1]))
+            elif isinstance(mod, tuple) and mod[0] == "bn":
+                self._add(VecSeg([mod[1].weight]))
+                self._add(VecSeg([mod[1].bias]))
             elif isinstance(mod, enn.BaseConv):
                 w = mod.conv.weight
                 k = w.shape[2]
@@ -292,7 +300,12 @@ def exec_order(model):
     any other container (tests build single blocks) falls back to registration order."""
     if not isinstance(model, enn.YOLOX):
         for m in model.modules():
-            if isinstance(m, enn.ResBottleneck):          # tests build stand-alone stages of the swapped backbone
+            if isinstance(m, enn.ConvBlock):              # tests build stand-alone stages of the swapped backbones
+                yield ("bn", m.bn)
+                yield ("conv", m.conv, False)
+            elif isinstance(m, enn.BaseConv_DN):
+                yield ("unit", m.conv, m.bn, False)
+            elif isinstance(m, enn.ResBottleneck):
                 if m.downsample is not None:
                     yield ("unit", m.downsample[0], m.downsample[1], False)
                 for conv, bn in ((m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)):
@@ -316,6 +329,27 @@ def exec_order(model):
         for conv, bn in bb.used_units():
             yield ("unit", conv, bn, first)
             first = False
+    elif isinstance(bb, enn.DenseNet):
+        yield ("unit", bb.stem[0].conv, bb.stem[0].bn, True)
+
+        def block(blk):
+            for lay in blk.denseblock:
+                for cb in lay.conv_block:
+                    yield ("bn", cb.bn)
+                    yield ("conv", cb.conv, False)
+
+        def trans(t):
+            yield ("bn", t.trans[0].bn)
+            yield ("conv", t.trans[0].conv, False)
+        yield from block(bb.D1)
+        yield from trans(bb.T1)
+        yield from block(bb.D2)
+        yield ("unit", bb.baseconv1.conv, bb.baseconv1.bn, False)
+        yield from trans(bb.T2)
+        yield from block(bb.D3)
+        yield ("unit", bb.baseconv2.conv, bb.baseconv2.bn, False)
+        yield from trans(bb.T3)
+        yield from block(bb.D4)
     else:
         yield bb.stem.conv
         for name in ("dark2", "dark3", "dark4"):
@@ -388,6 +422,7 @@ class Engine:
         self.fuse_bn_bwd = os.environ.get("EP24_FUSED_BN") == "1"
         self._events = []
         self._bwd_builders = []
+        self.pre_bn_inputs = {}                  # BatchNorm module -> the Act its pre-activation form reads (tests)
         self.dyn = {"origin": None, "d_origin": None}   # run-time pointers (incoming gradient, L1-branch buffers)
         self.origin = None                       # [B,A,26] raw regression outputs, filled while use_l1 is on
         self._stats_specs, self._sum_specs = [], []
@@ -401,7 +436,8 @@ class Engine:
     def _f(self, name, *args, ev=None):
         """Append a forward launch; `ev` = the (name, args) that replaces it in the eval-mode list (default: the same)."""
         self.fwd.append((name, args))
-        self.fwd_eval.append(ev if ev is not None else (name, args))
+        if ev is not False:                          # ev=False: a training-only launch (batch statistics, dropout)
+            self.fwd_eval.append(ev if ev is not None else (name, args))
 
     def _b(self, name, args, writes=(), reads=None):
         if self._force_side and name[0] != "@" and not name.startswith("side:"):
@@ -418,7 +454,7 @@ class Engine:
         bb, neck, head = m.backbone.backbone, m.backbone, m.head
         F = S // 2
         self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
-        swapped = isinstance(bb, enn.ResNet)
+        swapped = isinstance(bb, (enn.ResNet, enn.DenseNet))
         c3, c4, c5 = (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels,
                                                        bb.dark5[0].conv.out_channels)
         H3, H4, H5 = S // 8, S // 16, S // 32
@@ -428,7 +464,8 @@ class Engine:
         cat_n3 = self.new_act(2 * c3, H4, H4)        # [bu_conv2(pan_out2) | fpn_out1]
         cat_n4 = self.new_act(2 * c4, H5, H5)        # [bu_conv1(pan_out1) | fpn_out0]
         if swapped:                                       # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
-            x2, x1, x0 = self.resnet(bb, cat_p3.slice(c3, c3), cat_p4.slice(c4, c4))
+            build = self.resnet if isinstance(bb, enn.ResNet) else self.densenet
+            x2, x1, x0 = build(bb, cat_p3.slice(c3, c3), cat_p4.slice(c4, c4))
         else:
             # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
             rows = self.new_act(112, F, F)
@@ -689,10 +726,11 @@ class Engine:
         self._add_builder(build_bwd)
         return y
 
-    def maxpool3s2(self, x):
+    def maxpool3s2(self, x, out=None):
         """nn.MaxPool2d(3, 2, 1) (darknet.py:303)."""
         OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
-        y = self.new_act(x.C, OH, OW)
+        y = self.new_act(x.C, OH, OW) if out is None else out
+        assert (y.H, y.W, y.C) == (OH, OW, x.C)
         idx = torch.zeros(y.M * x.C, dtype=torch.uint8, device=self.dev)
         self._f("maxpool3s2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, ptr(idx), x.B, x.H, x.W, x.C)
 
@@ -732,6 +770,153 @@ class Engine:
                 x = self.res_block(blk, x, out)
             feats.append(x)
         return feats[1], feats[2], feats[3]
+
+    # ---- DenseNet pieces (darknet.py:515-674) ------------------------------------------------------------------
+    def conv_raw(self, conv, x, out):
+        """A convolution whose output is stored as it is (no BatchNorm behind it: DenseNet's come in front) into ``out``,
+        typically a channel slice of a block's concatenation."""
+        home = self.home
+        seg = home.by_param[conv.weight]
+        k, s = conv.kernel_size[0], conv.stride[0]
+        B, H, W, cin, cout = x.B, x.H, x.W, x.C, seg.cout
+        assert x.C == seg.cin and (out.H, out.W, out.C) == ((H - 1) // s + 1, (W - 1) // s + 1, cout)
+        wf = ptr(home.wf, seg.wf_off)
+        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, out.ptr(), out.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s)
+        self.unit_acts[conv] = (x, None, out)
+
+        def build_bwd():
+            assert out.gready(), "activation without a gradient producer"
+            splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k, s)
+            soff = self._slab_floats
+            self._slab_floats += splits * seg.numel
+            idx = self._bwd_units
+            self._bwd_units += 1
+            # the chunk of the concatenation's gradient this conv owns is final here (every later consumer has run) and
+            # nothing writes those columns again, so the weight-gradient lane can read it in place
+            self._b("@side_wait_main", ())
+            self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, out.gptr(), out.gld, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
+                                                  splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k, s))
+            self._b("@side_record", (idx,))
+            self._pending_reduce.append((seg, splits, soff))
+            if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
+                self._flush_reduce()
+            if x.needs_grad:
+                acc = x.gwrite()
+                self._b("conv_dgrad_bf16", (out.gptr(), out.gld, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
+                                            seg.cout_pad, k, s))
+
+        self._add_builder(build_bwd)
+        return out
+
+    def pre_bn(self, bn, x, bstats, ld_stats):
+        """Pre-activation BatchNorm + ReLU over ``x`` (a prefix of a block's concatenation): the batch statistics are the
+        block's (``bstats``, one entry per channel of the whole concatenation, filled as chunks are produced); the layer
+        gathers its prefix.  In backward the input gradient ACCUMULATES into the concatenation's gradient."""
+        home = self.home
+        gam, bet = home.by_param[bn.weight], home.by_param[bn.bias]
+        C, M = x.C, x.M
+        a = self.new_act(C, x.H, x.W)
+        self.pre_bn_inputs[bn] = x
+        lstats = self._stats_slot(C)
+        save = torch.zeros(2 * C, dtype=torch.float32, device=self.dev)
+        sum_g, sum_b, _ = self._sums_slot(C)
+        flat, gflat = home.flat, home.gflat
+        self._f("stats_gather", bstats, ld_stats, lstats, C, STATS_REPLICAS, ev=False)
+        self._f("bn_act_fwd", x.ptr(), x.ld, lstats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
+                ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), a.ptr(), a.ld, None, 0, M, C, float(bn.eps),
+                float(bn.momentum), 2,
+                ev=("bn_act_infer", (x.ptr(), x.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
+                                     ptr(bn.running_var), a.ptr(), a.ld, None, 0, M, C, float(bn.eps), 2)))
+
+        def build_bwd():
+            assert a.gready(), "activation without a gradient producer"
+            acc = x.gwrite()
+            self._b("bn_act_bwd_reduce", (a.gptr(), a.gld, x.ptr(), x.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
+                                          sum_g, sum_b, M, C, 2), reads=a)
+            self._b("bn_act_bwd_apply_acc" if acc else "bn_act_bwd_apply",
+                    (a.gptr(), a.gld, x.ptr(), x.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sum_g, sum_b,
+                     ptr(gflat, gam.off), ptr(gflat, bet.off), x.gptr(), x.gld, M, C, 2), writes=(gam, bet))
+
+        self._add_builder(build_bwd)
+        return a
+
+    def chan_dropout(self, x, layer):
+        """nn.Dropout2d(0.3) of a dense layer (darknet.py:574-576), training only: the keep factors of the step live in
+        self.drop_keep[layer] (drawn by draw_dropout())."""
+        keep = self.drop_keep[layer]
+        self._f("chanscale", x.ptr(), x.ld, ptr(keep), x.B, x.H * x.W, x.C, ev=False)
+
+        def build_bwd():
+            assert x.gready()
+            _PENDING_GW.append(x.gregion())
+            self._b("chanscale", (x.gptr(), x.gld, ptr(keep), x.B, x.H * x.W, x.C))
+
+        self._add_builder(build_bwd)
+
+    def dense_block(self, blk, cat, c0, bstats, base):
+        """DenseBlock (darknet.py:582-597): ``cat`` [M, c0 + 32 n] holds the block input in its first c0 channels (its
+        statistics already in ``bstats``); every layer appends 32 channels and their statistics."""
+        ct = cat.C
+        for i, lay in enumerate(blk.denseblock):
+            ci = c0 + 32 * i
+            cb1, cb2 = lay.conv_block
+            a = self.pre_bn(cb1.bn, cat.slice(0, ci), bstats, ct)
+            b = self.unit(None, a, conv=cb1.conv, bn=cb2.bn, act=2)
+            chunk = cat.slice(ci, 32)
+            self.conv_raw(cb2.conv, b, chunk)
+            if lay.drop_rate > 0:
+                self.chan_dropout(chunk, base + i)
+            self._f("colstats", chunk.ptr(), chunk.ld, (lambda ci=ci: bstats() + 8 * ci), ct, chunk.M, 32, ev=False)
+        return cat
+
+    def densenet(self, bb, out3, out4):
+        B, S = self.B, self.S
+        rows = self.new_act(152, S // 2, S // 2)
+        rows.needs_grad = False
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, S, S, 7, 2, 3)
+        x = self.unit(None, rows, stem=True, conv=bb.stem[0].conv, bn=bb.stem[0].bn, act=2)
+        n_layers = sum(len(b.denseblock) for b in (bb.D1, bb.D2, bb.D3, bb.D4))
+        self.drop_keep = torch.ones(n_layers, B, 32, dtype=torch.float32, device=self.dev)
+        self.drop_p = 0.3
+        H = S // 4
+        base, cat, feats = 0, None, []
+        for bi, (blk, tr) in enumerate(((bb.D1, bb.T1), (bb.D2, bb.T2), (bb.D3, bb.T3), (bb.D4, None))):
+            c0 = 64 if bi == 0 else cat.C // 2
+            ncat = self.new_act(c0 + 32 * len(blk.denseblock), H, H)
+            bstats = self._stats_slot(ncat.C)
+            head = ncat.slice(0, c0)
+            if bi == 0:
+                self.maxpool3s2(x, out=head)
+            else:
+                t = self.new_act(c0, 2 * H, 2 * H)
+                self.conv_raw(tr_prev.trans[0].conv, self.pre_bn(tr_prev.trans[0].bn, cat, prev_stats, cat.C), t)
+                self.avgpool2(t, head)
+            self._f("colstats", head.ptr(), head.ld, bstats, ncat.C, head.M, c0, ev=False)
+            cat = self.dense_block(blk, ncat, c0, bstats, base)
+            base += len(blk.denseblock)
+            feats.append(cat)
+            tr_prev, prev_stats = tr, bstats
+            H //= 2
+        c3 = self.unit(None, feats[1], out=out3, conv=bb.baseconv1.conv, bn=bb.baseconv1.bn, act=2)
+        c4 = self.unit(None, feats[2], out=out4, conv=bb.baseconv2.conv, bn=bb.baseconv2.bn, act=2)
+        return c3, c4, feats[3]
+
+    def avgpool2(self, x, y):
+        """nn.AvgPool2d(2, 2) into ``y`` (the head of the next block's concatenation)."""
+        self._f("avgpool2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, x.B, x.H, x.W, x.C)
+
+        def build_bwd():
+            assert y.gready()
+            acc = x.gwrite()
+            self._b("avgpool2_bwd", (y.gptr(), y.gld, x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
+
+        self._add_builder(build_bwd)
+        return y
+
+    def draw_dropout(self):
+        """New Dropout2d keep factors for the next training forward (torch's generator on the device: no host sync)."""
+        if getattr(self, "drop_keep", None) is not None and not getattr(self, "fixed_dropout", False):
+            self.drop_keep.bernoulli_(1.0 - self.drop_p).div_(1.0 - self.drop_p)
 
     def spp(self, mod, x):
         """SPPBottleneck: conv1 -> cat(x, pool5, pool9, pool13) -> conv2 (network_blocks.py:139-144)."""
@@ -919,6 +1104,8 @@ class Engine:
         """Train-mode forward into self.outputs ([B,A,27+C] fp32, decoded)."""
         if images is not None:
             self.images.copy_(images)
+        if not torch.cuda.is_current_stream_capturing():
+            self.draw_dropout()                      # a captured step draws before it replays (ep24.train)
         self.zero_step_buffers()
         self.home.pack()
         self._run(self.fwd)

@@ -181,8 +181,98 @@ def resnet50():
     return ResNet((3, 4, 6, 3))
 
 
+class BaseConv_DN(nn.Module):
+    """conv -> BatchNorm -> ReLU of the DenseNet stem and output convs (darknet.py:518-529)."""
+
+    def __init__(self, in_channels, out_channels, **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, eps=0.001)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class ConvBlock(nn.Module):
+    """Pre-activation BatchNorm -> ReLU -> conv (darknet.py:532-543)."""
+
+    def __init__(self, in_channels, out_channels, **kwargs):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(in_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(in_channels, out_channels, **kwargs)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class Transition(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.trans = nn.Sequential(ConvBlock(in_channels, out_channels, kernel_size=1, stride=1, bias=False), nn.AvgPool2d(2, 2))
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class DenseLayer(nn.Module):
+    """1x1 conv to 4k channels, 3x3 conv to k = 32, Dropout2d (darknet.py:560-577)."""
+
+    def __init__(self, in_channels, drop_rate=0):
+        super().__init__()
+        self.growth_rate, self.bn_size = 32, 4
+        self.conv_block = nn.Sequential(ConvBlock(in_channels, 128, kernel_size=1, stride=1, bias=False),
+                                        ConvBlock(128, 32, kernel_size=3, stride=1, padding=1, bias=False))
+        self.drop_rate = float(drop_rate)
+        self.dropout = nn.Dropout2d(self.drop_rate)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class DenseBlock(nn.Module):
+    def __init__(self, num_layers, in_channels, drop_rate=0):
+        super().__init__()
+        self.growth_rate = 32
+        self.denseblock = nn.Sequential(*[DenseLayer(in_channels + i * 32, drop_rate=drop_rate) for i in range(num_layers)])
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class DenseNet(nn.Module):
+    """``densenet121()`` of the reference (darknet.py:586-674): growth 32, blocks [6, 12, 24, 16], Dropout2d(0.3) in every dense
+    layer; dark3 / dark4 = 1x1 conv-BN-ReLU of the D2 / D3 outputs, dark5 = the raw D4 concatenation (1024 channels)."""
+
+    def __init__(self, growth_rate=32, block_layer=(6, 12, 24, 16)):
+        super().__init__()
+        self.out_features = ("dark3", "dark4", "dark5")
+        self.growth_rate, self.block_config, self.num_init_channels = growth_rate, list(block_layer), 64
+        self.stem = nn.Sequential(BaseConv_DN(3, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.MaxPool2d(3, 2, 1))
+        t1 = 64 + block_layer[0] * 32
+        t2 = t1 // 2 + block_layer[1] * 32
+        t3 = t2 // 2 + block_layer[2] * 32
+        self.D1 = DenseBlock(block_layer[0], 64, drop_rate=0.3)
+        self.T1 = Transition(t1, t1 // 2)
+        self.D2 = DenseBlock(block_layer[1], t1 // 2, drop_rate=0.3)
+        self.T2 = Transition(t2, t2 // 2)
+        self.D3 = DenseBlock(block_layer[2], t2 // 2, drop_rate=0.3)
+        self.T3 = Transition(t3, t3 // 2)
+        self.D4 = DenseBlock(block_layer[3], t3 // 2, drop_rate=0.3)
+        self.baseconv1 = BaseConv_DN(t2, t2 // 2, kernel_size=1, bias=False)
+        self.baseconv2 = BaseConv_DN(t3, t3 // 2, kernel_size=1, bias=False)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+def densenet121():
+    return DenseNet(32, (6, 12, 24, 16))
+
+
 class YOLOPAFPN(nn.Module):
-    """``backbone_type`` is the switch of yolox/models/yolo_pafpn.py:31-38 ('darknet' | 'resnet'; the 24p tree's own
+    """``backbone_type`` is the switch of yolox/models/yolo_pafpn.py:31-38 ('darknet' | 'resnet' | 'densenet'; the 24p tree's own
     YOLOPAFPN hard-codes CSPDarknet, so it is a keyword here and the positional signature stays the 24p one)."""
 
     def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
@@ -194,8 +284,12 @@ class YOLOPAFPN(nn.Module):
             if width != 1.0:
                 raise NotImplementedError("resnet50() emits 256/512/1024 channels: it pairs with width 1.0 (BASELINE config 4)")
             self.backbone = resnet50()
+        elif backbone_type == "densenet":
+            if width != 1.0:
+                raise NotImplementedError("densenet121() emits 256/512/1024 channels: it pairs with width 1.0 (BASELINE config 4)")
+            self.backbone = densenet121()
         else:
-            raise NotImplementedError("backbone_type %r: 'darknet' and 'resnet' are built ('densenet' / 'vgg' are not)" % backbone_type)
+            raise NotImplementedError("backbone_type %r: 'darknet', 'resnet' and 'densenet' are built ('vgg' is not)" % backbone_type)
         self.backbone_type = backbone_type
         self.in_features = in_features
         self.in_channels = in_channels

@@ -216,6 +216,7 @@ class TrainStep:
         if self.graphs is None and self.use_graph:
             self._capture()
         self._push_hparams()
+        eng.draw_dropout()                               # DenseNet backbone: this step's Dropout2d factors (device RNG)
         if not self.use_graph:
             self._phase_forward()
             self._phase_backward(0, len(eng.bwd))

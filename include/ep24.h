@@ -354,6 +354,27 @@ int ep24_maxpool3s2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, uint
 int ep24_maxpool3s2_bwd(const void* dy, int64_t ld_dy, const uint8_t* idx, void* dx, int64_t ld_dx, int accumulate, int B,
                         int H, int W, int C, void* stream);
 
+/* DenseNet pieces (darknet.py:515-674).  Its pre-activation blocks (BatchNorm -> ReLU -> conv over a growing concatenation)
+ * run as ep24_bn_act_fwd on the shared input with per-layer statistics gathered from the block's, the input gradient of
+ * every consumer accumulating through ep24_bn_act_bwd_apply_acc. */
+/* per-channel sum / sum of squares of x [M][C] (row stride ld) added to stats[0][0..1][c] with channel stride ld_stats
+ * (the conv epilogue's fixed-point layout [rep][2][ld_stats]). */
+int ep24_colstats(const void* x, int64_t ld, int64_t* stats, int64_t ld_stats, int64_t M, int C, void* stream);
+/* dst[rep][2][C] = the first C channels of src[rep][2][ld_src]. */
+int ep24_stats_gather(const int64_t* src, int64_t ld_src, int64_t* dst, int C, int reps, void* stream);
+/* ep24_bn_act_bwd_apply with dz += instead of dz = (same arguments). */
+int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                              const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                              float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                              void* stream);
+/* nn.AvgPool2d(2, 2) of the Transition blocks, NHWC bf16. */
+int ep24_avgpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream);
+int ep24_avgpool2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C,
+                      void* stream);
+/* nn.Dropout2d as data: x[n, :, :, c] *= keep[n*C + c] in place (keep = 0 or 1/(1-p), drawn by the host once per step);
+ * the same call is its backward. */
+int ep24_chanscale(void* x, int64_t ld, const float* keep, int B, int64_t HW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

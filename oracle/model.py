@@ -187,12 +187,108 @@ class ResNetBackbone(nn.Module):
         return c3, c4, self.layer4(c4)
 
 
+def bn_act_conv(x, bn, conv, training):
+    """Pre-activation block of DenseNet (darknet.py:532-543): BatchNorm over the (concatenated) input -> ReLU -> conv, with
+    the product's bf16 storage points emulated on request (the normalised, rectified tensor is stored; the conv output is
+    stored raw)."""
+    if not EMULATE_BF16:
+        return conv(F.relu(bn(x)))
+    mean = x.mean((0, 2, 3))
+    var = x.var((0, 2, 3), unbiased=False)
+    if training:
+        with torch.no_grad():
+            n = x.numel() / x.shape[1]
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(m * mean)
+            bn.running_var.mul_(1 - m).add_(m * var * n / max(n - 1, 1))
+            bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    scale = bn.weight / torch.sqrt(var + bn.eps)
+    a = _q(F.relu(x * scale.view(1, -1, 1, 1) + (bn.bias - mean * scale).view(1, -1, 1, 1)))
+    return _q(F.conv2d(a, _q(conv.weight), None, conv.stride, conv.padding))
+
+
+class DenseNetBackbone(nn.Module):
+    """densenet121() of darknet.py:515-674 with the reference's state-dict names.  ``keep`` (optional, [n_layers, B, 32] of 0
+    or 1/(1-p)) replaces the Dropout2d draws, so that training-mode runs are reproducible (the reference's masks are
+    captured by the golden generator and handed to both sides)."""
+
+    def __init__(self, blocks=(6, 12, 24, 16)):
+        super().__init__()
+
+        def cb(cin, cout, k):
+            m = nn.Module()
+            m.bn, m.relu, m.conv = nn.BatchNorm2d(cin), nn.ReLU(), nn.Conv2d(cin, cout, k, 1, k // 2, bias=False)
+            return m
+
+        def dn(cin, cout, k, s=1):
+            m = nn.Module()
+            m.conv, m.bn, m.relu = nn.Conv2d(cin, cout, k, s, k // 2, bias=False), nn.BatchNorm2d(cout, eps=0.001), nn.ReLU()
+            return m
+
+        def block(n, cin):
+            m = nn.Module()
+            layers = []
+            for i in range(n):
+                lay = nn.Module()
+                lay.conv_block = nn.Sequential(cb(cin + 32 * i, 128, 1), cb(128, 32, 3))
+                lay.dropout = nn.Dropout2d(0.3)
+                layers.append(lay)
+            m.denseblock = nn.Sequential(*layers)
+            return m
+
+        def trans(cin):
+            m = nn.Module()
+            m.trans = nn.Sequential(cb(cin, cin // 2, 1), nn.AvgPool2d(2, 2))
+            return m
+
+        self.stem = nn.Sequential(dn(3, 64, 7, 2), nn.MaxPool2d(3, 2, 1))
+        t1 = 64 + blocks[0] * 32
+        t2 = t1 // 2 + blocks[1] * 32
+        t3 = t2 // 2 + blocks[2] * 32
+        self.D1, self.T1 = block(blocks[0], 64), trans(t1)
+        self.D2, self.T2 = block(blocks[1], t1 // 2), trans(t2)
+        self.D3, self.T3 = block(blocks[2], t2 // 2), trans(t3)
+        self.D4 = block(blocks[3], t3 // 2)
+        self.baseconv1, self.baseconv2 = dn(t2, t2 // 2, 1), dn(t3, t3 // 2, 1)
+        self.keep = None
+
+    def _block(self, blk, x, base):
+        for i, lay in enumerate(blk.denseblock):
+            c1, c2 = lay.conv_block
+            z1 = bn_act_conv(x, c1.bn, c1.conv, self.training)
+            z2 = bn_act_conv(z1, c2.bn, c2.conv, self.training)
+            if self.training:
+                if self.keep is not None:
+                    z2 = z2 * self.keep[base + i].view(z2.shape[0], 32, 1, 1)
+                    z2 = _q(z2) if EMULATE_BF16 else z2
+                else:
+                    z2 = lay.dropout(z2)
+            x = torch.cat((x, z2), 1)
+        return x, base + len(blk.denseblock)
+
+    def _trans(self, t, x):
+        return F.avg_pool2d(bn_act_conv(x, t.trans[0].bn, t.trans[0].conv, self.training), 2, 2)
+
+    def forward(self, x):
+        st = self.stem[0]
+        x = F.max_pool2d(conv_bn_act(x, st.conv, st.bn, "relu", self.training), 3, 2, 1)
+        x, n = self._block(self.D1, x, 0)
+        x, n = self._block(self.D2, self._trans(self.T1, x), n)
+        c3 = conv_bn_act(x, self.baseconv1.conv, self.baseconv1.bn, "relu", self.training)
+        x, n = self._block(self.D3, self._trans(self.T2, x), n)
+        c4 = conv_bn_act(x, self.baseconv2.conv, self.baseconv2.bn, "relu", self.training)
+        x, n = self._block(self.D4, self._trans(self.T3, x), n)
+        return c3, c4, x
+
+
 class Neck(nn.Module):
     def __init__(self, depth, width, in_channels=(256, 512, 1024), backbone_type="darknet"):
         super().__init__()
         c3, c4, c5 = [int(c * width) for c in in_channels]
         n = round(3 * depth)
-        self.backbone = Backbone(depth, width) if backbone_type == "darknet" else ResNetBackbone()
+        self.backbone = {"darknet": lambda: Backbone(depth, width), "resnet": ResNetBackbone, "densenet": DenseNetBackbone}[backbone_type]()
         self.lateral_conv0 = Unit(c5, c4, 1)
         self.C3_p4 = CSP(2 * c4, c4, n, add=False)
         self.reduce_conv1 = Unit(c4, c3, 1)

@@ -651,10 +651,60 @@ def gen_resnet(utils, models):
         store["out_eval"] = model(x, train=False)[:, ::3]
     save("g15_resnet", **store)
 
+DENSE_GRADS = ("backbone.backbone.stem.0.conv.weight", "backbone.backbone.D1.denseblock.0.conv_block.0.bn.weight",
+               "backbone.backbone.D1.denseblock.5.conv_block.1.conv.weight", "backbone.backbone.T1.trans.0.conv.weight",
+               "backbone.backbone.D2.denseblock.3.conv_block.0.conv.weight", "backbone.backbone.baseconv1.conv.weight",
+               "backbone.backbone.D3.denseblock.23.conv_block.1.bn.bias", "backbone.backbone.T3.trans.0.bn.weight",
+               "backbone.backbone.D4.denseblock.15.conv_block.1.conv.weight", "backbone.lateral_conv0.conv.weight",
+               "head.stems.0.conv.weight")
+
+
+def gen_densenet(utils, models):
+    """YOLOX with ``backbone.backbone = densenet121()``: like G15; the Dropout2d(0.3) draws of the training-mode run are
+    recorded (per layer, sample and channel) so that the oracle and the product can replay them."""
+    dk = importlib.import_module("models.darknet")
+    torch.manual_seed(0)
+    backbone = models.YOLOPAFPN(0.33, 1.0, in_channels=[256, 512, 1024], act="silu")
+    backbone.backbone = dk.densenet121()
+    head = models.YOLOXHead(80, 1.0, in_channels=[256, 512, 1024], act="silu")
+    model = models.YOLOX(backbone, head)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    synth.fill_state(model, seed=16)
+    model.train()
+    keeps = []
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.register_forward_hook(lambda mod, inp, out: keeps.append((out.abs().sum((2, 3)) > 0).float() / (1.0 - mod.p)))
+    B, S = 2, 256
+    torch.manual_seed(161)
+    x = synth.make_images(B, S, seed=162)
+    out = model(x, train=True)[3]
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(152)) * torch.tensor([0.05] * 26 + [1.0] * 81)
+    (out * gy).sum().backward()
+    sd = dict(model.named_parameters())
+    keep = torch.stack(keeps)
+    assert keep.shape == (58, B, 32) and 0.5 < float((keep > 0).float().mean()) < 0.9
+    store = {"B": B, "S": S, "out": out.detach()[:, ::3], "keys": np.array(sorted(model.state_dict().keys())), "keep": keep,
+             "n_params": sum(p.numel() for p in model.parameters())}
+    for name in DENSE_GRADS:
+        g = sd[name].grad
+        store["g:" + name] = g if g.numel() <= 40000 else g.reshape(-1)[:: g.numel() // 20000 + 1]
+        store["gn:" + name] = float(g.double().norm())
+    msd = model.state_dict()
+    for name in ("backbone.backbone.stem.0.bn.running_mean", "backbone.backbone.D1.denseblock.2.conv_block.0.bn.running_var",
+                 "backbone.backbone.T2.trans.0.bn.running_mean"):
+        store["b:" + name] = msd[name]
+    model.eval()
+    with torch.no_grad():
+        store["out_eval"] = model(x, train=False)[:, ::3]
+    save("g16_densenet", **store)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet", "densenet"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -674,3 +724,5 @@ if __name__ == "__main__":
         gen_input()
     if "resnet" in which:
         gen_resnet(utils, models)
+    if "densenet" in which:
+        gen_densenet(utils, models)
