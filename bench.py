@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--long-run", action="store_true", help="non-default: also run the SURVEY 8f N2 pieces inside the step (L1 "
                     "branch on, ModelEMA fused into the update, a yoloxwarmcos rate pushed every step)")
+    ap.add_argument("--fisheye", action="store_true", help="non-default: BASELINE config 5 - every step first warps its uint8 source images "
+                    "(and masks) with the sector warp on the GPU and letterboxes the results into the network input")
     ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet"], help="non-default: BASELINE config 4 (backbone swap)")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     a = ap.parse_args()
@@ -249,6 +251,27 @@ def main():
     ts.eng.images.copy_(images)
     ts.labels.copy_(labels)
 
+    if a.fisheye:
+        from ep24 import input as ein, sector as esec
+        dist_op = esec.Image_Distortion(str(dev))
+        g8 = torch.Generator().manual_seed(77 + shard)
+        src = [(torch.rand(a.size, a.size, 3, generator=g8) * 255).to(torch.uint8).to(dev) for _ in range(a.batch)]
+        msk = [torch.zeros(a.size, a.size, 3, dtype=torch.uint8, device=dev) for _ in range(a.batch)]
+        for mk in msk:
+            mk[a.size // 4: a.size // 2, a.size // 4: a.size // 2] = 255
+        thetas = [30 + 60 * i // max(a.batch - 1, 1) for i in range(a.batch)]          # Theta in [30, 90], SURVEY 8d C5
+        plain_step2 = ts.step
+
+        def step_with_warp(*args):
+            warped = []
+            for im, mk, th in zip(src, msk, thetas):
+                winner, cw, box, T = dist_op._map(th, a.size, a.size, None)
+                warped.append(dist_op._warp(im, winner, cw, box, T, 114))
+                dist_op._warp(mk, winner, cw, box, T, 0)
+            ein.preproc_batch(warped, (a.size, a.size), device=str(dev), out=ts.eng.images)
+            return plain_step2(*args)
+        ts.step = step_with_warp
+
     for _ in range(a.warmup):
         ts.step()
     if world > 1:
@@ -284,7 +307,8 @@ def main():
                                                                                    a.size, a.size, a.batch, a.gts),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
                                      else "fwd+loss, update, backward as two lanes of captured segments"),
-                       **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {})},
+                       **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
+                       **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),
             "step_mfma_frac": round(ips / world * {"darknet": TRAIN_GFLOP_PER_IMAGE, "resnet": 290.7, "densenet": 388.0}[a.backbone] * (a.size / 640.0) ** 2 / 1e3
                                     / MFMA_BF16_PEAK_TFLOPS, 4),      # swaps: 3 x 2 x 48.45 / 64.67 GMAC
