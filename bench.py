@@ -218,6 +218,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # EP24_NCCL_SOLO=1 (one-GPU box): a one-rank RCCL group, so that the reducer path - buckets, communication stream,
+    # the nccl backend's stream semantics next to the captured segments - runs exactly as it will on 8 GPUs
+    solo = world == 1 and os.environ.get("EP24_NCCL_SOLO") == "1"
+    if solo:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
 
     torch.manual_seed(0)                                     # identical replicas on every rank
     model = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0, backbone_type=a.backbone), enn.YOLOXHead(80, 1.0))
@@ -227,7 +232,7 @@ def main():
     model.head.initialize_biases(1e-2)
     model.to(dev)
     lf = eloss.Loss_Function(80)
-    reducer = dp.GradReducer() if world > 1 else None
+    reducer = dp.GradReducer() if (world > 1 or solo) else None
     ema, sched = None, None
     if a.long_run:
         from ep24.ema import ModelEMA
@@ -326,6 +331,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif solo:
         dist.destroy_process_group()
 
 
