@@ -7,7 +7,7 @@ normalisation, gradients averaged over ranks.
 
 MI355X form: all gradients already live in ONE flat fp32 buffer (ep24.engine.ParamHome), laid out in
 execution order, so backward completes it from the tail.  The buffer is cut into a few large buckets
-(default 32 MB: xGMI is point-to-point, few large collectives beat many small ones); the backward launch list
+(4 MB, 32 MB, then 96 MB pieces from the head of the buffer: see plan()); the backward launch list
 is cut where a bucket's last writer has run, and each bucket's all-reduce is issued on a communication stream
 while the next backward segment (its own hipGraph) keeps the compute stream busy.  No collective sits inside
 a captured graph.  Works unchanged with the gloo backend on CPU tensors (tests).
@@ -17,13 +17,19 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes=32 << 20):
+    def __init__(self, group=None, bucket_bytes=32 << 20, first_bucket_bytes=4 << 20):
         if not dist.is_initialized():
             raise RuntimeError("ep24.dp: torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        import os
+        if os.environ.get("EP24_BUCKET_MB"):
+            bucket_bytes = int(os.environ["EP24_BUCKET_MB"]) << 20
         self.bucket_bytes = bucket_bytes
+        # the head of the buffer (stem, dark2: few parameters) is what backward finishes LAST, and the all-reduce of that
+        # bucket is the only one nothing overlaps: it is kept small so that the exposed tail is a fraction of a 32 MB ring pass
+        self.first_bucket_bytes = min(first_bucket_bytes, bucket_bytes)
         self.flat = None
         self.buckets = []          # (lo, hi) element ranges in readiness order
         self._cuts = None
@@ -37,8 +43,18 @@ class GradReducer:
         Chooses buckets and the backward indices after which each bucket is complete."""
         self.flat = flat
         n = flat.numel()
+        # bucket sizes follow the time backward leaves for them: the buffer is in execution order, so its head completes last.
+        # [first 4 MB | one bucket_bytes bucket | the rest in 3 x bucket_bytes pieces]: the late buckets are small (their
+        # all-reduce has little backward left to hide under), the early ones - most of the parameters sit in dark5, the
+        # neck and the head, whose gradients are complete before half of backward has run - are few and large (xGMI is
+        # point to point: few large collectives; every collective and every extra segment cut costs ~0.08 ms of launches)
         per = max(1, self.bucket_bytes // flat.element_size())
-        bounds = list(range(0, n, per)) + [n]
+        first = max(1, self.first_bucket_bytes // flat.element_size())
+        bounds = [0]
+        for size in (first, per):
+            if bounds[-1] + size < n:
+                bounds.append(bounds[-1] + size)
+        bounds += list(range(bounds[-1] + 3 * per, n, 3 * per)) + [n]
         ranges = list(zip(bounds[:-1], bounds[1:]))
         last = [-1] * len(ranges)
         for i, ws in enumerate(writes):

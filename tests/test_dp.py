@@ -41,7 +41,7 @@ def _plan_case(rank, world):
     flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
     # backward "ops": op i writes [900-100*i, 1000-100*i) -> the buffer completes from its tail
     writes = [[(900 - 100 * i, 100)] for i in range(10)]
-    red = dp.GradReducer(bucket_bytes=250 * 4)
+    red = dp.GradReducer(bucket_bytes=250 * 4, first_bucket_bytes=50 * 4)
     red.plan(flat, writes)
     cuts = red.cuts()
     assert cuts[0] == 0 and cuts[-1] == 10 and cuts == sorted(set(cuts))
@@ -55,7 +55,8 @@ def _plan_case(rank, world):
             order.append((lo, hi))
         red.bucket_ready(seg)
     red.wait()
-    assert sorted(order) == [(0, 250), (250, 500), (500, 750), (750, 1000)] and order[0] == (750, 1000)
+    # graduated sizes from the head of the buffer (what backward completes last): 50 | 250 | the rest in 750-element pieces
+    assert sorted(order) == [(0, 50), (50, 300), (300, 1000)] and order[0] == (300, 1000) and order[-1] == (0, 50)
     want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     return bool(torch.equal(flat, want))
 
