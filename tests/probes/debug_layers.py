@@ -1,7 +1,7 @@
 """Debug helper (GPU box): per-layer comparison of the HIP plan against the bf16-emulating oracle."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
 from ep24 import nn as enn, synth
 from oracle import model as om

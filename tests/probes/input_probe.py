@@ -1,7 +1,7 @@
 """GPU box helper: throughput of the input-pipeline kernels, sources resident in HBM and PCIe-inclusive,
 next to the CPU oracle.  usage: input_probe.py [batch] [h] [w] [S]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,7 +1,7 @@
 """GPU box helper: throughput of the label-generation kernels with the masks resident in HBM, next to the
 CPU oracle.  usage: labels_probe.py [n_objects] [H] [W]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,6 +1,6 @@
 """GPU box helper: per-image time of the sector warp (a13) on device-resident inputs vs the CPU oracle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
 sys.path.insert(0, ROOT)
 import numpy as np
