@@ -311,7 +311,7 @@ def main():
                                    "SimOTA + 24-circle GIoU loss, SGD nesterov" % ({"darknet": "CSPDarknet53", "resnet": "resnet50 backbone swap", "densenet": "densenet121 backbone swap"}[a.backbone],
                                                                                    a.size, a.size, a.batch, a.gts),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
-                                     else "fwd+loss, update, backward as two lanes of captured segments"),
+                                     else "forward and backward as two lanes of captured segments, loss, update"),
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
                        **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),

@@ -482,6 +482,7 @@ class Engine:
         fpn_out1 = self.unit(neck.reduce_conv1, f_out0, out=cat_n3.slice(c3, c3))
         self.up2(fpn_out1, cat_p3.slice(0, c3))
         pan_out2 = self.csp(neck.C3_p3, cat_p3)
+        self.fwd_fork = len(self.fwd)                 # pan_out2 is complete: head level 0 can start (ep24.train runs it on a second lane)
         self.unit(neck.bu_conv2, pan_out2, out=cat_n3.slice(0, c3))
         pan_out1 = self.csp(neck.C3_n3, cat_n3)
         self.unit(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
@@ -491,8 +492,12 @@ class Engine:
         self.outputs = torch.zeros(B, self.A, self.ncols, dtype=torch.float32, device=self.dev)
         a0 = 0
         self.levels = []
+        self.fwd_head0 = None
         for k, feat in enumerate((pan_out2, pan_out1, pan_out0)):
+            lo = len(self.fwd)
             self.head_level(head, k, feat, a0)
+            if k == 0:
+                self.fwd_head0 = (lo, len(self.fwd))
             self._cur_tag = None
             a0 += feat.H * feat.W
         # anchor tables of the train-mode tuple (yolo_head_24p.py:172-176)

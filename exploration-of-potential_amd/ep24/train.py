@@ -89,6 +89,8 @@ class TrainStep:
         # replays each lane as a chain of captured segments (no launch gaps: 28.7 ms/step at YOLOX-l / B=20);
         # False launches the same lanes from the host with per-layer events (29.4 ms)
         self.graph_backward = graph_backward
+        import os
+        self.parallel_forward = graph_backward and not os.environ.get("EP24_NO_PAR_FWD")
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
             reducer.attach(self.home, eng)
@@ -123,6 +125,34 @@ class TrainStep:
             self._hp_dirty = False
 
     # the three phases, each a pure launch sequence on the current stream
+    # The forward pass as two lanes too: from the point where the 80x80 PAFPN output is complete, the level-0 head chain
+    # (the big kernels) runs on the second lane next to the rest of the neck and the level-1/2 heads (40x40 / 20x20 kernels
+    # that leave most of the chip idle).  Three graphs, two events, no cross-stream edge inside a graph.
+    def _fwd_split(self):
+        eng = self.eng
+        if getattr(eng, "fwd_head0", None) is None or not self.parallel_forward:
+            return None
+        lo, hi = eng.fwd_head0
+        fork = eng.fwd_fork
+        return eng.fwd[:fork], eng.fwd[fork:lo] + eng.fwd[hi:], eng.fwd[lo:hi]
+
+    def _phase_forward_head(self):
+        eng = self.eng
+        self.home.zero_grad()
+        if not torch.cuda.is_current_stream_capturing():
+            eng.draw_dropout()
+        eng.zero_step_buffers()
+        self.home.pack()
+        eng.run_lane(self._fwd_split()[0])
+
+    def _phase_loss(self):
+        eng = self.eng
+        origin = eng.origin if self.use_l1 else None
+        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin)
+        eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
+        eng.dyn["dout"] = self.ws.dout.data_ptr()
+        eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
+
     def _phase_forward(self):
         eng = self.eng
         self.home.zero_grad()
@@ -188,7 +218,14 @@ class TrainStep:
             pool[0] = g.pool()
             return g
 
-        self.g_fwd = capture(self._phase_forward)
+        split = self._fwd_split()
+        if split is None:
+            self.g_fwd = capture(self._phase_forward)
+        else:
+            self.g_fwd = (capture(self._phase_forward_head), capture(lambda: eng.run_lane(split[1])),
+                          capture(lambda: eng.run_lane(split[2])), capture(self._phase_loss))
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=eng.dev)
         self.g_upd = capture(self._phase_update)
         self._cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
         self.g_bwd = None
@@ -224,7 +261,22 @@ class TrainStep:
                 self.reducer.reduce_all()
             self._phase_update()
             return self.ws.result
-        self.g_fwd.replay()
+        if isinstance(self.g_fwd, tuple):
+            g1, g_main, g_side, g_loss = self.g_fwd
+            main, side = torch.cuda.current_stream(), self._side
+            g1.replay()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            g_main.replay()                           # the main lane's graph is enqueued first (see the backward loop)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                g_side.replay()
+            ev2 = torch.cuda.Event()
+            ev2.record(side)
+            main.wait_event(ev2)
+            g_loss.replay()
+        else:
+            self.g_fwd.replay()
         if self.g_bwd is not None:
             main, side = torch.cuda.current_stream(), self._side
             # Host order matters: a graph launch into a stream that is still waiting on an event can hold the host, so
