@@ -485,6 +485,7 @@ class Engine:
         self.fwd_fork = len(self.fwd)                 # pan_out2 is complete: head level 0 can start (ep24.train runs it on a second lane)
         self.unit(neck.bu_conv2, pan_out2, out=cat_n3.slice(0, c3))
         pan_out1 = self.csp(neck.C3_n3, cat_n3)
+        self.fwd_fork1 = len(self.fwd)                # pan_out1 is complete: head level 1 can start
         self.unit(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
         pan_out0 = self.csp(neck.C3_n4, cat_n4)
         # head
@@ -498,6 +499,8 @@ class Engine:
             self.head_level(head, k, feat, a0)
             if k == 0:
                 self.fwd_head0 = (lo, len(self.fwd))
+            if k == 1:
+                self.fwd_head1 = (lo, len(self.fwd))
             self._cur_tag = None
             a0 += feat.H * feat.W
         # anchor tables of the train-mode tuple (yolo_head_24p.py:172-176)

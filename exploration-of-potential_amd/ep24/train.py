@@ -91,6 +91,7 @@ class TrainStep:
         self.graph_backward = graph_backward
         import os
         self.parallel_forward = graph_backward and not os.environ.get("EP24_NO_PAR_FWD")
+        self.forward_lanes = int(os.environ.get("EP24_FWD_LANES", 2))
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
             reducer.attach(self.home, eng)
@@ -134,6 +135,9 @@ class TrainStep:
             return None
         lo, hi = eng.fwd_head0
         fork = eng.fwd_fork
+        if self.forward_lanes >= 3:                   # a third lane: head level 1 from the point its input is complete
+            f1, (lo1, hi1) = eng.fwd_fork1, eng.fwd_head1
+            return eng.fwd[:fork], eng.fwd[fork:f1], eng.fwd[lo:hi], eng.fwd[f1:lo] + eng.fwd[hi1:], eng.fwd[lo1:hi1]
         return eng.fwd[:fork], eng.fwd[fork:lo] + eng.fwd[hi:], eng.fwd[lo:hi]
 
     def _phase_forward_head(self):
@@ -222,10 +226,12 @@ class TrainStep:
         if split is None:
             self.g_fwd = capture(self._phase_forward)
         else:
-            self.g_fwd = (capture(self._phase_forward_head), capture(lambda: eng.run_lane(split[1])),
-                          capture(lambda: eng.run_lane(split[2])), capture(self._phase_loss))
+            self.g_fwd = (capture(self._phase_forward_head),) + tuple(capture(lambda l=l: eng.run_lane(l)) for l in split[1:]) + \
+                         (capture(self._phase_loss),)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
+            if len(split) == 5 and getattr(self, "_side2", None) is None:
+                self._side2 = torch.cuda.Stream(device=eng.dev)
         self.g_upd = capture(self._phase_update)
         self._cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
         self.g_bwd = None
@@ -261,7 +267,26 @@ class TrainStep:
                 self.reducer.reduce_all()
             self._phase_update()
             return self.ws.result
-        if isinstance(self.g_fwd, tuple):
+        if isinstance(self.g_fwd, tuple) and len(self.g_fwd) == 6:
+            g1, g_main_a, g_side, g_main_b, g_side2, g_loss = self.g_fwd
+            main, side, side2 = torch.cuda.current_stream(), self._side, self._side2
+            g1.replay()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            g_main_a.replay()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                g_side.replay()
+            eva = torch.cuda.Event()
+            eva.record(main)
+            g_main_b.replay()
+            side2.wait_event(eva)
+            with torch.cuda.stream(side2):
+                g_side2.replay()
+            main.wait_stream(side)
+            main.wait_stream(side2)
+            g_loss.replay()
+        elif isinstance(self.g_fwd, tuple):
             g1, g_main, g_side, g_loss = self.g_fwd
             main, side = torch.cuda.current_stream(), self._side
             g1.replay()
