@@ -186,3 +186,25 @@ def test_full_batch_vs_oracle():
     assert float((g - og).abs().max()) <= 2e-3 * float(og.abs().max())
     # gradient is zero exactly where the oracle's is (background anchors, reg/cls columns)
     assert torch.equal(g[..., :26] != 0, og[..., :26] != 0)
+
+
+def test_batch_without_any_label_vs_oracle():
+    """Every image empty (losses.py:212-217 for all of them): num_fg clamps to 1, only the objectness term is non-zero,
+    the gradient is the objectness gradient alone."""
+    from ep24 import loss as L
+    from oracle.loss import LossOracle
+    B = 3
+    labels = synth.make_labels(B, [0, 0, 0], seed=7)
+    outputs = synth.decode_head(synth.make_raw_head(B, seed=8))
+    lf = L.Loss_Function(80)
+    tup, grad = _run_loss(L, lf, outputs, labels)
+    o_out = outputs.clone().requires_grad_(True)
+    o_tup = LossOracle(80)(synth.outputs_train_tuple(o_out), labels)
+    o_tup[0].backward()
+    torch.testing.assert_close(tup[0].detach().cpu(), o_tup[0].detach(), rtol=1e-4, atol=1e-6)
+    assert float(tup[1].abs().sum()) == 0.0 and float(tup[3]) == 0.0 and float(tup[5]) == 0.0
+    g, og = grad.cpu(), o_out.grad
+    assert float(g[..., :26].abs().sum()) == 0.0 and float(g[..., 27:].abs().sum()) == 0.0
+    torch.testing.assert_close(g[..., 26], og[..., 26], rtol=1e-4, atol=1e-9)
+    for b in range(B):
+        assert lf.assignment_of(labels, b)[4] == 0
