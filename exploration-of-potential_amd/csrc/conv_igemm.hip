@@ -38,6 +38,8 @@ struct IgemmArgs {
     // whose pre-activation is bn_z; the epilogue adds sum(du) / sum(du*zhat) per channel to bn_sb / bn_sg
     const bf16* bn_z; long bn_ldz; const float* bn_save; const float* bn_gamma; const float* bn_beta;
     long long* bn_sg; long long* bn_sb; int bn_act;
+    // inference epilogue (BatchNorm folded into weights and bias): y = act(acc + bias) + residual
+    int epi_act; const bf16* epi_res; long epi_ldres; int epi_infer;
     int b_resident_max;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernel
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 }
 
 // Shared epilogue of the DMA kernels: bias, BN statistics, bf16 / fp32 stores, fixed-point statistic atomics.
-template <int BN, bool OUT_F32, int MT, bool BNR = false>
+template <int BN, bool OUT_F32, int MT, int BNR = 0>           // BNR: 0 plain, 1 fused BN-backward pass 1, 2 inference (act + residual)
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
     constexpr int WN = BN / 64, WM = 4 / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,7 +320,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr bool bnr = BNR && !OUT_F32;              // compiled in only for the experiment's instantiation
+    constexpr bool bnr = BNR == 1 && !OUT_F32;         // compiled in only for the experiment's instantiation
+    constexpr bool infer = BNR == 2 && !OUT_F32;       // compiled in only for the eval-mode instantiation
     float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
     if (bnr) {
 #pragma unroll
@@ -357,6 +360,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
                     if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
             } else {
                 bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
+                if (infer) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < p.N) {
+                            float y = act_fwd(v[q], p.epi_act);
+                            if (p.epi_res) y += (float)p.epi_res[dpix * p.epi_ldres + c0 + q];
+                            v[q] = y;
+                        }
+                }
                 if (c0 + 3 < p.N) {
                     if (p.accumulate) {
                         bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
@@ -433,7 +445,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, bool OUT_F32, bool BNR = false>
+template <int BN, bool OUT_F32, int BNR = 0>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
 // A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
 // block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
 // registers until the end.  Waves of a workgroup share the rows (WN waves, 64 columns each) through L1.
-template <int BN, int H, bool BNR = false>
+template <int BN, int H, int BNR = 0>                          // BNR: 0 plain, 1 fused BN-backward pass 1, 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = 2, RG = WM * MT * 16;   // 32-row blocks per wave: ~170 VGPRs, 3 waves per SIMD
     constexpr int OOB = 0x7FFFFFF0;
@@ -782,7 +794,14 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     f32x4 acc[MT][4];
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int c0 = n0 + wn * 64 + 4 * frow;
-    constexpr bool bnr = BNR;                               // fused pass 1 of the next BN backward (see igemm_epilogue)
+    constexpr bool bnr = BNR == 1;                          // fused pass 1 of the next BN backward (see igemm_epilogue)
+    constexpr bool infer = BNR == 2;                        // eval mode: y = act(acc + bias) + residual
+    float ibias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (infer) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < p.N) ibias[q] = p.bias[c0 + q];
+    }
     float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
     if (bnr) {
 #pragma unroll
@@ -829,7 +848,10 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[q] = acc[i][q][r];
-                    if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
+                    if (infer) {
+                        v[q] = act_fwd(v[q] + ibias[q], p.epi_act);
+                        if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
+                    } else if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
                 }
                 bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
                 if (c0 + 3 < p.N) {
@@ -920,14 +942,16 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     const int npan = (a.K + 63) / 64;
     size_t lds = (size_t)npan * BN * 128;
     if (lds < 2048) lds = 2048;
-    if (a.bn_z) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, true>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
-    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, false>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    else if (a.bn_z) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 1>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
 }
 
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
     if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
-    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, true>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
+    else if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
+    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 1>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
     else if (!getenv("EP24_IGEMM_RING")) hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
     else {
         // experimental: BK=32 ring with counted vmcnt (EP24_IGEMM_RING=2|3|4 stages); measured within +-10 % of the
@@ -945,7 +969,7 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
-        !a.bias && plain_dst && a.ld_dst % 4 == 0 && !getenv("EP24_NO_STREAM")) {
+        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && !getenv("EP24_NO_STREAM")) {
         if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
         else          { if (a.K > 128) launch_stream<64, 2>(a, stream); else launch_stream<64, 1>(a, stream); }
         EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
@@ -1010,6 +1034,31 @@ extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, vo
     a.accumulate = 0; a.bias = bias; a.stats = (long long*)stats; a.stats_replicas = stats ? stats_replicas : 1;
     a.M = (long)B * OH * OW;
     return launch(a, y_f32 != 0, (hipStream_t)stream);
+}
+
+// Eval-mode unit in one launch: BatchNorm's running statistics are folded into the packed weights and a bias
+// (ep24_fold_bn), so conv -> BN -> act (+ residual) is the conv with y = act(acc + bias) + residual in its epilogue.
+extern "C" int ep24_conv_fwd_infer_bf16(const void* x, int64_t ld_x, const void* w, const float* bias, int act, const void* res,
+                                        int64_t ld_res, void* y, int64_t ld_y, int B, int H, int W, int Cin, int Cout, int ksize,
+                                        int stride, void* stream) {
+    EP24_REQUIRE(x && w && y && bias, EP24_E_ARG, "conv_fwd_infer: null pointer");
+    EP24_REQUIRE(Cin % 8 == 0 && Cin > 0, EP24_E_ARG, "conv_fwd_infer: Cin=%d must be a multiple of 8", Cin);
+    EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED, "conv_fwd_infer: k=%d s=%d unsupported", ksize, stride);
+    EP24_REQUIRE(ld_x % 8 == 0 && ld_y % 4 == 0 && (!res || ld_res % 4 == 0), EP24_E_ARG, "conv_fwd_infer: row stride alignment");
+    const int pad = (ksize - 1) / 2;
+    const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+    IgemmArgs a{};
+    a.src = (const bf16*)x; a.ld_src = ld_x; a.B = B; a.SH = H; a.SW = W;
+    a.GH = OH; a.GW = OW; a.sy = stride; a.sx = stride;
+    a.T = ksize * ksize;
+    for (int t = 0; t < a.T; ++t) { a.oy[t] = t / ksize - pad; a.ox[t] = t % ksize - pad; a.wslot[t] = t; }
+    a.wt = (const bf16*)w; a.WT = a.T; a.K = Cin; a.N = Cout;
+    a.dst = y; a.ld_dst = ld_y; a.DH = OH; a.DW = OW; a.dsy = a.dsx = 1; a.dy0 = a.dx0 = 0;
+    a.dbs = (long)OH * OW; a.dp0 = 0;
+    a.accumulate = 0; a.bias = bias; a.stats = nullptr; a.stats_replicas = 1;
+    a.epi_infer = 1; a.epi_act = act; a.epi_res = (const bf16*)res; a.epi_ldres = ld_res;
+    a.M = (long)B * OH * OW;
+    return launch(a, false, (hipStream_t)stream);
 }
 
 namespace {

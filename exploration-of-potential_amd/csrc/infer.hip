@@ -36,6 +36,57 @@ __global__ __launch_bounds__(256) void bn_act_infer_kernel(const bf16* z, long l
     }
 }
 
+// BatchNorm folding for every conv unit of the network in two launches: w' = w * gamma / sqrt(running_var + eps) per output
+// channel (packed bf16 [Cout][T][Cin_pad], the layout of the forward weights), bias = beta - running_mean * scale.
+// desc[s][12] = {master offset, packed offset, Cout, T, Cin, Cin_pad, gamma offset, beta offset (flat), running-mean offset,
+// running-var offset (statistics buffer), bias offset, 0}; prefix[s] = first element of segment s; eps[s].
+__global__ __launch_bounds__(256) void fold_bn_weights_kernel(const float* flat, const float* bstat, const long* desc, const long* prefix,
+                                                              const float* eps, int n_seg, bf16* wf) {
+    __shared__ int s_first;
+    const long total = prefix[n_seg];
+    for (long base = (long)blockIdx.x * 1024; base < total; base += (long)gridDim.x * 1024) {
+        if (threadIdx.x == 0) {
+            int lo = 0, hi = n_seg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (prefix[mid] <= base) lo = mid; else hi = mid - 1;
+            }
+            s_first = lo;
+        }
+        __syncthreads();
+        int seg = s_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long i = base + threadIdx.x + 256 * k;
+            if (i >= total) break;
+            while (i >= prefix[seg + 1]) ++seg;
+            const long* d = desc + (long)seg * 12;
+            const long e = i - prefix[seg];
+            const int T = (int)d[3], Cin = (int)d[4], Cin_pad = (int)d[5];
+            const int co = (int)(e / ((long)T * Cin));
+            const float scale = flat[d[6] + co] / sqrtf(bstat[d[9] + co] + eps[seg]);
+            wf[d[1] + (e / Cin) * Cin_pad + e % Cin] = (bf16)(flat[d[0] + e] * scale);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_bn_bias_kernel(const float* flat, const float* bstat, const long* desc, const long* cprefix,
+                                                           const float* eps, int n_seg, float* bias) {
+    const long total = cprefix[n_seg];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int lo = 0, hi = n_seg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cprefix[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long* d = desc + (long)lo * 12;
+        const int co = (int)(i - cprefix[lo]);
+        const float scale = flat[d[6] + co] / sqrtf(bstat[d[9] + co] + eps[lo]);
+        bias[d[10] + co] = flat[d[7] + co] - bstat[d[8] + co] * scale;
+    }
+}
+
 // eval head: xy = (t + grid) * s, r = exp(t) * s, obj / cls = sigmoid(logit)
 __global__ __launch_bounds__(256) void decode_eval_kernel(float* out, int B, int A, int a0, int H, int W, float s, int ncols) {
     const long total = (long)B * H * W * ncols;
@@ -176,6 +227,19 @@ extern "C" int ep24_bn_act_infer(const void* z, int64_t ld_z, const float* gamma
                        (const bf16*)z, ld_z, gamma, beta, running_mean, running_var, (bf16*)y, ld_y, (const bf16*)residual, ld_res, (long)M,
                        C, eps, act);
     EP24_LAUNCH_CHECK("ep24_bn_act_infer");
+    return EP24_OK;
+}
+
+extern "C" int ep24_fold_bn(const float* flat, const float* bstat, const int64_t* desc, const int64_t* prefix, const int64_t* cprefix,
+                            const float* eps, int n_seg, int64_t total, int64_t total_channels, void* w_folded, float* bias, void* stream) {
+    EP24_REQUIRE(flat && bstat && desc && prefix && cprefix && eps && w_folded && bias && n_seg > 0 && total > 0, EP24_E_ARG,
+                 "fold_bn: bad arguments");
+    long blocks = (total + 1023) / 1024;
+    hipLaunchKernelGGL(fold_bn_weights_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, flat, bstat,
+                       (const long*)desc, (const long*)prefix, eps, n_seg, (bf16*)w_folded);
+    hipLaunchKernelGGL(fold_bn_bias_kernel, dim3((unsigned)((total_channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, bstat,
+                       (const long*)desc, (const long*)cprefix, eps, n_seg, bias);
+    EP24_LAUNCH_CHECK("ep24_fold_bn");
     return EP24_OK;
 }
 

@@ -423,6 +423,9 @@ class Engine:
         self._events = []
         self._bwd_builders = []
         self.pre_bn_inputs = {}                  # BatchNorm module -> the Act its pre-activation form reads (tests)
+        # eval mode: BatchNorm folded into the conv (ep24_fold_bn + ep24_conv_fwd_infer_bf16): one launch per unit instead of two
+        self.fold_bn_eval = not os.environ.get("EP24_NO_FOLD")
+        self._fold_units, self._fold_w, self._fold_c = [], 0, 0
         self.dyn = {"origin": None, "d_origin": None}   # run-time pointers (incoming gradient, L1-branch buffers)
         self.origin = None                       # [B,A,26] raw regression outputs, filled while use_l1 is on
         self._stats_specs, self._sum_specs = [], []
@@ -551,6 +554,20 @@ class Engine:
         if self.fuse_bn_reduce:
             self._fuse_reduce_into_dgrad()
         self.slab = torch.zeros(max(self._slab_floats, 4), dtype=torch.float32, device=self.dev)
+        self.fold_w = torch.zeros(max(self._fold_w, 8), dtype=BF16, device=self.dev)
+        self.fold_b = torch.zeros(max(self._fold_c, 4), dtype=torch.float32, device=self.dev)
+        if self._fold_units:
+            b0 = self.home.bflat.data_ptr()
+            rows, pref, cpref, eps = [], [0], [0], []
+            for seg, gam, bet, bn, woff, coff in self._fold_units:
+                rows.append([seg.off, woff, seg.cout, seg.taps, seg.cin, seg.cin_pad, gam.off, bet.off,
+                             (bn.running_mean.data_ptr() - b0) // 4, (bn.running_var.data_ptr() - b0) // 4, coff, 0])
+                pref.append(pref[-1] + seg.numel)
+                cpref.append(cpref[-1] + seg.cout)
+                eps.append(float(bn.eps))
+            t64 = dict(dtype=torch.int64, device=self.dev)
+            self._fold_desc = (torch.tensor(rows, **t64), torch.tensor(pref, **t64), torch.tensor(cpref, **t64),
+                               torch.tensor(eps, dtype=torch.float32, device=self.dev), len(rows), pref[-1], cpref[-1])
         # every layer keeps its own dz (the gradient w.r.t. the raw conv output): the weight-gradient lane may lag the
         # main lane by a whole segment without a write-after-read hazard (3.4 GB at -l / B=20; there are 288)
         self.dzbuf = torch.zeros(max(self._dz_elems, 8), dtype=BF16, device=self.dev)
@@ -645,15 +662,25 @@ class Engine:
         sum_g, sum_b, bar_cnt = self._sums_slot(cout)
         flat, gflat = home.flat, home.gflat
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
-        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s,
-                ev=("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s)))
         res_p = residual.ptr() if residual is not None else None
         res_ld = residual.ld if residual is not None else 0
+        if self.fold_bn_eval:
+            woff, coff = self._fold_w, self._fold_c
+            self._fold_w += cout * seg.taps * seg.cin_pad
+            self._fold_c += cout
+            self._fold_units.append((seg, gam, bet, bn, woff, coff))
+            ev_conv = ("conv_fwd_infer_bf16", (x.ptr(), x.ld, (lambda woff=woff: self.fold_w.data_ptr() + 2 * woff),
+                                               (lambda coff=coff: self.fold_b.data_ptr() + 4 * coff), act, res_p, res_ld, out.ptr(), out.ld,
+                                               B, H, W, cin, cout, k, s))
+        else:
+            ev_conv = ("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s))
+        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s, ev=ev_conv)
         self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
                 ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld,
                 res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), act,
-                ev=("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
-                                     ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), act)))
+                ev=False if self.fold_bn_eval else
+                ("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
+                                  ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), act)))
         if residual is not None:
             residual.alias_grad(out)
         self.unit_acts[mod if mod is not None else conv] = (x, z, out)
@@ -1125,8 +1152,16 @@ class Engine:
         if images is not None:
             self.images.copy_(images)
         self.home.pack()
+        self.fold()
         self._run(self.fwd_eval)
         return self.outputs
+
+    def fold(self):
+        """Fold every unit's BatchNorm (running statistics) into its packed weights and a bias: two launches for the network."""
+        if self._fold_units:
+            d, pf, cp, eps, n, tot, totc = self._fold_desc
+            call("fold_bn", ptr(self.home.flat), ptr(self.home.bflat), ptr(d), ptr(pf), ptr(cp), ptr(eps), n, tot, totc,
+                 ptr(self.fold_w), ptr(self.fold_b), stream_ptr())
 
     def backward(self, dout, d_origin=None):
         """Accumulates parameter gradients into the flat gradient buffer; dout [B,A,27+C] fp32 contiguous, d_origin

@@ -291,6 +291,18 @@ int ep24_bn_act_infer(const void* z, int64_t ld_z, const float* gamma, const flo
                       int64_t M, int C, float eps, int act, void* stream);
 /* eval head (yolo_head_24p.py:190-191, 239-256): decode xy / radii in place and apply sigmoid to obj and class logits. */
 int ep24_head_decode_eval(float* out, int B, int A, int a0, int H, int W, float stride, int ncols, void* stream);
+/* BatchNorm folding for inference, all conv units in two launches: w' = w * gamma / sqrt(running_var + eps) (packed bf16
+ * [Cout][T][Cin_pad]) and bias = beta - running_mean * scale.  flat = the fp32 parameter buffer, bstat = the running
+ * statistics buffer; desc[n_seg][12] int64 = {master offset, packed offset, Cout, T, Cin, Cin_pad, gamma offset, beta offset
+ * (flat), running-mean offset, running-var offset (bstat), bias offset, 0}; prefix / cprefix [n_seg+1] = element / channel
+ * prefix sums; eps[n_seg]. */
+int ep24_fold_bn(const float* flat, const float* bstat, const int64_t* desc, const int64_t* prefix, const int64_t* cprefix,
+                 const float* eps, int n_seg, int64_t total, int64_t total_channels, void* w_folded, float* bias, void* stream);
+/* conv -> BN(running statistics) -> act (+ residual) of the eval-mode network as ONE launch: the conv over the folded weights
+ * with y = act(acc + bias) + residual in its epilogue (act: 0 none, 1 SiLU, 2 ReLU; res nullable). */
+int ep24_conv_fwd_infer_bf16(const void* x, int64_t ld_x, const void* w, const float* bias, int act, const void* res,
+                             int64_t ld_res, void* y, int64_t ld_y, int B, int H, int W, int Cin, int Cout, int ksize,
+                             int stride, void* stream);
 /* postprocess (utils/boxes.py:29-99) in three launches.  prepare: per row best class (first maximum), class_conf,
  * score = obj*class_conf or -1 when below conf_thre, bounding rectangle of the 24 points (with the reference's
  * theta*cos(theta) factors, passed in as the host computes them).  nms: per image (one workgroup) candidates sorted by score (ties: lower row first), greedy
