@@ -597,7 +597,6 @@ __global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
     const int lchunk = (0x1320 >> (4 * (pslot ^ rh))) & 3;   // PINV = {0,2,3,1}
     const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
-    constexpr int OOB = 0x7FFFFFF0;
     int rowoff[A_INSTR];
     unsigned vmask[A_INSTR];
 #pragma unroll
