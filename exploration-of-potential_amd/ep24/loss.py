@@ -41,14 +41,23 @@ class LossWorkspace:
         return self.d_origin
 
 
-def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin=None):
+def assign_candidates(ws, labels, xs, ys, strides):
+    """a4+a5: the geometric candidate masks depend on the labels and the anchor grid only, so a captured step runs them
+    next to the forward pass (ep24.train) instead of behind it."""
+    in_box, in_ctr = ws.masks[0], ws.masks[1]
+    call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ws.B, ws.A,
+         stream_ptr())
+
+
+def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin=None, candidates_done=False):
     """Kernels a4..a10 forward: fills ws.matched_* and ws.result; updates `state` (device [26]).  ``origin`` [B,A,26]
     (the head's raw regression outputs) switches the L1 branch on (losses.py:197-198, 304-309)."""
     B, A, C = ws.B, ws.A, ws.C
     ncols = NCOLS_BASE + C
     s = stream_ptr()
     in_box, in_ctr, match = ws.masks[0], ws.masks[1], ws.masks[2]
-    call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), B, A, s)
+    if not candidates_done:
+        call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), B, A, s)
     call("assign_cost", ptr(outputs), ncols, ptr(labels), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ptr(ws.pw),
          ptr(ws.cost), B, A, C, s)
     call("memset_zero", ptr(match), match.numel() * 8, s)

@@ -149,10 +149,15 @@ class TrainStep:
         self.home.pack()
         eng.run_lane(self._fwd_split()[0])
 
+    def _phase_side_forward(self, lst):
+        """The second forward lane: the label-only part of SimOTA (candidate masks), then the level-0 head chain."""
+        eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
+        self.eng.run_lane(lst)
+
     def _phase_loss(self):
         eng = self.eng
         origin = eng.origin if self.use_l1 else None
-        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin)
+        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin, candidates_done=True)
         eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
         eng.dyn["dout"] = self.ws.dout.data_ptr()
         eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
@@ -226,8 +231,9 @@ class TrainStep:
         if split is None:
             self.g_fwd = capture(self._phase_forward)
         else:
-            self.g_fwd = (capture(self._phase_forward_head),) + tuple(capture(lambda l=l: eng.run_lane(l)) for l in split[1:]) + \
-                         (capture(self._phase_loss),)
+            lanes = [capture((lambda l=l: self._phase_side_forward(l)) if i == 1 else (lambda l=l: eng.run_lane(l)))
+                     for i, l in enumerate(split[1:])]                            # index 1 = the level-0 head lane
+            self.g_fwd = (capture(self._phase_forward_head),) + tuple(lanes) + (capture(self._phase_loss),)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
             if len(split) == 5 and getattr(self, "_side2", None) is None:
