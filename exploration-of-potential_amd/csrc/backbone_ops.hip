@@ -259,9 +259,18 @@ __global__ __launch_bounds__(256) void chanscale_kernel(bf16* x, long ld, const 
     }
 }
 
+__global__ void incr_i64_kernel(long long* p) { *p += 1; }
+
 }  // namespace
 
 #define S_ (hipStream_t) stream
+
+extern "C" int ep24_incr_i64(int64_t* p, void* stream) {
+    EP24_REQUIRE(p, EP24_E_ARG, "incr_i64: null pointer");
+    hipLaunchKernelGGL(incr_i64_kernel, dim3(1), dim3(1), 0, S_, (long long*)p);
+    EP24_LAUNCH_CHECK("ep24_incr_i64");
+    return EP24_OK;
+}
 
 extern "C" int ep24_colstats(const void* x, int64_t ld, int64_t* stats, int64_t ld_stats, int64_t M, int C, void* stream) {
     EP24_REQUIRE(x && stats && C % 8 == 0 && C <= 2048 && ld % 8 == 0 && M > 0 && ld_stats >= C, EP24_E_ARG, "colstats: bad arguments");

@@ -123,6 +123,14 @@ class Act:
             return 1
         assert not any(not (hi <= a or b <= lo) for a, b in w), "partially written gradient region"
         w.append((lo, hi))
+        w.sort()
+        merged = [w[0]]
+        for a, b in w[1:]:                            # adjacent producers make one region (a merged CSP unit reads [x_2 | x_1])
+            if a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        w[:] = merged
         return 0
 
     def gready(self):
@@ -149,6 +157,9 @@ class VecSeg:
         self.off = None
 
 
+MERGE_CSP = not os.environ.get("EP24_NO_CSP_MERGE")
+
+
 class ParamHome:
     """Flat fp32 parameter / gradient / momentum buffers + packed bf16 weight copies for one model."""
 
@@ -158,6 +169,7 @@ class ParamHome:
             raise _lib.Ep24Error("ep24: move the model to the GPU before running it (model.to('cuda'))")
         self.dev = dev
         self.convs, self.vecs, self.order, self.by_param = [], [], [], {}
+        self.merged_bn = []                               # (bn of conv2, bn of conv1) of the merged CSP units
         stems = {m.conv for m in model.modules() if isinstance(m, enn.Focus)}
         for mod in exec_order(model):
             if isinstance(mod, tuple) and mod[0] == "unit":          # (conv, bn) pair of a swapped backbone
@@ -172,6 +184,13 @@ class ParamHome:
                 self._add(VecSeg([bn_.bias]))
             elif isinstance(mod, tuple) and mod[0] == "unused":      # in the state dict, not in the graph: gradient stays 0
                 self._add(VecSeg([mod[1]]))
+            elif isinstance(mod, tuple) and mod[0] == "csp_merged":
+                c2, c1 = mod[1].conv2, mod[1].conv1
+                w2, w1 = c2.conv.weight, c1.conv.weight
+                self._add(ConvSeg([w2, w1], w2.shape[0] + w1.shape[0], 1, w2.shape[1]))
+                self._add(VecSeg([c2.bn.weight, c1.bn.weight]))
+                self._add(VecSeg([c2.bn.bias, c1.bn.bias]))
+                self.merged_bn.append((c2.bn, c1.bn))
             elif isinstance(mod, tuple) and mod[0] == "conv":        # a conv on its own (DenseNet: BN sits in front of it)
                 w = mod[1].weight
                 k = w.shape[2]
@@ -217,19 +236,23 @@ class ParamHome:
         self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
         # BatchNorm running statistics in one flat buffer too (module buffers become views): ModelEMA averages every
         # floating-point state_dict entry (utils/ema.py:55-60), i.e. these next to the parameters, in two launches
-        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-        nb = sum((b.num_features + 3) // 4 * 8 for b in bns)
+        paired = {id(b) for pair in self.merged_bn for b in pair}
+        groups = [[m] for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d) and id(m) not in paired]
+        groups += [list(pair) for pair in self.merged_bn]     # [rm2 | rm1 | rv2 | rv1]: one BN launch covers both
+        nb = sum((b.num_features + 3) // 4 * 8 for g in groups for b in g)
         self.bflat = torch.zeros(max(nb, 4), dtype=torch.float32, device=dev)
         self.bnumel = nb
         o = 0
         with torch.no_grad():
-            for b in bns:
-                c = b.num_features
+            for g in groups:
                 for name in ("running_mean", "running_var"):
-                    v = self.bflat[o:o + c]
-                    v.copy_(getattr(b, name))
-                    setattr(b, name, v)
-                    o += (c + 3) // 4 * 4
+                    for b in g:
+                        c = b.num_features
+                        assert len(g) == 1 or c % 4 == 0
+                        v = self.bflat[o:o + c]
+                        v.copy_(getattr(b, name))
+                        setattr(b, name, v)
+                        o += (c + 3) // 4 * 4
         rows, pref, tpref = [], [0], [0]
         for seg in self.convs:
             rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
@@ -295,11 +318,25 @@ class ParamHome:
             call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
 
 
+def csp_is_merged(m):
+    """CSP layers without shortcut bottlenecks (the neck's four and dark5's) run conv1 and conv2 - two 1x1 convs over the
+    same input - as ONE GEMM with one BatchNorm launch: their weights, BN parameters and running statistics sit next to each
+    other in the flat buffers (order conv2, conv1: the layout of the concatenation the block builds)."""
+    return MERGE_CSP and len(m.m) > 0 and not any(b.use_add for b in m.m)
+
+
 def exec_order(model):
     """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
     any other container (tests build single blocks) falls back to registration order."""
     if not isinstance(model, enn.YOLOX):
+        skip = set()
         for m in model.modules():
+            if m in skip:
+                continue
+            if isinstance(m, enn.CSPLayer) and csp_is_merged(m):
+                yield ("csp_merged", m)
+                skip |= {m.conv1, m.conv2}
+                continue
             if isinstance(m, enn.ConvBlock):              # tests build stand-alone stages of the swapped backbones
                 yield ("bn", m.bn)
                 yield ("conv", m.conv, False)
@@ -315,8 +352,11 @@ def exec_order(model):
         return
 
     def csp(m):
-        yield m.conv1
-        yield m.conv2
+        if csp_is_merged(m):
+            yield ("csp_merged", m)
+        else:
+            yield m.conv1
+            yield m.conv2
         for blk in m.m:
             yield blk.conv1
             yield blk.conv2
@@ -737,6 +777,8 @@ class Engine:
 
     def csp(self, mod, x, out=None):
         """CSPLayer: cat(m(conv1(x)), conv2(x)) -> conv3 (network_blocks.py:179-185)."""
+        if csp_is_merged(mod):
+            return self.csp_merged(mod, x, out)
         h = self.home.by_param[mod.conv1.conv.weight].cout
         cat = self.new_act(2 * h, x.H, x.W)
         n = len(mod.m)
@@ -952,6 +994,24 @@ class Engine:
         """New Dropout2d keep factors for the next training forward (torch's generator on the device: no host sync)."""
         if getattr(self, "drop_keep", None) is not None and not getattr(self, "fixed_dropout", False):
             self.drop_keep.bernoulli_(1.0 - self.drop_p).div_(1.0 - self.drop_p)
+
+    def csp_merged(self, mod, x, out=None):
+        """CSP layer without shortcuts with conv1 and conv2 as one GEMM: P = [m(x_1) | x_2 | x_1]; the merged unit writes
+        [x_2 | x_1] (columns h..3h), the bottleneck chain reads x_1 and ends in columns 0..h, conv3 reads columns 0..2h."""
+        h = mod.conv1.conv.out_channels
+        P = self.new_act(3 * h, x.H, x.W)
+        both = P.slice(h, 2 * h)
+        self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn)
+        xa, za, ya = self.unit_acts.pop(mod.conv2.conv)
+        self.unit_acts[mod.conv2] = (xa, za.slice(0, h), ya.slice(0, h))      # per-module views (tests walk unit_acts)
+        self.unit_acts[mod.conv1] = (xa, za.slice(h, h), ya.slice(h, h))
+        self._f("incr_i64", ptr(mod.conv1.bn.num_batches_tracked), ev=False)  # the BN launch counted for conv2's module
+        t = P.slice(2 * h, h)
+        n = len(mod.m)
+        for i, blk in enumerate(mod.m):
+            u = self.unit(blk.conv1, t)
+            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None)
+        return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 
     def spp(self, mod, x):
         """SPPBottleneck: conv1 -> cat(x, pool5, pool9, pool13) -> conv2 (network_blocks.py:139-144)."""

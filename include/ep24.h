@@ -383,6 +383,9 @@ int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int6
 int ep24_avgpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream);
 int ep24_avgpool2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C,
                       void* stream);
+/* *p += 1 on the stream: num_batches_tracked of a BatchNorm module whose launch is shared with a neighbour (the merged
+ * conv1 / conv2 unit of a CSP layer). */
+int ep24_incr_i64(int64_t* p, void* stream);
 /* nn.Dropout2d as data: x[n, :, :, c] *= keep[n*C + c] in place (keep = 0 or 1/(1-p), drawn by the host once per step);
  * the same call is its backward. */
 int ep24_chanscale(void* x, int64_t ld, const float* keep, int B, int64_t HW, int C, void* stream);

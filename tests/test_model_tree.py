@@ -33,6 +33,9 @@ def test_exec_order_covers_every_parameter():
     for mod in exec_order(m):
         if isinstance(mod, enn.BaseConv):
             seen |= {mod.conv.weight, mod.bn.weight, mod.bn.bias}
+        elif isinstance(mod, tuple) and mod[0] == "csp_merged":       # conv1 and conv2 of a shortcut-free CSP layer as one unit
+            for c in (mod[1].conv1, mod[1].conv2):
+                seen |= {c.conv.weight, c.bn.weight, c.bn.bias}
         elif isinstance(mod, enn.YOLOXHead):
             for k in range(3):
                 for c in (mod.reg_preds[k], mod.obj_preds[k], mod.cls_preds[k]):
