@@ -158,6 +158,7 @@ class VecSeg:
 
 
 MERGE_CSP = not os.environ.get("EP24_NO_CSP_MERGE")
+MERGE_CSP_SHORTCUT = not os.environ.get("EP24_NO_CSP_MERGE_SHORTCUT")     # the backbone's CSP layers too (one gradient copy each)
 
 
 class ParamHome:
@@ -322,7 +323,7 @@ def csp_is_merged(m):
     """CSP layers without shortcut bottlenecks (the neck's four and dark5's) run conv1 and conv2 - two 1x1 convs over the
     same input - as ONE GEMM with one BatchNorm launch: their weights, BN parameters and running statistics sit next to each
     other in the flat buffers (order conv2, conv1: the layout of the concatenation the block builds)."""
-    return MERGE_CSP and len(m.m) > 0 and not any(b.use_add for b in m.m)
+    return MERGE_CSP and len(m.m) > 0 and (MERGE_CSP_SHORTCUT or not any(b.use_add for b in m.m))
 
 
 def exec_order(model):
@@ -1006,11 +1007,22 @@ class Engine:
         self.unit_acts[mod.conv2] = (xa, za.slice(0, h), ya.slice(0, h))      # per-module views (tests walk unit_acts)
         self.unit_acts[mod.conv1] = (xa, za.slice(h, h), ya.slice(h, h))
         self._f("incr_i64", ptr(mod.conv1.bn.num_batches_tracked), ev=False)  # the BN launch counted for conv2's module
-        t = P.slice(2 * h, h)
+        t = x1 = P.slice(2 * h, h)
         n = len(mod.m)
+        if any(blk.use_add for blk in mod.m):
+            # with shortcuts d(x_1) shares storage with the bottleneck chain's gradient (residual aliasing), which is not where
+            # the merged unit reads it: one copy into columns 2h..3h of the gradient, after the chain's backward
+            raw = P.slice(2 * h, h)
+
+            def build_copy():
+                assert x1._alias is not None and x1._groot().buf.gwritten
+                acc = raw.gwrite()
+                self._b("rows_copy", (x1.gptr(), x1.gld, raw.gptr(), raw.gld, acc, x1.M, h))
+
+            self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
             u = self.unit(blk.conv1, t)
-            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None)
+            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None)
         return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 
     def spp(self, mod, x):
