@@ -158,7 +158,8 @@ class VecSeg:
 
 
 MERGE_CSP = not os.environ.get("EP24_NO_CSP_MERGE")
-MERGE_CSP_SHORTCUT = not os.environ.get("EP24_NO_CSP_MERGE_SHORTCUT")     # the backbone's CSP layers too (one gradient copy each)
+MERGE_CSP_SHORTCUT = not os.environ.get("EP24_NO_CSP_MERGE_SHORTCUT")
+MERGE_HEAD = not os.environ.get("EP24_NO_HEAD_MERGE")     # the backbone's CSP layers too (one gradient copy each)
 
 
 class ParamHome:
@@ -185,10 +186,11 @@ class ParamHome:
                 self._add(VecSeg([bn_.bias]))
             elif isinstance(mod, tuple) and mod[0] == "unused":      # in the state dict, not in the graph: gradient stays 0
                 self._add(VecSeg([mod[1]]))
-            elif isinstance(mod, tuple) and mod[0] == "csp_merged":
-                c2, c1 = mod[1].conv2, mod[1].conv1
+            elif isinstance(mod, tuple) and mod[0] in ("csp_merged", "pair_merged"):
+                # two BaseConv units over the same input as one GEMM + one BN launch; (first, second) = channel order of the output
+                c2, c1 = (mod[1].conv2, mod[1].conv1) if mod[0] == "csp_merged" else (mod[1], mod[2])
                 w2, w1 = c2.conv.weight, c1.conv.weight
-                self._add(ConvSeg([w2, w1], w2.shape[0] + w1.shape[0], 1, w2.shape[1]))
+                self._add(ConvSeg([w2, w1], w2.shape[0] + w1.shape[0], w2.shape[2] * w2.shape[3], w2.shape[1]))
                 self._add(VecSeg([c2.bn.weight, c1.bn.weight]))
                 self._add(VecSeg([c2.bn.bias, c1.bn.bias]))
                 self.merged_bn.append((c2.bn, c1.bn))
@@ -411,8 +413,13 @@ def exec_order(model):
     yield from csp(neck.C3_n4)
     for k in range(len(head.stems)):
         yield head.stems[k]
-        yield from head.cls_convs[k]
-        yield from head.reg_convs[k]
+        if MERGE_HEAD:                                # the first 3x3 conv of the class and of the regression branch read the same tensor
+            yield ("pair_merged", head.cls_convs[k][0], head.reg_convs[k][0])
+            yield head.cls_convs[k][1]
+            yield head.reg_convs[k][1]
+        else:
+            yield from head.cls_convs[k]
+            yield from head.reg_convs[k]
     yield head
     if isinstance(bb, enn.ResNet):                     # fc / baseconv1..3: parameters the reference never runs (darknet.py:311-330)
         used = {id(p) for conv, bn in bb.used_units() for p in (conv.weight, bn.weight, bn.bias)}
@@ -1062,8 +1069,19 @@ class Engine:
         self.levels.append((H, W, s))
         self._cur_tag = ("head", k)
         x = self.unit(head.stems[k], feat)
-        cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x))
-        rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x))
+        if MERGE_HEAD:
+            c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
+            hc = c0.conv.out_channels
+            both = self.unit(None, x, conv=c0.conv, bn=c0.bn)          # [class branch | regression branch], one GEMM (N = 2h)
+            xa, za, ya = self.unit_acts.pop(c0.conv)
+            self.unit_acts[c0] = (xa, za.slice(0, hc), ya.slice(0, hc))
+            self.unit_acts[r0] = (xa, za.slice(hc, hc), ya.slice(hc, hc))
+            self._f("incr_i64", ptr(r0.bn.num_batches_tracked), ev=False)
+            cf = self.unit(head.cls_convs[k][1], both.slice(0, hc))
+            rf = self.unit(head.reg_convs[k][1], both.slice(hc, hc))
+        else:
+            cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x))
+            rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x))
         ro_seg = home.by_param[head.reg_preds[k].weight]
         ro_b = home.by_param[head.reg_preds[k].bias]
         cl_seg = home.by_param[head.cls_preds[k].weight]

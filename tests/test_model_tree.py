@@ -33,8 +33,8 @@ def test_exec_order_covers_every_parameter():
     for mod in exec_order(m):
         if isinstance(mod, enn.BaseConv):
             seen |= {mod.conv.weight, mod.bn.weight, mod.bn.bias}
-        elif isinstance(mod, tuple) and mod[0] == "csp_merged":       # conv1 and conv2 of a shortcut-free CSP layer as one unit
-            for c in (mod[1].conv1, mod[1].conv2):
+        elif isinstance(mod, tuple) and mod[0] in ("csp_merged", "pair_merged"):   # two units over one input run as one
+            for c in ((mod[1].conv1, mod[1].conv2) if mod[0] == "csp_merged" else mod[1:]):
                 seen |= {c.conv.weight, c.bn.weight, c.bn.bias}
         elif isinstance(mod, enn.YOLOXHead):
             for k in range(3):
