@@ -321,6 +321,13 @@ class ParamHome:
             call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
 
 
+def _same_bn(a, b):
+    """Two BatchNorm modules that share one launch must agree on everything but their parameters and statistics."""
+    if (a.eps, a.momentum, a.num_features) != (b.eps, b.momentum, b.num_features):
+        raise _lib.Ep24Error("ep24: merged units need identical BatchNorm eps / momentum / width (%s vs %s); set EP24_NO_CSP_MERGE=1 "
+                             "EP24_NO_HEAD_MERGE=1 to run them separately" % ((a.eps, a.momentum), (b.eps, b.momentum)))
+
+
 def csp_is_merged(m):
     """CSP layers without shortcut bottlenecks (the neck's four and dark5's) run conv1 and conv2 - two 1x1 convs over the
     same input - as ONE GEMM with one BatchNorm launch: their weights, BN parameters and running statistics sit next to each
@@ -1007,6 +1014,7 @@ class Engine:
         """CSP layer without shortcuts with conv1 and conv2 as one GEMM: P = [m(x_1) | x_2 | x_1]; the merged unit writes
         [x_2 | x_1] (columns h..3h), the bottleneck chain reads x_1 and ends in columns 0..h, conv3 reads columns 0..2h."""
         h = mod.conv1.conv.out_channels
+        _same_bn(mod.conv2.bn, mod.conv1.bn)
         P = self.new_act(3 * h, x.H, x.W)
         both = P.slice(h, 2 * h)
         self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn)
@@ -1072,6 +1080,7 @@ class Engine:
         if MERGE_HEAD:
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
+            _same_bn(c0.bn, r0.bn)
             both = self.unit(None, x, conv=c0.conv, bn=c0.bn)          # [class branch | regression branch], one GEMM (N = 2h)
             xa, za, ya = self.unit_acts.pop(c0.conv)
             self.unit_acts[c0] = (xa, za.slice(0, hc), ya.slice(0, hc))
