@@ -194,7 +194,7 @@ def main():
                     "branch on, ModelEMA fused into the update, a yoloxwarmcos rate pushed every step)")
     ap.add_argument("--fisheye", action="store_true", help="non-default: BASELINE config 5 - every step first warps its uint8 source images "
                     "(and masks) with the sector warp on the GPU and letterboxes the results into the network input")
-    ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet"], help="non-default: BASELINE config 4 (backbone swap)")
+    ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet", "vgg"], help="non-default: BASELINE config 4 (backbone swap)")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     a = ap.parse_args()
 
@@ -308,14 +308,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "YOLOX-l-24p (%s+PAFPN+24p head) train step, %dx%d, batch %d/GPU, %d GTs/img, "
-                                   "SimOTA + 24-circle GIoU loss, SGD nesterov" % ({"darknet": "CSPDarknet53", "resnet": "resnet50 backbone swap", "densenet": "densenet121 backbone swap"}[a.backbone],
+                                   "SimOTA + 24-circle GIoU loss, SGD nesterov" % ({"darknet": "CSPDarknet53", "resnet": "resnet50 backbone swap", "densenet": "densenet121 backbone swap", "vgg": "vgg19 backbone swap"}[a.backbone],
                                                                                    a.size, a.size, a.batch, a.gts),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
                                      else "forward and backward as two lanes of captured segments, loss, update"),
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
                        **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),
-            "step_mfma_frac": round(ips / world * {"darknet": TRAIN_GFLOP_PER_IMAGE, "resnet": 290.7, "densenet": 388.0}[a.backbone] * (a.size / 640.0) ** 2 / 1e3
+            "step_mfma_frac": round(ips / world * {"darknet": TRAIN_GFLOP_PER_IMAGE, "resnet": 290.7, "densenet": 388.0, "vgg": 1196.0}[a.backbone] * (a.size / 640.0) ** 2 / 1e3
                                     / MFMA_BF16_PEAK_TFLOPS, 4),      # swaps: 3 x 2 x 48.45 / 64.67 GMAC
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,

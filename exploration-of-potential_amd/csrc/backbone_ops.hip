@@ -259,11 +259,89 @@ __global__ __launch_bounds__(256) void chanscale_kernel(bf16* x, long ld, const 
     }
 }
 
+// nn.MaxPool2d(kernel_size=2, stride=2) (VGG, darknet.py:481): non-overlapping windows, idx = winning tap (dy*2 + dx, first
+// maximum in scan order as ATen); the backward is a gather: every input pixel belongs to exactly one window.
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16* x, long ld_x, bf16* y, long ld_y, uint8_t* idx, int B, int H,
+                                                           int W, int C) {
+    const int cgs = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)B * OH * OW * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long op = i / cgs;
+        const int n = (int)(op / ((long)OH * OW));
+        const int rem = (int)(op - (long)n * OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        float best[8];
+        uint8_t code[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(n * H + 2 * oy + (t >> 1)) * W + 2 * ox + (t & 1)) * ld_x + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[j];
+                if (t == 0 || f > best[j] || f != f) { best[j] = f; code[j] = (uint8_t)t; }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)best[j];
+        *reinterpret_cast<bf16x8*>(y + op * ld_y + cg * 8) = o;
+        uint2 c;
+        c.x = code[0] | (code[1] << 8) | (code[2] << 16) | ((unsigned)code[3] << 24);
+        c.y = code[4] | (code[5] << 8) | (code[6] << 16) | ((unsigned)code[7] << 24);
+        *reinterpret_cast<uint2*>(idx + op * C + cg * 8) = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16* dy, long ld_dy, const uint8_t* idx, bf16* dx, long ld_dx,
+                                                           int accumulate, int B, int H, int W, int C) {
+    const int cgs = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)B * H * W * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long pix = i / cgs;
+        const int n = (int)(pix / ((long)H * W));
+        const int rem = (int)(pix - (long)n * H * W);
+        const int py = rem / W, px = rem - py * W;
+        const long op = (long)(n * OH + (py >> 1)) * OW + (px >> 1);
+        const unsigned want = (unsigned)((py & 1) * 2 + (px & 1));
+        const uint2 c = *reinterpret_cast<const uint2*>(idx + op * C + cg * 8);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ld_dy + cg * 8);
+        bf16x8* d = reinterpret_cast<bf16x8*>(dx + pix * ld_dx + cg * 8);
+        bf16x8 o;
+        const bf16x8 old = accumulate ? *d : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool hit = (((j < 4 ? c.x : c.y) >> (8 * (j & 3))) & 0xFFu) == want;
+            o[j] = (bf16)((float)old[j] + (hit ? (float)g[j] : 0.f));
+        }
+        *d = o;
+    }
+}
+
 __global__ void incr_i64_kernel(long long* p) { *p += 1; }
 
 }  // namespace
 
 #define S_ (hipStream_t) stream
+
+extern "C" int ep24_maxpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, uint8_t* idx, int B, int H, int W, int C,
+                                 void* stream) {
+    EP24_REQUIRE(x && y && idx && C % 8 == 0 && ld_x % 8 == 0 && ld_y % 8 == 0 && H % 2 == 0 && W % 2 == 0, EP24_E_ARG, "maxpool2_fwd: bad arguments");
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(cap_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, S_, (const bf16*)x, (long)ld_x,
+                       (bf16*)y, (long)ld_y, idx, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_maxpool2_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_maxpool2_bwd(const void* dy, int64_t ld_dy, const uint8_t* idx, void* dx, int64_t ld_dx, int accumulate, int B,
+                                 int H, int W, int C, void* stream) {
+    EP24_REQUIRE(dy && idx && dx && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && H % 2 == 0 && W % 2 == 0, EP24_E_ARG, "maxpool2_bwd: bad arguments");
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy, (long)ld_dy, idx,
+                       (bf16*)dx, (long)ld_dx, accumulate, B, H, W, C);
+    EP24_LAUNCH_CHECK("ep24_maxpool2_bwd");
+    return EP24_OK;
+}
 
 extern "C" int ep24_incr_i64(int64_t* p, void* stream) {
     EP24_REQUIRE(p, EP24_E_ARG, "incr_i64: null pointer");

@@ -350,7 +350,7 @@ def exec_order(model):
             if isinstance(m, enn.ConvBlock):              # tests build stand-alone stages of the swapped backbones
                 yield ("bn", m.bn)
                 yield ("conv", m.conv, False)
-            elif isinstance(m, enn.BaseConv_DN):
+            elif isinstance(m, (enn.BaseConv_DN, enn.ConvBNReLU)):
                 yield ("unit", m.conv, m.bn, False)
             elif isinstance(m, enn.ResBottleneck):
                 if m.downsample is not None:
@@ -379,6 +379,14 @@ def exec_order(model):
         for conv, bn in bb.used_units():
             yield ("unit", conv, bn, first)
             first = False
+    elif isinstance(bb, enn.VGG):
+        first = True
+        for stage in bb.stages():
+            for m in stage:
+                if isinstance(m, enn.ConvBNReLU):
+                    yield ("unit", m.conv, m.bn, first)
+                    first = False
+        yield ("unit", bb.conv_add.conv, bb.conv_add.bn, False)
     elif isinstance(bb, enn.DenseNet):
         yield ("unit", bb.stem[0].conv, bb.stem[0].bn, True)
 
@@ -512,7 +520,7 @@ class Engine:
         bb, neck, head = m.backbone.backbone, m.backbone, m.head
         F = S // 2
         self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
-        swapped = isinstance(bb, (enn.ResNet, enn.DenseNet))
+        swapped = isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG))
         c3, c4, c5 = (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels,
                                                        bb.dark5[0].conv.out_channels)
         H3, H4, H5 = S // 8, S // 16, S // 32
@@ -522,7 +530,7 @@ class Engine:
         cat_n3 = self.new_act(2 * c3, H4, H4)        # [bu_conv2(pan_out2) | fpn_out1]
         cat_n4 = self.new_act(2 * c4, H5, H5)        # [bu_conv1(pan_out1) | fpn_out0]
         if swapped:                                       # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
-            build = self.resnet if isinstance(bb, enn.ResNet) else self.densenet
+            build = self.resnet if isinstance(bb, enn.ResNet) else self.vgg if isinstance(bb, enn.VGG) else self.densenet
             x2, x1, x0 = build(bb, cat_p3.slice(c3, c3), cat_p4.slice(c4, c4))
         else:
             # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
@@ -833,6 +841,39 @@ class Engine:
 
         self._add_builder(build_bwd)
         return y
+
+    def maxpool2(self, x, out=None):
+        """nn.MaxPool2d(kernel_size=2, stride=2) (darknet.py:481)."""
+        y = self.new_act(x.C, x.H // 2, x.W // 2) if out is None else out
+        assert (y.H, y.W, y.C) == (x.H // 2, x.W // 2, x.C)
+        idx = torch.zeros(y.M * x.C, dtype=torch.uint8, device=self.dev)
+        self._f("maxpool2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, ptr(idx), x.B, x.H, x.W, x.C)
+
+        def build_bwd():
+            assert y.gready()
+            acc = x.gwrite()
+            self._b("maxpool2_bwd", (y.gptr(), y.gld, ptr(idx), x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
+
+        self._add_builder(build_bwd)
+        return y
+
+    def vgg(self, bb, out3, out4):
+        """vgg19() (darknet.py:447-513): the first conv (3 -> 64 at full resolution) as im2col rows (27 -> 32 columns) x GEMM, then
+        plain conv-BN-ReLU units and 2x2 max pools; dark3 / dark4 are the pooled outputs of stages 3 / 4, dark5 = conv_add."""
+        B, S = self.B, self.S
+        rows = self.new_act(32, S, S)
+        rows.needs_grad = False
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 32, B, 3, S, S, 3, 1, 1)
+        x, feats = rows, []
+        for si, stage in enumerate(bb.stages()):
+            for m in stage:
+                if isinstance(m, enn.ConvBNReLU):
+                    x = self.unit(None, x, stem=x is rows, conv=m.conv, bn=m.bn, act=2)
+                else:
+                    x = self.maxpool2(x, out=out3 if si == 2 else out4 if si == 3 else None)
+            feats.append(x)
+        x0 = self.unit(None, feats[4], conv=bb.conv_add.conv, bn=bb.conv_add.bn, act=2)
+        return feats[2], feats[3], x0
 
     def res_block(self, blk, x, out=None):
         """ResNet bottleneck (darknet.py:247-271).  The downsample unit is placed first so that, in backward, its 1x1

@@ -271,8 +271,55 @@ def densenet121():
     return DenseNet(32, (6, 12, 24, 16))
 
 
+class ConvBNReLU(nn.Module):
+    """conv -> BatchNorm -> ReLU of the VGG backbone (darknet.py:432-445)."""
+
+    def __init__(self, in_channels, out_channels, **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, eps=0.001)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+class VGG(nn.Module):
+    """``vgg19()`` of the reference (darknet.py:447-513): five conv-pool stages of [2, 2, 4, 4, 4] 3x3 conv-BN-ReLU units with
+    64/128/256/512/512 channels at full / 2 / 4 / 8 / 16 resolution before their 2x2 max pool, and a 1x1 conv to 1024 channels;
+    dark3 / dark4 / dark5 = the outputs of stage 3, stage 4 and conv_add."""
+
+    def __init__(self, layer=(2, 2, 4, 4, 4)):
+        super().__init__()
+        self.out_features = ("dark3", "dark4", "dark5")
+        c = 64
+        self.conv_pool1 = self._make_layer(3, c, layer[0])
+        self.conv_pool2 = self._make_layer(c, c * 2, layer[1])
+        self.conv_pool3 = self._make_layer(c * 2, c * 4, layer[2])
+        self.conv_pool4 = self._make_layer(c * 4, c * 8, layer[3])
+        self.conv_pool5 = self._make_layer(c * 8, c * 8, layer[4])
+        self.conv_add = ConvBNReLU(c * 8, c * 16, kernel_size=1, bias=False)
+
+    @staticmethod
+    def _make_layer(cin, cout, n):
+        layers = [ConvBNReLU(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)]
+        layers += [ConvBNReLU(cout, cout, kernel_size=3, stride=1, padding=1, bias=False) for _ in range(1, n)]
+        layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        return nn.Sequential(*layers)
+
+    def stages(self):
+        return (self.conv_pool1, self.conv_pool2, self.conv_pool3, self.conv_pool4, self.conv_pool5)
+
+    def forward(self, x):
+        _no_eager(self)
+
+
+def vgg19():
+    return VGG((2, 2, 4, 4, 4))
+
+
 class YOLOPAFPN(nn.Module):
-    """``backbone_type`` is the switch of yolox/models/yolo_pafpn.py:31-38 ('darknet' | 'resnet' | 'densenet'; the 24p tree's own
+    """``backbone_type`` is the switch of yolox/models/yolo_pafpn.py:31-38 ('darknet' | 'resnet' | 'densenet' | 'vgg'; the 24p tree's own
     YOLOPAFPN hard-codes CSPDarknet, so it is a keyword here and the positional signature stays the 24p one)."""
 
     def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
@@ -288,8 +335,12 @@ class YOLOPAFPN(nn.Module):
             if width != 1.0:
                 raise NotImplementedError("densenet121() emits 256/512/1024 channels: it pairs with width 1.0 (BASELINE config 4)")
             self.backbone = densenet121()
+        elif backbone_type == "vgg":
+            if width != 1.0:
+                raise NotImplementedError("vgg19() emits 256/512/1024 channels: it pairs with width 1.0")
+            self.backbone = vgg19()
         else:
-            raise NotImplementedError("backbone_type %r: 'darknet', 'resnet' and 'densenet' are built ('vgg' is not)" % backbone_type)
+            raise NotImplementedError("backbone_type %r is not one of 'darknet', 'resnet', 'densenet', 'vgg'" % backbone_type)
         self.backbone_type = backbone_type
         self.in_features = in_features
         self.in_channels = in_channels

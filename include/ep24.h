@@ -383,6 +383,11 @@ int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int6
 int ep24_avgpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream);
 int ep24_avgpool2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C,
                       void* stream);
+/* nn.MaxPool2d(kernel_size=2, stride=2) of the VGG backbone (darknet.py:481), NHWC bf16; idx = winning tap per output element. */
+int ep24_maxpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, uint8_t* idx, int B, int H, int W, int C,
+                      void* stream);
+int ep24_maxpool2_bwd(const void* dy, int64_t ld_dy, const uint8_t* idx, void* dx, int64_t ld_dx, int accumulate, int B,
+                      int H, int W, int C, void* stream);
 /* *p += 1 on the stream: num_batches_tracked of a BatchNorm module whose launch is shared with a neighbour (the merged
  * conv1 / conv2 unit of a CSP layer). */
 int ep24_incr_i64(int64_t* p, void* stream);

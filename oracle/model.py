@@ -283,12 +283,43 @@ class DenseNetBackbone(nn.Module):
         return c3, c4, x
 
 
+class VGGBackbone(nn.Module):
+    """vgg19() of darknet.py:447-513 with the reference's state-dict names (conv_pool1..5.{i}.{conv,bn}, conv_add)."""
+
+    def __init__(self, layer=(2, 2, 4, 4, 4)):
+        super().__init__()
+
+        def cbr(cin, cout, k):
+            m = nn.Module()
+            m.conv, m.bn, m.relu = nn.Conv2d(cin, cout, k, 1, k // 2, bias=False), nn.BatchNorm2d(cout, eps=0.001), nn.ReLU()
+            return m
+
+        def stage(cin, cout, n):
+            return nn.Sequential(*([cbr(cin, cout, 3)] + [cbr(cout, cout, 3) for _ in range(1, n)] + [nn.MaxPool2d(2, 2)]))
+        self.conv_pool1, self.conv_pool2 = stage(3, 64, layer[0]), stage(64, 128, layer[1])
+        self.conv_pool3, self.conv_pool4 = stage(128, 256, layer[2]), stage(256, 512, layer[3])
+        self.conv_pool5 = stage(512, 512, layer[4])
+        self.conv_add = cbr(512, 1024, 1)
+
+    def _stage(self, st, x):
+        for m in st:
+            x = F.max_pool2d(x, 2, 2) if isinstance(m, nn.MaxPool2d) else conv_bn_act(x, m.conv, m.bn, "relu", self.training)
+        return x
+
+    def forward(self, x):
+        x = self._stage(self.conv_pool2, self._stage(self.conv_pool1, x))
+        c3 = self._stage(self.conv_pool3, x)
+        c4 = self._stage(self.conv_pool4, c3)
+        x = self._stage(self.conv_pool5, c4)
+        return c3, c4, conv_bn_act(x, self.conv_add.conv, self.conv_add.bn, "relu", self.training)
+
+
 class Neck(nn.Module):
     def __init__(self, depth, width, in_channels=(256, 512, 1024), backbone_type="darknet"):
         super().__init__()
         c3, c4, c5 = [int(c * width) for c in in_channels]
         n = round(3 * depth)
-        self.backbone = {"darknet": lambda: Backbone(depth, width), "resnet": ResNetBackbone, "densenet": DenseNetBackbone}[backbone_type]()
+        self.backbone = {"darknet": lambda: Backbone(depth, width), "resnet": ResNetBackbone, "densenet": DenseNetBackbone, "vgg": VGGBackbone}[backbone_type]()
         self.lateral_conv0 = Unit(c5, c4, 1)
         self.C3_p4 = CSP(2 * c4, c4, n, add=False)
         self.reduce_conv1 = Unit(c4, c3, 1)

@@ -701,10 +701,48 @@ def gen_densenet(utils, models):
         store["out_eval"] = model(x, train=False)[:, ::3]
     save("g16_densenet", **store)
 
+VGG_GRADS = ("backbone.backbone.conv_pool1.0.conv.weight", "backbone.backbone.conv_pool1.1.bn.weight", "backbone.backbone.conv_pool3.2.conv.weight",
+             "backbone.backbone.conv_pool5.3.bn.bias", "backbone.backbone.conv_add.conv.weight", "backbone.lateral_conv0.conv.weight",
+             "head.stems.0.conv.weight")
+
+
+def gen_vgg(utils, models):
+    """YOLOX with ``backbone.backbone = vgg19()`` (the fourth value of the backbone switch; not in BASELINE's configs)."""
+    dk = importlib.import_module("models.darknet")
+    torch.manual_seed(0)
+    backbone = models.YOLOPAFPN(0.33, 1.0, in_channels=[256, 512, 1024], act="silu")
+    backbone.backbone = dk.vgg19()
+    head = models.YOLOXHead(80, 1.0, in_channels=[256, 512, 1024], act="silu")
+    model = models.YOLOX(backbone, head)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    synth.fill_state(model, seed=17)
+    model.train()
+    B, S = 2, 128
+    x = synth.make_images(B, S, seed=171)
+    out = model(x, train=True)[3]
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(152)) * torch.tensor([0.05] * 26 + [1.0] * 81)
+    (out * gy).sum().backward()
+    sd = dict(model.named_parameters())
+    store = {"B": B, "S": S, "out": out.detach(), "keys": np.array(sorted(model.state_dict().keys())),
+             "n_params": sum(p.numel() for p in model.parameters())}
+    for name in VGG_GRADS:
+        g = sd[name].grad
+        store["g:" + name] = g if g.numel() <= 40000 else g.reshape(-1)[:: g.numel() // 20000 + 1]
+        store["gn:" + name] = float(g.double().norm())
+    msd = model.state_dict()
+    for name in ("backbone.backbone.conv_pool1.0.bn.running_mean", "backbone.backbone.conv_pool1.0.bn.running_var"):
+        store["b:" + name] = msd[name]
+    model.eval()
+    with torch.no_grad():
+        store["out_eval"] = model(x, train=False)
+    save("g17_vgg", **store)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet", "densenet"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet", "densenet", "vgg"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -726,3 +764,5 @@ if __name__ == "__main__":
         gen_resnet(utils, models)
     if "densenet" in which:
         gen_densenet(utils, models)
+    if "vgg" in which:
+        gen_vgg(utils, models)

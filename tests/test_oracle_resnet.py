@@ -57,8 +57,4 @@ def test_mirror_parameter_tree(golden):
     assert all(tuple(v.shape) == tuple(ref[k].shape) for k, v in m.state_dict().items())
     units = list(m.backbone.backbone.used_units())
     assert len(units) == 1 + 16 * 3 + 4 and units[0][0].kernel_size == (7, 7)
-    try:
-        enn.YOLOPAFPN(1.0, 1.0, backbone_type="vgg")
-        raise AssertionError("vgg is not built")
-    except NotImplementedError:
-        pass
+    assert isinstance(enn.YOLOPAFPN(1.0, 1.0, backbone_type="resnet").backbone, enn.ResNet)
