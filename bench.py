@@ -149,7 +149,7 @@ def instrumented_step(ts):
     return fam
 
 
-def cpu_baseline(steps=2):
+def cpu_baseline(steps=3):
     """Oracle (CPU restatement, fp32) train step of YOLOX-l-24p at B=1, 640x640, 5 GTs on the host cores."""
     from ep24 import synth
     from oracle import model as om
@@ -180,6 +180,33 @@ def cpu_baseline(steps=2):
                 sample="oracle fp32 train step (fwd+SimOTA loss+bwd+SGD), YOLOX-l-24p, B=1, 640x640, 5 GTs, %d steps after 1 warm-up" % steps)
 
 
+def self_launch(n):
+    """Run this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port) and relay the output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,8 +222,16 @@ def main():
     ap.add_argument("--fisheye", action="store_true", help="non-default: BASELINE config 5 - every step first warps its uint8 source images "
                     "(and masks) with the sector warp on the GPU and letterboxes the results into the network input")
     ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet", "vgg"], help="non-default: BASELINE config 4 (backbone swap)")
+    ap.add_argument("--width", type=float, default=1.0, help="non-default: channel multiplier (tests run a small network through the same path)")
+    ap.add_argument("--depth", type=float, default=1.0, help="non-default: depth multiplier")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (the reference's launcher also spawns its own ranks,
+        # yolox_24p/core/launch.py:82-96).  Decided before anything touches the GPU; the ranks are child processes of a
+        # torch.distributed.run child (never an exec), rank 0's JSON line is relayed, a failing rank fails the run.
+        sys.exit(self_launch(a.gpus))
 
     import torch.distributed as dist
     from ep24 import dp, loss as eloss, nn as enn, synth, train as etrain
@@ -210,7 +245,9 @@ def main():
     if rehearse:
         local = 0
     if world > 1:
-        assert int(os.environ.get("WORLD_SIZE", 1)) == world, "launch with torch.distributed.run --nproc-per-node N"
+        if int(os.environ.get("WORLD_SIZE", 1)) != world:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s (start it plainly, or with torch.distributed.run --nproc-per-node %d)"
+                     % (world, os.environ.get("WORLD_SIZE"), world))
         torch.cuda.set_device(local)
         if rehearse:
             dist.init_process_group("gloo")
@@ -225,7 +262,7 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
 
     torch.manual_seed(0)                                     # identical replicas on every rank
-    model = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0, backbone_type=a.backbone), enn.YOLOXHead(80, 1.0))
+    model = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width, backbone_type=a.backbone), enn.YOLOXHead(80, a.width))
     for mod in model.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):            # init_yolo, exp/yolox_base.py:58-62
             mod.eps, mod.momentum = 1e-3, 0.03

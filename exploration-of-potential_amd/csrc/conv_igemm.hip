@@ -1,439 +1,21 @@
-// ep24 - bf16 implicit-GEMM convolution on CDNA4 MFMA (forward and input-gradient).
+// ep24 - bf16 implicit-GEMM convolution on CDNA4 MFMA (forward and input-gradient): the generic LDS-DMA tiled kernel and
+// the streaming kernel of the memory-bound 1x1 layers.  The gather-GEMM form, its argument block and the shared epilogue
+// are in igemm.h; the 3x3 stride-1 layers run in conv_patch.hip (host wrappers at the bottom of this file dispatch).
 //
-//   D[m][n] = sum_t sum_k  S[pix(m) + off(t)][k] * Wt[n][slot(t)][k]
-//
-// m runs over a pixel grid [B,GH,GW]; S is an NHWC bf16 tensor with row stride ld_src; taps t carry a
-// spatial offset and a weight slot.  Forward conv, stride-1 dgrad and the four parity classes of a stride-2
-// dgrad are all instances of this one gather-GEMM (host wrappers at the bottom build the tap tables).
-//
-// Tiling: 128 x BN x 64 per workgroup of 4 waves (64-lane), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
-// Global -> registers -> LDS (register staging, the gather needs per-lane addresses and zero fill), one LDS
-// stage and 4 co-resident workgroups per CU instead of a deep per-workgroup pipeline;
-// LDS rows are 128 B (64 bf16) with the 16-B chunk index XOR-ed by (row & 7): ds_write_b128 of one row by 8
-// lanes and ds_read_b128 of 16 rows x {chunk c, c+1} by a wave are both bank-conflict free.
-// Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel
-// 4j+t) so every lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
+// Tiling here: 128 x BN x 64 per workgroup of 4 waves (64-lane), v_mfma_f32_16x16x32_bf16, fp32 accumulate; two LDS stages
+// filled by LDS-DMA, two workgroups per CU.  LDS rows are 128 B (64 bf16) with the 16-B chunk index XOR-ed by (row & 7).
+// Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel 4j+t) so every
+// lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
 #include <stdlib.h>
-#include "common.h"
+#include "igemm.h"
 
-// Ablation switches used by tools/conv_probe.py experiments are compiled in only with -DEP24_ABLATE.
-#ifdef EP24_ABLATE
-#define DBG(p, bit) ((p).dbg_mode & (bit))
-#else
-#define DBG(p, bit) 0
-#endif
+using namespace ep24_igemm;
 
 namespace {
 
-struct IgemmArgs {
-    const bf16* src; long ld_src; int B, SH, SW;
-    int GH, GW, sy, sx;
-    int T; int oy[16]; int ox[16]; int wslot[16];
-    const bf16* wt; int WT; int K; int N;
-    void* dst; long ld_dst; int DH, DW, dsy, dsx, dy0, dx0; long dbs, dp0;   // dst pixel = n*dbs + dp0 + (gy*dsy+dy0)*DW + gx*dsx+dx0
-    int accumulate;
-    const float* bias;
-    long long* stats; int stats_replicas;
-    // fused pass 1 of the NEXT BatchNorm backward (input gradient only): D is the complete gradient of a BN+act output
-    // whose pre-activation is bn_z; the epilogue adds sum(du) / sum(du*zhat) per channel to bn_sb / bn_sg
-    const bf16* bn_z; long bn_ldz; const float* bn_save; const float* bn_gamma; const float* bn_beta;
-    long long* bn_sg; long long* bn_sb; int bn_act;
-    // inference epilogue (BatchNorm folded into weights and bias): y = act(acc + bias) + residual
-    int epi_act; const bf16* epi_res; long epi_ldres; int epi_infer;
-    int b_resident_max;
-    int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
-    unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernel
-    FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
-    int dbg_same_addr;              // tools/conv_probe.py experiment: every lane fetches the same few lines
-    int dbg_mode;                   // ablations: 1 no MFMA, 2 no DMA, 4 no barrier/wait, 8 no LDS fragment reads
-    long M;
-};
-
-constexpr int BM = 128;
-constexpr int BK = 64;
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-template <int BN, bool OUT_F32, bool PERSIST>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
-    constexpr int WN = BN / 64;            // waves along N
-    constexpr int WM = 4 / WN;             // waves along M
-    constexpr int MT = BM / WM / 16;       // 16-row tiles per wave (4 or 2)
-    constexpr int NT = 4;
-    constexpr int A_BYTES = BM * 128;
-    constexpr int B_BYTES = BN * 128;
-    constexpr int B_PIECES = BN * 8 / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // ONE LDS stage for A (16 KB) so that up to 4 workgroups share a CU: while one waits at its barriers or for
-    // HBM the others keep the MFMA pipe and the memory system busy; the next tile's global loads are issued
-    // before the MFMAs of the current one and land in registers meanwhile.  The workgroup is persistent over M
-    // tiles (blockIdx.x, stride gridDim.x): the prefetch runs across tile boundaries, BN statistics stay in
-    // registers until the end (one atomic per channel per workgroup) and, when the whole K extent fits in
-    // MAX_RESIDENT stages, the weight tiles are loaded once and stay in LDS.
-    const int KC = (p.K + BK - 1) / BK;          // K is a multiple of 8; the last 64-chunk may be partial
-    const int n_iter = p.T * KC;
-    const bool b_resident = PERSIST && n_iter <= p.b_resident_max;
-    char* const lds_a = smem;
-    char* const lds_b0 = smem + A_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.y * BN;
-    const int tiles_m = (int)((p.M + BM - 1) / BM);
-    const int my_tiles = PERSIST ? (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
-    const int total = my_tiles * n_iter;
-
-    // ---- per-thread gather bookkeeping for the tile being LOADED: 4 A rows (tid>>3)+32i, chunk tid&7
-    const int chunk = tid & 7;
-    const int lrow = tid >> 3;
-    int pixbase[4], iy0[4], ix0[4];
-    bool rvalid[4];
-    auto setup_rows = [&](int tile) {
-        const long m0 = (long)tile * BM;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long m = m0 + lrow + 32 * i;
-            rvalid[i] = m < p.M;
-            int mm = rvalid[i] ? (int)m : 0;
-            int n = fdiv(mm, p.d_plane);
-            int rem = mm - n * (p.GH * p.GW);
-            int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
-            pixbase[i] = n * p.SH * p.SW;
-            iy0[i] = gy * p.sy;
-            ix0[i] = gx * p.sx;
-        }
-    };
-    // B rows: weight row n -> LDS row (relabelled inside each 64 span)
-    int brow_g[B_PIECES], brow_l[B_PIECES];
-#pragma unroll
-    for (int i = 0; i < B_PIECES; ++i) {
-        int r = lrow + 32 * i;                       // 0..BN-1 : logical channel inside the tile
-        brow_g[i] = n0 + r;
-        brow_l[i] = (r & ~63) + ((r & 3) << 4) + ((r >> 2) & 15);
-    }
-
-    bf16x8 ra[4], rb[B_PIECES];
-    int ld_it = 0, ld_tile = blockIdx.x;             // (K-step, M tile) of the next load
-    int ld_t = 0, ld_kc = 0;                         // its (tap, channel chunk)
-    bool ld_first = true;                            // still inside this workgroup's first M tile
-
-    auto load_tile = [&]() {
-        if (ld_it == 0) { setup_rows(ld_tile); ld_t = 0; ld_kc = 0; }
-        const int t = ld_t, kc = ld_kc;
-        if (++ld_kc == KC) { ld_kc = 0; ++ld_t; }
-        const int oy = p.oy[t], ox = p.ox[t];
-        const bool kok = kc * BK + chunk * 8 < p.K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int iy = iy0[i] + oy, ix = ix0[i] + ox;
-            bool ok = kok && rvalid[i] && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const bf16* s = p.src + ((long)(pixbase[i] + iy * p.SW + ix)) * p.ld_src + kc * BK + chunk * 8;
-                v = *reinterpret_cast<const bf16x8*>(s);
-            }
-            ra[i] = v;
-        }
-        if (!b_resident || ld_first) {
-            const long wtap = (long)p.wslot[t] * p.K + kc * BK + chunk * 8;
-#pragma unroll
-            for (int i = 0; i < B_PIECES; ++i) {
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (kok && brow_g[i] < p.N) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)brow_g[i] * p.WT * p.K + wtap);
-                rb[i] = v;
-            }
-        }
-    };
-    // the tile held in registers is (st_it, st_first); advance the load cursor after each load
-    int st_it = 0;
-    bool st_first = true;
-    auto advance_load = [&]() {
-        st_it = ld_it; st_first = ld_first;
-        if (++ld_it == n_iter) { ld_it = 0; ld_tile += gridDim.x; ld_first = false; }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<bf16x8*>(lds_a + swz(lrow + 32 * i, chunk)) = ra[i];
-        if (!b_resident || st_first) {
-            char* lb = lds_b0 + (b_resident ? st_it * B_BYTES : 0);
-#pragma unroll
-            for (int i = 0; i < B_PIECES; ++i)
-                *reinterpret_cast<bf16x8*>(lb + swz(brow_l[i], chunk)) = rb[i];
-        }
-    };
-
-    f32x4 acc[MT][NT];
-    const int frow = lane & 15;      // row inside a 16-row tile (A: pixel, B: relabelled channel)
-    const int fq = lane >> 4;        // k-chunk inside a 32-deep k-step
-    const int c0 = n0 + wn * 64 + 4 * frow;      // lane owns channels c0..c0+3 (n-tiles 0..3)
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr bool bnr = false;                        // (the fused BN reduce exists in the LDS-DMA and streaming kernels only)
-    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bnr) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < p.N) {
-                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
-                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
-            }
-    }
-    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
-                           p.dbs == (long)p.GH * p.GW);
-
-    if (total > 0) { load_tile(); advance_load(); }
-    int j = 0, tile = blockIdx.x;
-    for (int tl = 0; tl < my_tiles; ++tl) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int it = 0; it < n_iter; ++it, ++j) {
-            if (j) __syncthreads();                // every wave is done reading the previous stage
-            store_tile();
-            __syncthreads();
-            if (j + 1 < total) load_tile();        // in flight during the MFMAs below
-            const char* lb = lds_b0 + (b_resident ? it * B_BYTES : 0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[MT], fb[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8*>(lds_a + swz(wm * (MT * 16) + i * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    fb[q] = *reinterpret_cast<const bf16x8*>(lb + swz(wn * 64 + q * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
-            }
-            if (j + 1 < total) advance_load();
-        }
-
-        // ---- epilogue of this M tile: pixels 4*fq + r of every m-tile, channels c0..c0+3
-        const long m0 = (long)tile * BM;
-        tile += gridDim.x;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
-                if (m >= p.M) continue;
-                long dpix = m;
-                if (!fast_dst) {
-                    int n = fdiv((int)m, p.d_plane);
-                    int rem = (int)m - n * (p.GH * p.GW);
-                    int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
-                    dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
-                }
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = acc[i][q][r] + bias4[q];
-                    s1[q] += v[q];
-                    s2[q] += v[q] * v[q];
-                }
-                if constexpr (OUT_F32) {
-                    float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
-                } else {
-                    bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
-                    if (c0 + 3 < p.N) {
-                        if (p.accumulate) {
-                            bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
-                        }
-                        bf16x4 w;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
-                        *reinterpret_cast<bf16x4*>(d) = w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                    }
-                }
-            }
-        }
-    }
-
-    if (p.stats) {
-        // per-channel sums of this workgroup: fold the 4 lane groups of a wave, then the WM waves that share
-        // the channel range through LDS, then ONE fixed-point atomic per channel (coalesced, 512 B per wave)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a = s1[q], b = s2[q];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (fq == 0) {
-                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
-            }
-        }
-        __syncthreads();
-        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
-        for (int i = tid; i < 2 * BN; i += 256) {
-            const int which = i / BN, c = i - which * BN;      // channel inside the tile
-            const int wcol = c >> 6;                            // wave column owning it
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
-        }
-    }
-}
-
-// Shared epilogue of the DMA kernels: bias, BN statistics, bf16 / fp32 stores, fixed-point statistic atomics.
-template <int BN, bool OUT_F32, int MT, int BNR = 0>           // BNR: 0 plain, 1 fused BN-backward pass 1, 2 inference (act + residual)
-__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
-    constexpr int WN = BN / 64, WM = 4 / WN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int frow = lane & 15, fq = lane >> 4;
-    if (DBG(p, 64)) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(acc[i][q]));
-        return;
-    }
-    const int c0 = n0 + wn * 64 + 4 * frow;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr bool bnr = BNR == 1 && !OUT_F32;         // compiled in only for the experiment's instantiation
-    constexpr bool infer = BNR == 2 && !OUT_F32;       // compiled in only for the eval-mode instantiation
-    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bnr) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < p.N) {
-                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
-                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
-            }
-    }
-    const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
-                           p.dbs == (long)p.GH * p.GW);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
-            if (m >= p.M) continue;
-            long dpix = m;
-            if (!fast_dst) {
-                int n = fdiv((int)m, p.d_plane);
-                int rem = (int)m - n * (p.GH * p.GW);
-                int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
-                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
-            }
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[q] = acc[i][q][r] + bias4[q];
-                if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
-            }
-            if (DBG(p, 16)) continue;
-            if constexpr (OUT_F32) {
-                float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c0 + q < p.N) d[q] = p.accumulate ? d[q] + v[q] : v[q];
-            } else {
-                bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + c0;
-                if (infer) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) {
-                            float y = act_fwd(v[q], p.epi_act);
-                            if (p.epi_res) y += (float)p.epi_res[dpix * p.epi_ldres + c0 + q];
-                            v[q] = y;
-                        }
-                }
-                if (c0 + 3 < p.N) {
-                    if (p.accumulate) {
-                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
-                    }
-                    bf16x4 w;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
-                    *reinterpret_cast<bf16x4*>(d) = w;
-                    if (bnr) {
-                        const bf16x4 zz = *reinterpret_cast<const bf16x4*>(p.bn_z + dpix * p.bn_ldz + c0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float zf = (float)zz[q];
-                            const float du = (float)w[q] * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                            s1[q] += du;                             // -> sum(du)
-                            s2[q] += du * (zf * biv[q] - bmi[q]);    // -> sum(du * zhat)
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) {
-                            const bf16 w = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                            d[q] = w;
-                            if (bnr) {
-                                const float zf = (float)p.bn_z[dpix * p.bn_ldz + c0 + q];
-                                const float du = (float)w * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                                s1[q] += du;
-                                s2[q] += du * (zf * biv[q] - bmi[q]);
-                            }
-                        }
-                }
-            }
-        }
-    }
-    if ((p.stats || bnr) && !DBG(p, 32)) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a = s1[q], b = s2[q];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (fq == 0) {
-                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
-            }
-        }
-        __syncthreads();
-        long long* st = bnr ? nullptr : p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
-        for (int i = tid; i < 2 * BN; i += 256) {
-            const int which = i / BN, c = i - which * BN;
-            const int wcol = c >> 6;
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) {
-                long long* dst = bnr ? (which ? p.bn_sg : p.bn_sb) + n0 + c : st + (long)which * p.N + n0 + c;
-                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(v));
-            }
-        }
-    }
-}
+// ep24_conv_set_patch(0) routes the 3x3 stride-1 layers through the generic tiled kernel again (A/B measurements, tests that
+// compare the two kernels on one shape); read once per launch, no environment lookups on the launch path
+int g_use_patch = 1;
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
@@ -442,9 +24,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 // SOURCE address: LDS unit U = row*8 + pchunk is fetched from (row, pchunk ^ (row & 7)); padding taps and the
 // M / N / K tails use an out-of-range buffer offset, for which the DMA writes zeros.  Two LDS stages, one barrier per K-step: the DMA of tile t+1 is
 // in flight while tile t feeds the MFMAs.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 template <int BN, bool OUT_F32, int BNR = 0>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
@@ -473,7 +52,6 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
     const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
-    constexpr int OOB = 0x7FFFFFF0;
     int rowoff[A_INSTR];
     unsigned vmask[A_INSTR];
 #pragma unroll
@@ -515,13 +93,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             int vo = (kok && ((vmask[i] >> t) & 1u)) ? rowoff[i] + a_s : OOB;
-            if (DBG(p, 256) || (DBG(p, 1024) && (i & 1))) vo = OOB;          // ablation: drop (half of) the A fill traffic
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             int vo = kok ? wvoff[i] + b_s : OOB;
-            if (DBG(p, 512)) vo = OOB;                                        // ablation: drop the B fill traffic
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
     };
@@ -533,10 +109,18 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
 
+    // fused BN-reduce epilogue (BNR == 1): this lane's z values are fetched into registers one K-step before the end
+    // of the loop, so the epilogue finds them there instead of waiting for 8-byte loads at the exposed end of the tile
+    ZTile4 zt;
+    const bool zpre = BNR == 1 && !OUT_F32 && p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
+                      p.dbs == (long)p.GH * p.GW;
+    if (zpre && n_iter == 1) load_ztile<MT>(p, zt, m0, n0, wm, wn, lane);
+
     issue(0);
     for (int it = 0; it < n_iter; ++it) {
         __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
         if (it + 1 < n_iter) issue((it + 1) & 1);
+        if (zpre && it == n_iter - 2) load_ztile<MT>(p, zt, m0, n0, wm, wn, lane);
         const char* la = smem + (it & 1) * STAGE;
         const char* lb = la + A_BYTES;
 #pragma unroll
@@ -556,178 +140,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         }
     }
 
-    igemm_epilogue<BN, OUT_F32, MT, BNR>(p, acc, m0, n0, tile_m, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Ring variant: BK = 32 stages (A 8 KB + B 8/4 KB), RING stages per workgroup, DMA runs RING-1 stages ahead and is
-// retired with COUNTED s_waitcnt vmcnt(N) + a raw s_barrier (a __syncthreads() would drain every DMA in flight).
-// With one stage of lookahead every K-step waited a full L2/HBM round trip (~2-4 k cycles against 512 cycles of
-// MFMA); here three stages are in flight per workgroup and two workgroups share a CU.
-// LDS rows are 64 B: unit (row, chunk c) sits at 16-B slot ((row>>2)&3) ^ PERM[c] of its row, which makes the
-// ds_read_b128 fragment reads (16 rows x chunks {c, c+1} per lane group) conflict free; the DMA applies the inverse
-// on the source side.
-#define EP24_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-template <int BN, bool OUT_F32, int RING>
-__global__ __launch_bounds__(256) void igemm_ring_kernel(const IgemmArgs p) {
-    constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
-    constexpr int RK = 32;
-    if (DBG(p, 128)) return;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = A_BYTES / 1024 / 4;          // 2 DMA instructions per wave
-    constexpr int B_INSTR = B_BYTES / 1024 / 4;          // 2 (BN=128) or 1 (BN=64)
-    constexpr int GROUP = A_INSTR + B_INSTR;             // vmcnt units per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = tile_id / tiles_n;
-    const long m0 = (long)tile_m * BM;
-    const int n0 = (tile_id - tile_m * tiles_n) * BN;
-    const int KC = (p.K + RK - 1) / RK;
-    const int n_iter = p.T * KC;
-
-    // lane -> LDS unit U = (wave*NI + i)*64 + lane: row = U>>2, physical slot = U&3, logical chunk = PINV[slot ^ rh]
-    const int rh = (lane >> 4) & 3;                       // ((row >> 2) & 3) with row = 16*k + (lane >> 2)
-    const int pslot = lane & 3;
-    const int lchunk = (0x1320 >> (4 * (pslot ^ rh))) & 3;   // PINV = {0,2,3,1}
-    const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
-    const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
-    int rowoff[A_INSTR];
-    unsigned vmask[A_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const long m = m0 + (wave * A_INSTR + i) * 16 + (lane >> 2);
-        const bool rv = m < p.M;
-        const int mm = rv ? (int)m : 0;
-        const int n = fdiv(mm, p.d_plane);
-        const int rem = mm - n * (p.GH * p.GW);
-        const int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
-        const int iy0 = gy * p.sy, ix0 = gx * p.sx;
-        rowoff[i] = (int)((((long)n * p.SH * p.SW + (long)iy0 * p.SW + ix0) * p.ld_src + lchunk * 8) * 2);
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {         // static trip count: the tap tables arrive with the kernel arguments
-            const int iy = iy0 + p.oy[t], ix = ix0 + p.ox[t];
-            if (t < p.T && rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
-        }
-        vmask[i] = mk;
-    }
-    int wvoff[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int q = (wave * B_INSTR + i) * 16 + (lane >> 2);
-        const int r = (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
-        wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : 0x40000000;
-    }
-    const int kmax = (p.K - lchunk * 8 + RK - 1) / RK;
-    if (p.dbg_same_addr) {
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) rowoff[i] = (lane & 7) * 16 + 4096;
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) wvoff[i] = (lane & 7) * 16;
-    }
-
-    // per-tap scalars live in a small LDS table and are fetched one stage ahead (a dynamic kernarg index would be
-    // an s_load + full lgkmcnt wait inside every K step)
-    int* tap_tab = reinterpret_cast<int*>(smem + RING * STAGE);        // [0..15] source byte offset, [16..31] weight slot
-    if (tid < 16) { tap_tab[tid] = p.toff[tid]; tap_tab[16 + tid] = p.wslot[tid] * p.K * 2; }
-    __syncthreads();
-    int is_t = 0, is_kc = 0, is_stage = 0;
-    int pf_a = tap_tab[0], pf_b = tap_tab[16];
-    auto issue = [&]() {
-        const int t = is_t, kc = is_kc;
-        if (++is_t == p.T) { is_t = 0; ++is_kc; }
-        const int a_s = pf_a + kc * (RK * 2);
-        const int b_s = pf_b + kc * (RK * 2);
-        pf_a = tap_tab[is_t];                              // for the next call
-        pf_b = tap_tab[16 + is_t];
-        char* stage = smem + is_stage * STAGE;
-        if (++is_stage == RING) is_stage = 0;
-        // branch-free validity: an invalid lane adds 2^30 to its offset (beyond every buffer => the DMA writes zeros).
-        // The value is made opaque so the compiler cannot turn the select into two exec-masked copies of the load,
-        // which would break the counted vmcnt bookkeeping below.
-        int kbad = kc < kmax ? 0 : 0x40000000;
-        asm volatile("" : "+v"(kbad));
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            int bad = ((vmask[i] >> t) & 1u) ? 0 : 0x40000000;
-            asm volatile("" : "+v"(bad));
-            const int vo = (rowoff[i] + a_s) + (bad | kbad);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int vo = (wvoff[i] + b_s) + kbad;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4;
-    // fragment address inside a stage: row*64 + ((row>>2)&3 ^ PERM[fq])*16, PERM = {0,3,1,2}
-    const int pfq = (0x2130 >> (4 * fq)) & 3;
-    int a_off[MT], b_off[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = wm * (MT * 16) + i * 16 + frow;
-        a_off[i] = row * 64 + ((((row >> 2) & 3) ^ pfq) << 4);
-    }
-#pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int row = wn * 64 + q * 16 + frow;
-        b_off[q] = A_BYTES + row * 64 + ((((row >> 2) & 3) ^ pfq) << 4);
-    }
-
-    if (DBG(p, 256)) { asm volatile("" ::"v"(rowoff[0] + wvoff[0] + (int)vmask[0] + a_off[0] + b_off[0])); return; }
-    const int pre = n_iter < RING - 1 ? n_iter : RING - 1;
-    for (int s_ = 0; s_ < pre; ++s_) issue();
-    int issued = pre, cs = 0;
-    for (int it = 0; it < n_iter; ++it) {
-        const int ahead = issued - it - 1;               // stages issued after the one needed now (0..RING-2)
-        if (!DBG(p, 4)) {
-        if (ahead >= 2) { if constexpr (GROUP == 4) EP24_WAIT_VMCNT(8); else EP24_WAIT_VMCNT(6); }
-        else if (ahead == 1) { if constexpr (GROUP == 4) EP24_WAIT_VMCNT(4); else EP24_WAIT_VMCNT(3); }
-        else EP24_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();                     // stage `it` landed for every wave; stage it-1 is free
-        }
-        if (issued < n_iter) { if (!DBG(p, 2)) issue(); ++issued; }
-        const char* st = smem + cs * STAGE;
-        if (++cs == RING) cs = 0;
-        bf16x8 fa[MT], fb[NT];
-        if (!DBG(p, 8)) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i]);
-#pragma unroll
-        for (int q = 0; q < NT; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(st + b_off[q]);
-        } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(fa[i]));
-#pragma unroll
-        for (int q = 0; q < NT; ++q) asm volatile("" : "=v"(fb[q]));
-        }
-        if (!DBG(p, 1)) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int q = 0; q < NT; ++q)
-                acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
-        } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-        for (int q = 0; q < NT; ++q) asm volatile("" ::"v"(fb[q]));
-        }
-    }
-    igemm_epilogue<BN, OUT_F32, MT>(p, acc, m0, n0, tile_m, smem);
+    igemm_epilogue<BN, OUT_F32, MT, BNR>(p, acc, m0, n0, tile_m, smem, zpre ? &zt : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -937,7 +350,6 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
     long bpn = (512 / n_tiles + 7) / 8 * 8;
     if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
-    if (const char* e = getenv("EP24_DBG_STREAM_BPN")) bpn = atoi(e);
     const int npan = (a.K + 63) / 64;
     size_t lds = (size_t)npan * BN * 128;
     if (lds < 2048) lds = 2048;
@@ -947,68 +359,66 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
 }
 
 template <int BN, bool F32>
-void launch_variant(const IgemmArgs& a, bool persist, dim3 grid, size_t lds, hipStream_t stream) {
-    if (persist) hipLaunchKernelGGL((igemm_kernel<BN, F32, true>), grid, dim3(256), lds, stream, a);
-    else if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
-    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 1>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
-    else if (!getenv("EP24_IGEMM_RING")) hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(grid.x * grid.y), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
-    else {
-        // experimental: BK=32 ring with counted vmcnt (EP24_IGEMM_RING=2|3|4 stages); measured within +-10 % of the
-        // two-stage BK=64 kernel on the 3x3 layers, which stays the default
-        const int ring = atoi(getenv("EP24_IGEMM_RING"));
-        const dim3 g1(grid.x * grid.y);
-        const size_t st = BM * 64 + BN * 64;
-        if (ring == 2) hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 2>), g1, dim3(256), 2 * st + 128, stream, a);
-        else if (ring == 3) hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 3>), g1, dim3(256), 3 * st + 128, stream, a);
-        else hipLaunchKernelGGL((igemm_ring_kernel<BN, F32, 4>), g1, dim3(256), 4 * st + 128, stream, a);
-    }
+void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
+    constexpr size_t lds = 2 * (BM * 128 + BN * 128);
+    if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), lds, stream, a);
+    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 1>), dim3(tiles), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(tiles), dim3(256), lds, stream, a);
+}
+
+// The kernels address their operands with 32-bit byte offsets through buffer descriptors (out-of-range = zero fill is how
+// padding and tails work), so every operand extent must stay below 2 GiB and the pixel count below 2^31.
+int check_extents(const IgemmArgs& a) {
+    const long src_b = (((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2;
+    const long wt_b = (long)a.N * a.WT * a.K * 2;
+    EP24_REQUIRE(src_b < 0x7FFF0000L && wt_b < 0x7FFF0000L && a.M < (1L << 31) && (long)a.B * a.SH * a.SW < (1L << 31), EP24_E_UNSUPPORTED,
+                 "conv: a source of %ld bytes / weights of %ld bytes / %ld output pixels are beyond what the 32-bit tile addressing covers "
+                 "(2 GiB per operand): split the batch", src_b, wt_b, (long)a.M);
+    return EP24_OK;
 }
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
+    if (int rc = check_extents(a)) return rc;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
+    a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
+    a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
-        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && !getenv("EP24_NO_STREAM")) {
+        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0) {
         if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
         else          { if (a.K > 128) launch_stream<64, 2>(a, stream); else launch_stream<64, 1>(a, stream); }
         EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
         return EP24_OK;
     }
+    // 3x3 stride-1 (forward and input gradient): the halo-patch kernel, when the shape fits its LDS budget
+    if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer && g_use_patch &&
+        launch_patch(a, stream)) {
+        EP24_LAUNCH_CHECK("ep24_conv_patch");
+        return EP24_OK;
+    }
     // 128-wide N tiles unless that leaves at most one workgroup per CU (the 20x20 level at B = 20): 64-wide tiles then
     // double the workgroups (+3 .. +27 % on those layers)
     const bool wide = a.N > 64 && (long)ep24_cdiv(a.M, BM) * ep24_cdiv(a.N, 128) > 256;
-    const int gy = ep24_cdiv(a.N, wide ? 128 : 64);
-    const int tiles_m = ep24_cdiv(a.M, BM);
-    // The register-staged persistent kernel (workgroups walking several M tiles) is kept as an experiment switch
-    // only: since the LDS-DMA kernel got its hoisted addressing it is 1.3-1.5x faster on the large-M 3x3 layers too,
-    // and the memory-bound 1x1 layers have their own streaming kernel.
-    const bool persist = (long)tiles_m * gy > 2048 && getenv("EP24_PERSIST");
-    int gx = persist ? 1024 / gy : tiles_m;
-    if (gx < 1) gx = 1;
-    dim3 grid(gx, gy);
-    a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
-    a.dbg_same_addr = getenv("EP24_DBG_SAME_ADDR") != nullptr;
-    a.dbg_mode = getenv("EP24_DBG_MODE") ? atoi(getenv("EP24_DBG_MODE")) : 0;
-    for (int t = 0; t < a.T; ++t) a.toff[t] = a.dbg_same_addr ? 0 : (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
-    a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
-    a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
-    const int n_iter = a.T * ((a.K + BK - 1) / BK);
-    // keep the weight tiles resident in LDS when the whole reduction fits in two stages
-    a.b_resident_max = (persist && n_iter <= 2) ? 2 : 0;
-    const int b_stages = a.b_resident_max ? n_iter : 1;
-    size_t lds = BM * 128 + (size_t)b_stages * (wide ? 128 : 64) * 128;
+    const unsigned tiles = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, wide ? 128 : 64);
+    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
     if (wide) {
-        if (out_f32) launch_variant<128, true>(a, persist, grid, lds, stream);
-        else launch_variant<128, false>(a, persist, grid, lds, stream);
+        if (out_f32) launch_variant<128, true>(a, tiles, stream);
+        else launch_variant<128, false>(a, tiles, stream);
     } else {
-        if (out_f32) launch_variant<64, true>(a, persist, grid, lds, stream);
-        else launch_variant<64, false>(a, persist, grid, lds, stream);
+        if (out_f32) launch_variant<64, true>(a, tiles, stream);
+        else launch_variant<64, false>(a, tiles, stream);
     }
     EP24_LAUNCH_CHECK("ep24_conv_igemm");
     return EP24_OK;
 }
 
 }  // namespace
+
+extern "C" int ep24_conv_set_patch(int on) {
+    const int old = g_use_patch;
+    g_use_patch = on != 0;
+    return old;
+}
 
 extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                                   int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,

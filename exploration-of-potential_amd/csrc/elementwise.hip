@@ -257,126 +257,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
     }
 }
 
-// ---------------------------------------------------------------------------------------- fused BN backward
-// Both backward passes in ONE launch for the layers whose dy / z slices fit in the register files of the chip: a
-// workgroup loads its R rows per thread once, adds its partial sums (fixed-point atomics, memory side), crosses a
-// grid-wide barrier, reads the complete sums back and turns the rows it still holds into dz.  dy and z are read once
-// instead of twice (3 tensor passes instead of 5) and a launch boundary is saved.
-// Grid barrier = arrival counter (agent-scope atomic add by one lane per workgroup after every wave has drained its
-// atomics) polled with sc1 loads; at most one workgroup per CU (gridDim <= 256, 512 threads), so every workgroup is
-// resident once the kernels sharing the chip make room, and the spin is bounded: on timeout the kernel finishes with
-// g_sync_timeouts bumped instead of hanging (cdna guide section 1, "grid-wide barrier ... bound every spin").
-__device__ unsigned g_sync_timeouts = 0;
-
-template <int R>
-__global__ __launch_bounds__(512) void bn_act_bwd_fused_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
-                                                              const float* save, const float* gamma, const float* beta,
-                                                              long long* dgamma, long long* dbeta, float* ggrad, float* bgrad,
-                                                              bf16* dz, long ld_dz, long M, int C, int act, unsigned* counter) {
-    constexpr int NT = 512;
-    __shared__ float red[NT][16 + 1];
-    const RowMap rm(C, NT);
-    const int tid = threadIdx.x;
-    const int cg = tid % rm.tpr;
-    const int slot = tid / rm.tpr;
-    const bool active = slot < rm.rpb;
-    const long step = (long)gridDim.x * rm.rpb;
-    const long m_first = (long)blockIdx.x * rm.rpb + slot;
-    bf16x8 vdy[R], vz[R];
-    float sc[8], sh[8], iv[8], mi[8];
-    float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const long mm = m_first + k * step;
-            if (mm < M) {
-                vdy[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8));
-                vz[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            const float mean = save[c], inv = save[C + c];
-            sc[j] = gamma[c] * inv; sh[j] = beta[c] - mean * sc[j]; iv[j] = inv; mi[j] = mean * inv;
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            if (m_first + k * step >= M) break;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float zz = (float)vz[k][j];
-                const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
-                sb[j] += du;
-                sg[j] = fmaf(du, fmaf(zz, iv[j], -mi[j]), sg[j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[tid][j] = sg[j]; red[tid][8 + j] = sb[j]; }
-    __syncthreads();
-    for (int t = tid; t < rm.tpr * 16; t += NT) {
-        const int g = t >> 4, v = t & 15;
-        float a = 0.f;
-        for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
-        long long* dst = (v < 8 ? dgamma : dbeta) + g * 8 + (v & 7);
-        atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(a));
-    }
-    // ---- grid barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's atomics have been performed
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 24)) { atomicAdd(&g_sync_timeouts, 1u); break; }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // ---- pass 2 on the rows still in registers
-    if (!active) return;
-    const float invM = 1.f / (float)M;
-    float k1[8], k2[8], k3[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = cg * 8 + j;
-        const float sg_ = from_fix(__hip_atomic_load(dgamma + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float sb_ = from_fix(__hip_atomic_load(dbeta + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float mean = save[c], inv = iv[j];
-        k1[j] = sc[j];
-        k3[j] = k1[j] * inv * (sg_ * invM);
-        k2[j] = k1[j] * (sb_ * invM) - k3[j] * mean;
-        if (blockIdx.x == 0 && slot == 0 && ggrad) { ggrad[c] += sg_; bgrad[c] += sb_; }
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const long mm = m_first + k * step;
-        if (mm >= M) break;
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float zz = (float)vz[k][j];
-            const float du = (float)vdy[k][j] * act_grad(fmaf(zz, sc[j], sh[j]), act);
-            o[j] = (bf16)fmaf(-k3[j], zz, fmaf(k1[j], du, -k2[j]));
-        }
-        *reinterpret_cast<bf16x8*>(dz + mm * ld_dz + cg * 8) = o;
-    }
-}
-
-// rows per thread the fused kernel needs for [M, C] (0: does not fit - use the two-pass kernels); grid in *blocks
-int fused_rows(long M, int C, int* blocks) {
-    const int tpr = C >> 3;
-    if (C % 8 != 0 || tpr < 1 || tpr > 512) return 0;
-    const int rpb = 512 / tpr;
-    long nb = (M + rpb - 1) / rpb;
-    if (nb > 256) nb = 256;
-    const long need = (M + nb * rpb - 1) / (nb * rpb);
-    if (blocks) *blocks = (int)nb;
-    return need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 0;
-}
-
 int flat_grid(long M, int C, int per_thread) {       // flat 16-byte chunks, `per_thread` chunks per lane
     long blocks = (M * (C >> 3) + 256L * per_thread - 1) / (256L * per_thread);
     return (int)(blocks < 1 ? 1 : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks));
@@ -987,31 +867,6 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
-}
-
-extern "C" int ep24_bn_act_bwd_fused_rows(int64_t M, int C) { return M > 0 ? fused_rows(M, C, nullptr) : 0; }
-
-extern "C" int ep24_bn_act_bwd_fused(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                                     const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, float* gamma_grad,
-                                     float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act, uint32_t* counter,
-                                     void* stream) {
-    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz && counter, EP24_E_ARG, "bn_act_bwd_fused: null pointer");
-    EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_fused: alignment");
-    int nb = 0;
-    const int R = M > 0 ? fused_rows(M, C, &nb) : 0;
-    EP24_REQUIRE(R > 0, EP24_E_UNSUPPORTED, "bn_act_bwd_fused: [%ld, %d] does not fit the register-resident form", (long)M, C);
-#define EP24_FUSED(RR) hipLaunchKernelGGL(bn_act_bwd_fused_kernel<RR>, dim3(nb), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z, \
-                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, gamma_grad, beta_grad, (bf16*)dz, ld_dz, (long)M, C, act, counter)
-    if (R == 2) EP24_FUSED(2); else if (R == 4) EP24_FUSED(4); else if (R == 8) EP24_FUSED(8); else EP24_FUSED(16);
-#undef EP24_FUSED
-    EP24_LAUNCH_CHECK("ep24_bn_act_bwd_fused");
-    return EP24_OK;
-}
-
-extern "C" int ep24_debug_sync_timeouts(void) {
-    unsigned v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sync_timeouts), sizeof(v)) != hipSuccess) return -1;
-    return (int)v;
 }
 
 extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,

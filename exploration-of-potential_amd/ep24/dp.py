@@ -77,7 +77,13 @@ class GradReducer:
             self._comm = torch.cuda.Stream()
 
     def attach(self, home, eng):
+        """Plan the buckets over this model's flat gradient and make the replicas identical once: rank 0's parameters,
+        momentum and BatchNorm running statistics go to every rank (the legacy trainer relied on equal seeds,
+        core/trainer.py:163; a rank that loaded a checkpoint would silently diverge)."""
         self.plan(home.gflat, eng.bwd_writes)
+        if self.world > 1:
+            for buf in (home.flat, home.mflat, home.bflat, home.first_flag):
+                broadcast_parameters(buf, 0, self.group)
 
     def cuts(self, eng=None):
         return list(self._cuts)

@@ -480,9 +480,6 @@ class Engine:
         self._side = None
         self.use_side = True                    # weight gradients on a second stream
         self.capture_side = os.environ.get("EP24_CAPTURE_SIDE") == "1"   # also inside captured graphs (experimental)
-        # one-launch BN backward (grid barrier, rows kept in registers): measured 15-25 % SLOWER than the two kernels at
-        # YOLOX-l / B=20 (the barrier's serial latency chain outweighs the saved re-read), so it stays an experiment switch
-        self.fuse_bn_bwd = os.environ.get("EP24_FUSED_BN") == "1"
         self._events = []
         self._bwd_builders = []
         self.pre_bn_inputs = {}                  # BatchNorm module -> the Act its pre-activation form reads (tests)
@@ -693,9 +690,8 @@ class Engine:
 
     def _sums_slot(self, C):
         off = sum(self._sum_specs)
-        self._sum_specs.append(2 * C + 2)             # + the arrival counter of the fused backward's grid barrier
-        return ((lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C)),
-                (lambda: self.bnsums.data_ptr() + 8 * (off + 2 * C)))
+        self._sum_specs.append(2 * C)
+        return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
     def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=1):
@@ -722,7 +718,7 @@ class Engine:
         self.max_dz = max(self.max_dz, M * cout)
         save = torch.zeros(2 * cout, dtype=torch.float32, device=self.dev)
         stats = self._stats_slot(cout)
-        sum_g, sum_b, bar_cnt = self._sums_slot(cout)
+        sum_g, sum_b = self._sums_slot(cout)
         flat, gflat = home.flat, home.gflat
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
         res_p = residual.ptr() if residual is not None else None
@@ -755,17 +751,11 @@ class Engine:
             dzoff = self._dz_elems
             self._dz_elems += M * cout
             dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
-            if self.fuse_bn_bwd and _lib.lib().fn["ep24_bn_act_bwd_fused_rows"](M, cout) > 0:
-                # both passes in one launch: dy and z are read once and stay in registers across a grid barrier
-                self._b("bn_act_bwd_fused", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
-                                             sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, act,
-                                             bar_cnt), writes=(gam, bet))
-            else:
-                self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, act), reads=out)
-                self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                             ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                             dz, cout, M, cout, act), writes=(gam, bet))
+            self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, act), reads=out)
+            self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                         ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
+                                         dz, cout, M, cout, act), writes=(gam, bet))
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
@@ -952,7 +942,7 @@ class Engine:
         self.pre_bn_inputs[bn] = x
         lstats = self._stats_slot(C)
         save = torch.zeros(2 * C, dtype=torch.float32, device=self.dev)
-        sum_g, sum_b, _ = self._sums_slot(C)
+        sum_g, sum_b = self._sums_slot(C)
         flat, gflat = home.flat, home.gflat
         self._f("stats_gather", bstats, ld_stats, lstats, C, STATS_REPLICAS, ev=False)
         self._f("bn_act_fwd", x.ptr(), x.ld, lstats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),

@@ -16,6 +16,7 @@ class Exp(BaseExp):
         self.depth = 1.00
         self.width = 1.00
         self.act = "silu"
+        self.backbone_type = "darknet"   # 'darknet' | 'resnet' | 'densenet' | 'vgg': the switch of yolox/models/yolo_pafpn.py:31-38
         # data
         self.data_num_workers = 8
         self.input_size = (640, 640)
@@ -48,7 +49,7 @@ class Exp(BaseExp):
         from models import YOLOX, YOLOPAFPN, YOLOXHead
         if getattr(self, "model", None) is None:
             in_channels = [256, 512, 1024]
-            backbone = YOLOPAFPN(self.depth, self.width, in_channels=in_channels, act=self.act)
+            backbone = YOLOPAFPN(self.depth, self.width, in_channels=in_channels, act=self.act, backbone_type=self.backbone_type)
             head = YOLOXHead(self.num_classes, self.width, in_channels=in_channels, act=self.act)
             self.model = YOLOX(backbone, head)
         for m in self.model.modules():                    # init_yolo, yolox_base.py:58-62
@@ -61,8 +62,14 @@ class Exp(BaseExp):
     def get_data_loader(self, batch_size):
         from datasets import SyntheticDataset
         import torch
+        import os
         self.dataset = SyntheticDataset(self.synthetic_len, self.input_size[0], self.synthetic_gts, self.num_classes)
-        return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True)
+        world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+        sampler = None
+        if world > 1:                                     # every rank walks its own shard of the epoch
+            sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
+        return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True,
+                                           sampler=sampler)
 
     def preprocess(self, inputs, targets, tsize):
         scale_y = tsize[0] / self.input_size[0]

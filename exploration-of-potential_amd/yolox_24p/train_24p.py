@@ -8,7 +8,8 @@ The step body of the reference ``Trainer.train`` (:80-111: zero_grad, forward, L
 as ONE captured hipGraph (``ep24.train.TrainStep``); ``--no-graph`` runs the same kernels through the reference-style
 eager API (model(...), loss_func.forward(...), loss.backward(), optimizer.step()).  Scalars are logged from a single
 packed device->host copy every ``--log-interval`` steps instead of ~54 per-step ``add_scalar`` syncs (:115-137).
-Under torch.distributed.run every rank trains on its own shard and gradients are averaged over RCCL (ep24.dp).
+Under torch.distributed.run every rank trains on its own shard (DistributedSampler in Exp.get_data_loader), rank 0's
+parameters are broadcast once, and gradients are averaged over RCCL (ep24.dp).
 
 The reference carries three more pieces that its 24p trainer never switches on; they are opt-in
 here and all of them run inside the captured step: ``--sched`` follows ``exp.get_lr_scheduler`` (yoloxwarmcos,
@@ -41,11 +42,21 @@ class Trainer:
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
         local = int(os.environ.get("LOCAL_RANK", args.start_device))
-        self.device = torch.device("cuda", local)
+        dev = torch.device(args.device)
+        if dev.type != "cuda":
+            # SURVEY 5 lists --device for the reference's plumbing run (BASELINE config 1).  This build is the GPU path only:
+            # there is no CPU fallback behind the C ABI, and the trainer says so instead of silently running something else.
+            from ep24._lib import Ep24Error
+            raise Ep24Error("train_24p.py --device %s: the ep24 path runs on an MI355X only (no CPU fallback); the CPU "
+                            "restatement lives in oracle/ and is test infrastructure" % args.device)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else local)
         self.input_size = exp.input_size
         self.file_name = os.path.join(exp.output_dir, exp.exp_name)
         self.current_step = 0
         os.makedirs(self.file_name, exist_ok=True)
+        if not args.synthetic:
+            print("note: the COCO24P loader of the reference reads hard-coded paths (datasets/coco24p.py:19-20) and is out of "
+                  "scope; the synthetic source with the same label layout is used (--synthetic)")
         self.train_loader = exp.get_data_loader(args.batch_size)
         self.loss_func = Loss_Function(exp.num_classes)
         self.loss_func.draw = False
@@ -59,29 +70,49 @@ class Trainer:
         if self.world > 1:
             torch.distributed.init_process_group("nccl", device_id=self.device)
             reducer = dp.GradReducer()
-        torch.manual_seed(0)                              # identical replicas on every rank
+        torch.manual_seed(0)                              # identical replicas on every rank (made explicit by the reducer's broadcast)
         model = exp.get_model()
         model.to(self.device)
         self.model = model
         self.optimizer = exp.get_optimizer(args.learn_rate)
         self.max_iter = len(self.train_loader)
+        # -c / --resume / -e: the reference's parser accepts them and its trainer never reads them (train_24p.py:180-211); here
+        # they load what save_ckpt wrote.  The checkpoint goes in AFTER get_model() (which re-applies the bias prior on every
+        # call, exp/yolox_base.py:70-71) so the loaded predictor biases survive; --resume also restores momentum and epoch.
+        self.start_epoch, ck = 0, None
+        if args.ckpt:
+            from utils import load_ckpt
+            ck = torch.load(args.ckpt, map_location="cpu")
+            load_ckpt(model, ck.get("model", ck))
+            if args.resume:
+                if "optimizer" in ck:
+                    self.optimizer.load_state_dict(ck["optimizer"])
+                self.start_epoch = int(ck.get("start_epoch", 0))
+        if args.start_epoch is not None:
+            self.start_epoch = args.start_epoch
         self.tblogger = SummaryWriter(self.file_name) if (SummaryWriter and self.rank == 0) else None
         self.lr_scheduler = exp.get_lr_scheduler(args.learn_rate, self.max_iter) if args.sched else None
         self.ema_model = None
         if args.ema:
             from utils import ModelEMA
             self.ema_model = ModelEMA(model, 0.9998)
+            if ck is not None and args.resume and "ema_model" in ck:
+                self.ema_model.ema.load_state_dict(ck["ema_model"])
+                self.ema_model.updates = int(ck.get("ema_updates", 0))
         step_fn = None
         if not args.no_graph:
             step_fn = TrainStep(model, self.loss_func, lr=args.learn_rate, momentum=exp.momentum, batch=args.batch_size,
                                 size=self.input_size[0], reducer=reducer, ema=self.ema_model)
         print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "captured step" if step_fn else "eager API"))
         done = False
-        for epoch in range(self.max_epoch):
+        self.epoch = self.start_epoch
+        for epoch in range(self.start_epoch, self.max_epoch):
             self.epoch = epoch
             model.train()
+            if hasattr(self.train_loader.sampler, "set_epoch"):
+                self.train_loader.sampler.set_epoch(epoch)
             t0, seen = time.time(), 0
-            if args.l1 and epoch == self.L1_epoch:
+            if args.l1 and epoch >= self.L1_epoch and not self.loss_func.use_l1:
                 model.head.use_l1 = self.loss_func.use_l1 = True
                 if step_fn is not None:
                     step_fn.set_use_l1(True)
@@ -161,6 +192,9 @@ def make_parser():
     p.add_argument("-e", "--start_epoch", default=None, type=int, help="resume training start epoch")
     p.add_argument("--num_machines", default=1, type=int, help="num of node for training")
     # additions of this build
+    p.add_argument("--device", default="cuda", type=str, help="cuda or cuda:N (the ep24 path has no CPU fallback: cpu is refused)")
+    p.add_argument("--synthetic", action="store_true", help="synthetic images / labels with the reference's layout (the only source here)")
+    p.add_argument("--output-dir", default=None, type=str, help="overrides exp.output_dir")
     p.add_argument("--steps", default=0, type=int, help="stop after this many steps (0 = run all epochs)")
     p.add_argument("--log-interval", default=10, type=int)
     p.add_argument("--no-graph", action="store_true", help="reference-style eager loop instead of the captured step")
@@ -171,12 +205,11 @@ def make_parser():
 
 
 def main(exp, args):
+    if args.output_dir:
+        exp.output_dir = args.output_dir
     trainer = Trainer(exp, args)
-    if args.ckpt:
-        from utils import load_ckpt
-        ck = torch.load(args.ckpt, map_location="cpu")
-        load_ckpt(exp.get_model(), ck.get("model", ck))
     trainer.train()
+    return trainer
 
 
 if __name__ == "__main__":

@@ -51,6 +51,10 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
                        int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
+/* The 3x3 stride-1 layers (forward and input gradient) run in the halo-patch kernel (csrc/conv_patch.hip); 0 routes them
+ * through the generic tiled kernel instead (A/B timing, tests comparing the two on one shape).  Returns the previous value. */
+int ep24_conv_set_patch(int on);
+
 /* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 8 == 0 (zero padded).
  * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */
 int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
@@ -118,17 +122,6 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           void* stream);
-
-/* Both passes in one launch (dy and z read once, kept in registers across a grid-wide barrier) for the shapes whose
- * slices fit: ep24_bn_act_bwd_fused_rows(M, C) > 0.  counter: one zeroed uint32 per call (the barrier's arrival
- * count); dgamma/dbeta zeroed by the caller as for pass 1.  ep24_debug_sync_timeouts() returns how many barrier waits
- * gave up since the library was loaded (0 in a healthy run; the wait is bounded so that nothing can hang). */
-int ep24_bn_act_bwd_fused_rows(int64_t M, int C);
-int ep24_bn_act_bwd_fused(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
-                          const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta,
-                          float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
-                          uint32_t* counter, void* stream);
-int ep24_debug_sync_timeouts(void);
 
 /* ------------------------------------------------------------------------------------------------
  * a1/a2  glue ops of the graph

@@ -117,6 +117,99 @@ def test_conv_fwd_dgrad_wgrad(B, H, Cin, Cout, k, s):
     assert torch.equal(grads[0], grads[1])
 
 
+# The layers that carry ~80 % of YOLOX-l-24p's FLOPs at the BASELINE size (B = 20, 640 x 640: SURVEY.md 8d shape list), plus the
+# shapes that select every production instantiation: the halo-patch kernel with 256x128 / 128x128 / 256x64 tiles, the wide and
+# narrow tiled kernel (stride 2, K > 256 1x1), the streaming kernel with one and two K halves, the 112-column stem.
+HOT_SHAPES = [  # B, H, Cin, Cout, k, s
+    (20, 40, 256, 256, 3, 1), (20, 80, 128, 128, 3, 1), (20, 20, 512, 512, 3, 1), (20, 80, 256, 256, 3, 1), (4, 160, 64, 64, 3, 1),
+    (20, 40, 512, 1024, 3, 2), (20, 80, 256, 512, 3, 2), (20, 20, 2048, 1024, 1, 1), (20, 20, 1024, 512, 1, 1),
+    (20, 40, 512, 256, 1, 1), (20, 80, 128, 128, 1, 1), (20, 80, 256, 256, 1, 1), (2, 320, 112, 64, 1, 1),
+]
+
+
+def _torch_conv_ref(x, w, gy, s, pad):
+    """fp32 conv forward / input gradient / weight gradient on the bf16-rounded operands (device if it works, else host)."""
+    for dev in (DEV, "cpu"):
+        try:
+            xr = x.float().to(dev).requires_grad_(True)
+            wr = w.float().to(dev).requires_grad_(True)
+            y = F.conv2d(xr, wr, None, s, pad)
+            y.backward(gy.float().to(dev))
+            return y.detach().cpu(), xr.grad.cpu(), wr.grad.cpu()
+        except RuntimeError:
+            continue
+    raise RuntimeError("no fp32 reference")
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,s", HOT_SHAPES)
+def test_conv_hot_shapes(B, H, Cin, Cout, k, s):
+    call, ptr, sp = _abi()
+    from ep24 import _lib
+    fn = _lib.lib().fn
+    W = H
+    pad = (k - 1) // 2
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    OH = (H + 2 * pad - k) // s + 1
+    gy = rnd(B, Cout, OH, OH, seed=3)
+    y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
+
+    xd = nhwc(x).to(DEV)
+    wf = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(1, 2, 3, 0).contiguous().to(DEV)
+    gyd = nhwc(gy).to(DEV)
+    R = 8
+    outs = {}
+    for patch in (1, 0):                                                  # halo-patch kernel, then the generic tiled kernel
+        fn["ep24_conv_set_patch"](patch)
+        try:
+            y = torch.zeros(B, OH, OH, Cout, dtype=BF, device=DEV)
+            stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
+            call("conv_fwd_bf16", ptr(xd), Cin, ptr(wf), ptr(y), Cout, 0, 0, 0, None, ptr(stats), R, B, H, W, Cin, Cout, k, s, sp())
+            dx = torch.full((B, H, W, Cin), 7.0, dtype=BF, device=DEV)
+            if not (k == 1 and s == 2):
+                call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, k, s, sp())
+            base = rnd(B, H, W, Cin, seed=5).to(DEV)
+            dx2 = base.clone()
+            call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx2), Cin, 1, B, H, W, Cin, Cout, k, s, sp())
+            torch.cuda.synchronize()
+        finally:
+            fn["ep24_conv_set_patch"](1)
+        close(y.permute(0, 3, 1, 2), y_ref)
+        st = stats.sum(0).cpu().double().div(2 ** 20).float()
+        close(st[0], y_ref.sum((0, 2, 3)), rel=2e-3)
+        close(st[1], (y_ref * y_ref).sum((0, 2, 3)), rel=2e-3)
+        close(dx.permute(0, 3, 1, 2), dx_ref)
+        close(dx2.permute(0, 3, 1, 2), dx_ref + base.float().cpu().permute(0, 3, 1, 2))
+        outs[patch] = (y, dx)
+        if not (k == 3 and s == 1):
+            break                                                          # only the 3x3 stride-1 layers have two kernels
+    if len(outs) == 2:
+        # same products, same fp32 accumulation order per output element (channel chunks outer, taps inner): bit-equal
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+    splits = fn["ep24_conv_wgrad_splits"](B, H, W, Cin, Cout, k, s)
+    numel = Cout * k * k * Cin
+    slab = torch.full((splits * numel,), float("nan"), device=DEV)
+    g = torch.zeros(numel, device=DEV)
+    desc = torch.tensor([[0, numel, splits, 0]], dtype=torch.int64, device=DEV)
+    call("conv_wgrad_slab_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(slab), splits * numel, k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, sp())
+    call("wgrad_reduce", ptr(desc), 1, numel, ptr(g), ptr(slab), sp())
+    close(g.view(Cout, k, k, Cin).permute(0, 3, 1, 2), dw_ref, rel=5e-3)
+
+
+def test_conv_refuses_operands_beyond_2gib():
+    """32-bit tile addressing: an activation of 2 GiB or more is refused, not wrapped (pointers are never dereferenced)."""
+    call, ptr, sp = _abi()
+    from ep24 import _lib
+    t = torch.zeros(64, dtype=BF, device=DEV)
+    fn = _lib.lib().fn
+    rc = fn["ep24_conv_fwd_bf16"](ptr(t), 64, ptr(t), ptr(t), 64, 0, 0, 0, None, None, 1, 24, 1280, 1280, 64, 64, 3, 1, sp())
+    assert rc != 0 and "2 GiB" in _lib.lib().last_error()
+    rc = fn["ep24_conv_dgrad_bf16"](ptr(t), 64, ptr(t), ptr(t), 64, 0, 24, 1280, 1280, 64, 64, 3, 1, sp())
+    assert rc != 0 and "2 GiB" in _lib.lib().last_error()
+
+
 def test_conv_slices_fp32_out_bias_and_row_mapping():
     """1x1 predictor form: input is a channel slice of a wider buffer, output fp32 + bias into rows n*A + a0 + hw."""
     call, ptr, sp = _abi()
@@ -189,22 +282,6 @@ def test_bn_silu_fwd_bwd(M, C, res):
     close(dz, zr.grad, rel=2e-2)
     close(ggrad - 1, g_.grad, rel=5e-3)
     close(bgrad - 1, b_.grad, rel=5e-3)
-    # the one-launch form (grid barrier between the two passes) must agree with the two kernels
-    from ep24 import _lib
-    fn = _lib.lib().fn
-    assert fn["ep24_bn_act_bwd_fused_rows"](M, C) > 0
-    before = fn["ep24_debug_sync_timeouts"]()
-    sums2 = torch.zeros(2 * C + 2, dtype=torch.int64, device=DEV)
-    gg2, bg2 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
-    dz2 = torch.zeros(M, C, dtype=BF, device=DEV)
-    call("bn_act_bwd_fused", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums2), ptr(sums2, C), ptr(gg2), ptr(bg2),
-         ptr(dz2), C, M, C, 1, ptr(sums2, 2 * C), sp())
-    torch.cuda.synchronize()
-    assert fn["ep24_debug_sync_timeouts"]() == before
-    close(dz2, dz.float().cpu(), rel=1e-2)
-    close(gg2, ggrad.cpu(), rel=1e-5)
-    close(bg2, bgrad.cpu(), rel=1e-5)
-    assert int(sums2[2 * C]) == min(256, -(-M // (512 // (C // 8))))        # every workgroup arrived exactly once
 
 
 def test_spp_fwd_bwd():

@@ -1,0 +1,90 @@
+"""Data-parallel training step on the GPU box (BASELINE config 3's machinery on one card).
+
+The reference's only description of data parallelism is one process per GPU with NCCL DDP (yolox_24p/core/launch.py:82-124,
+core/trainer.py:163).  Here: ep24.dp.GradReducer next to the captured two-lane backward.  The box has ONE GPU, so
+  * two ranks share cuda:0 and reduce over gloo: identical batches -> losses bit-equal to the 1-rank run; a shard per
+    rank -> parameters bit-equal to a single process that sums the shard gradients itself;
+  * a one-rank RCCL group runs the nccl backend, the communication stream and the bucket cuts exactly as on 8 GPUs;
+  * `python bench.py --gpus 2` with no launcher starts its own ranks (the form the driver's scaling run may use).
+The ranks are child processes (tests/dp_worker.py); at most 3 processes touch the card at once."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def _run(cmd, env, timeout=600):
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-4000:]
+    return p.stdout
+
+
+@pytest.fixture(scope="module")
+def single(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dp") / "single.json")
+    _run([sys.executable, WORKER, "--mode", "single", "--out", out, "--sim-world", "2"], _env())
+    return json.load(open(out))
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(single, tmp_path):
+    out = str(tmp_path / "gloo.json")
+    _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+          "--master-port", str(_port()), WORKER, "--mode", "gloo", "--out", out], _env())
+    ranks = [json.load(open("%s.%d" % (out, r))) for r in range(2)]
+    for r in ranks:
+        assert r["world"] == 2 and r["buckets"] >= 3, r
+        # identical batches: sum of two equal gradients x 1/2 is exact -> same losses, same parameters as one rank
+        assert r["losses"] == single["losses"], (r["losses"], single["losses"])
+        assert r["crc_a"] == single["crc_a"]
+        # a shard per rank: equal to the single process that adds the two shard gradients itself
+        assert r["crc_b"] == single["crc_b"], (r["sum_b"], single["sum_b"])
+        # the backward list is cut where buckets complete, first cut 0, last cut = the whole list
+        assert r["cuts"][0] == 0 and r["cuts"][-1] == r["bwd_len"] and r["cuts"] == sorted(set(r["cuts"]))
+    assert ranks[0]["crc_b"] == ranks[1]["crc_b"]
+
+
+def test_one_rank_rccl_group_equals_plain_step(single, tmp_path):
+    out = str(tmp_path / "nccl.json")
+    _run([sys.executable, WORKER, "--mode", "nccl", "--out", out], _env(EP24_TEST_PORT=_port()))
+    r = json.load(open(out))
+    assert r["buckets"] >= 3 and len(r["cuts"]) >= 3
+    assert r["losses"] == single["losses"], (r["losses"], single["losses"])
+    assert r["crc_a"] == single["crc_a"]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment launches two ranks itself and prints one JSON line
+    (EP24_REHEARSE=1: both ranks on cuda:0 over gloo with the same batch, so the loss must equal the 1-rank loss)."""
+    env = _env(EP24_REHEARSE=1)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "4", "--size", "256", "--width", "0.25", "--depth", "0.33"]
+    two = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env, timeout=900)
+    line2 = [ln for ln in two.splitlines() if ln.startswith("{")]
+    assert len(line2) == 1, two[-3000:]
+    r2 = json.loads(line2[0])
+    one = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, _env(), timeout=900)
+    r1 = json.loads([ln for ln in one.splitlines() if ln.startswith("{")][0])
+    assert r2["n_gpus"] == 2 and r2["config"]["global_batch"] == 8 and r2["scaling"] == "weak"
+    assert r2["loss"] == r1["loss"], (r2["loss"], r1["loss"])
+    assert r2["value"] > 0 and "roofline" in r2
