@@ -15,7 +15,7 @@ namespace {
 
 // ep24_conv_set_patch(0) routes the 3x3 stride-1 layers through the generic tiled kernel again (A/B measurements, tests that
 // compare the two kernels on one shape); read once per launch, no environment lookups on the launch path
-int g_use_patch = 1;
+int g_use_patch = 1, g_narrow_epi = 0;
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
@@ -24,7 +24,7 @@ int g_use_patch = 1;
 // SOURCE address: LDS unit U = row*8 + pchunk is fetched from (row, pchunk ^ (row & 7)); padding taps and the
 // M / N / K tails use an out-of-range buffer offset, for which the DMA writes zeros.  Two LDS stages, one barrier per K-step: the DMA of tile t+1 is
 // in flight while tile t feeds the MFMAs.
-template <int BN, bool OUT_F32, int BNR = 0>
+template <int BN, bool OUT_F32, int EPI = 0>                // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -109,18 +109,10 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
 
-    // fused BN-reduce epilogue (BNR == 1): this lane's z values are fetched into registers one K-step before the end
-    // of the loop, so the epilogue finds them there instead of waiting for 8-byte loads at the exposed end of the tile
-    ZTile4 zt;
-    const bool zpre = BNR == 1 && !OUT_F32 && p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
-                      p.dbs == (long)p.GH * p.GW;
-    if (zpre && n_iter == 1) load_ztile<MT>(p, zt, m0, n0, wm, wn, lane);
-
     issue(0);
     for (int it = 0; it < n_iter; ++it) {
         __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
         if (it + 1 < n_iter) issue((it + 1) & 1);
-        if (zpre && it == n_iter - 2) load_ztile<MT>(p, zt, m0, n0, wm, wn, lane);
         const char* la = smem + (it & 1) * STAGE;
         const char* lb = la + A_BYTES;
 #pragma unroll
@@ -140,7 +132,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         }
     }
 
-    igemm_epilogue<BN, OUT_F32, MT, BNR>(p, acc, m0, n0, tile_m, smem, zpre ? &zt : nullptr);
+    igemm_epilogue<BN, OUT_F32, MT, EPI>(p, acc, m0, n0, tile_m, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -151,7 +143,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
 // A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
 // block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
 // registers until the end.  Waves of a workgroup share the rows (WN waves, 64 columns each) through L1.
-template <int BN, int H, int BNR = 0>                          // BNR: 0 plain, 1 fused BN-backward pass 1, 2 inference (bias, act, residual)
+template <int BN, int H, int EPI = 0>                          // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = 2, RG = WM * MT * 16;   // 32-row blocks per wave: ~170 VGPRs, 3 waves per SIMD
     constexpr int OOB = 0x7FFFFFF0;
@@ -206,22 +198,12 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     f32x4 acc[MT][4];
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int c0 = n0 + wn * 64 + 4 * frow;
-    constexpr bool bnr = BNR == 1;                          // fused pass 1 of the next BN backward (see igemm_epilogue)
-    constexpr bool infer = BNR == 2;                        // eval mode: y = act(acc + bias) + residual
+    constexpr bool infer = EPI == 2;                        // eval mode: y = act(acc + bias) + residual
     float ibias[4] = {0.f, 0.f, 0.f, 0.f};
     if (infer) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (c0 + q < p.N) ibias[q] = p.bias[c0 + q];
-    }
-    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bnr) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < p.N) {
-                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
-                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
-            }
     }
     auto zero_acc = [&]() {
 #pragma unroll
@@ -263,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
                     if (infer) {
                         v[q] = act_fwd(v[q] + ibias[q], p.epi_act);
                         if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
-                    } else if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
+                    } else { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
                 }
                 bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
                 if (c0 + 3 < p.N) {
@@ -276,29 +258,10 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
                     *reinterpret_cast<bf16x4*>(d) = w;
-                    if (bnr) {
-                        const bf16x4 zz = *reinterpret_cast<const bf16x4*>(p.bn_z + m * p.bn_ldz + c0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float zf = (float)zz[q];
-                            const float du = (float)w[q] * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                            s1[q] += du;
-                            s2[q] += du * (zf * biv[q] - bmi[q]);
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) {
-                            const bf16 w = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                            d[q] = w;
-                            if (bnr) {
-                                const float zf = (float)p.bn_z[m * p.bn_ldz + c0 + q];
-                                const float du = (float)w * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                                s1[q] += du;
-                                s2[q] += du * (zf * biv[q] - bmi[q]);
-                            }
-                        }
+                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
                 }
             }
         }
@@ -313,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         if (u + 1 < units) compute(A1, u + 1);
     }
 
-    if (p.stats || bnr) {
+    if (p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]; the weight tile is no longer needed
 #pragma unroll
@@ -327,17 +290,14 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
             }
         }
         __syncthreads();
-        long long* st = bnr ? nullptr : p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, c = i - which * BN;
             const int wcol = c >> 6;
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) {
-                long long* dst = bnr ? (which ? p.bn_sg : p.bn_sb) + n0 + c : st + (long)which * p.N + n0 + c;
-                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(v));
-            }
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
 }
@@ -354,7 +314,6 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     size_t lds = (size_t)npan * BN * 128;
     if (lds < 2048) lds = 2048;
     if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
-    else if (a.bn_z) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 1>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
     else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
 }
 
@@ -362,7 +321,6 @@ template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
     constexpr size_t lds = 2 * (BM * 128 + BN * 128);
     if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), lds, stream, a);
-    else if (a.bn_z && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 1>), dim3(tiles), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(tiles), dim3(256), lds, stream, a);
 }
 
@@ -379,6 +337,7 @@ int check_extents(const IgemmArgs& a) {
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     if (int rc = check_extents(a)) return rc;
+    a.narrow_epi = g_narrow_epi;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
@@ -415,8 +374,9 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
 }  // namespace
 
 extern "C" int ep24_conv_set_patch(int on) {
-    const int old = g_use_patch;
-    g_use_patch = on != 0;
+    const int old = g_use_patch | (g_narrow_epi << 1);
+    g_use_patch = on & 1;
+    g_narrow_epi = (on >> 1) & 1;
     return old;
 }
 
@@ -470,30 +430,9 @@ extern "C" int ep24_conv_fwd_infer_bf16(const void* x, int64_t ld_x, const void*
     return launch(a, false, (hipStream_t)stream);
 }
 
-namespace {
-struct BnReduce { const void* z; int64_t ld_z; const float* save; const float* gamma; const float* beta; int64_t* sg; int64_t* sb; int act; };
-int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin,
-               int Cout_k, int ksize, int stride, const BnReduce* bn, void* stream);
-}  // namespace
-
 extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
                                     int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
                                     void* stream) {
-    return dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, nullptr, stream);
-}
-
-extern "C" int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
-                                        int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
-                                        const void* z, int64_t ld_z, const float* save, const float* gamma, const float* beta,
-                                        int64_t* dgamma, int64_t* dbeta, int act, void* stream) {
-    EP24_REQUIRE(z && save && gamma && beta && dgamma && dbeta && ld_z % 4 == 0, EP24_E_ARG, "conv_dgrad_bnr: bad BN arguments");
-    const BnReduce bn{z, ld_z, save, gamma, beta, dgamma, dbeta, act};
-    return dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, &bn, stream);
-}
-
-namespace {
-int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin,
-               int Cout_k, int ksize, int stride, const BnReduce* bn, void* stream) {
     EP24_REQUIRE(dy && wt && dx, EP24_E_ARG, "conv_dgrad: null pointer");
     EP24_REQUIRE(Cout_k % 8 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 8", Cout_k);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
@@ -506,10 +445,6 @@ int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t 
     a.wt = (const bf16*)wt; a.WT = ksize * ksize; a.K = Cout_k; a.N = Cin;
     a.dst = dx; a.ld_dst = ld_dx; a.DH = H; a.DW = W; a.dbs = (long)H * W; a.dp0 = 0;
     a.accumulate = accumulate; a.bias = nullptr; a.stats = nullptr; a.stats_replicas = 1;
-    if (bn) {
-        a.bn_z = (const bf16*)bn->z; a.bn_ldz = bn->ld_z; a.bn_save = bn->save; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
-        a.bn_sg = (long long*)bn->sg; a.bn_sb = (long long*)bn->sb; a.bn_act = bn->act;
-    }
     if (stride == 1) {
         // dx[y,x] = sum_{kh,kw} dy[y + pad - kh, x + pad - kw] . w[:,kh,kw,:]
         a.GH = H; a.GW = W; a.sy = a.sx = 1;
@@ -543,4 +478,3 @@ int dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t 
         }
     return EP24_OK;
 }
-}  // namespace

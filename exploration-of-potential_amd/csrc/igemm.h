@@ -20,16 +20,13 @@ struct IgemmArgs {
     int accumulate;
     const float* bias;
     long long* stats; int stats_replicas;
-    // fused pass 1 of the NEXT BatchNorm backward (input gradient only): D is the complete gradient of a BN+act output
-    // whose pre-activation is bn_z; the epilogue adds sum(du) / sum(du*zhat) per channel to bn_sb / bn_sg
-    const bf16* bn_z; long bn_ldz; const float* bn_save; const float* bn_gamma; const float* bn_beta;
-    long long* bn_sg; long long* bn_sb; int bn_act;
     // inference epilogue (BatchNorm folded into weights and bias): y = act(acc + bias) + residual
     int epi_act; const bf16* epi_res; long epi_ldres; int epi_infer;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernels
     FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
     long M;
+    int narrow_epi;                 // A/B switch (ep24_conv_set_patch bit 1): the 8-byte-per-lane epilogue stores
 };
 
 constexpr int BM = 128;
@@ -46,15 +43,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Epilogue of the tiled kernels.  The workgroup has NWV waves laid out WM x WN over a (WM*MT*16) x (WN*64) tile; every
 // wave holds MT x 4 accumulator tiles of 16x16 with the output channels relabelled so that a lane owns 4 consecutive
 // channels of a pixel (8-byte packed bf16 stores).  Does: bias, BN batch statistics (2^-20 fixed-point int64 atomics, one
-// per channel per workgroup), bf16 / fp32 stores with optional accumulate, and for
-//   MODE 1: fused pass 1 of the next BatchNorm backward; the z values come from `zt` (the caller prefetched this
-//           lane's [MT][4 rows] x 4 channels while the main loop was still running, so nothing is exposed here),
-//   MODE 2: the inference form y = act(acc + bias) + residual.
-struct ZTile4 { bf16x4 v[4][4]; };      // [m-tile][row r] -> 4 channels; MT <= 4
-
+// per channel per workgroup), bf16 / fp32 stores with optional accumulate, and for MODE 2 the inference form
+// y = act(acc + bias) + residual.
 template <int BN, bool OUT_F32, int MT, int MODE = 0, int NWV = 4>
-__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem,
-                                               const ZTile4* zt = nullptr) {
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
     constexpr int WN = BN / 64, WM = NWV / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -67,19 +59,59 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             if (c0 + j < p.N) bias4[j] = p.bias[c0 + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr bool bnr = MODE == 1 && !OUT_F32;
     constexpr bool infer = MODE == 2 && !OUT_F32;
-    float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, biv[4] = {0.f, 0.f, 0.f, 0.f}, bmi[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bnr) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < p.N) {
-                const float mean = p.bn_save[c0 + q], inv = p.bn_save[p.N + c0 + q];
-                bsc[q] = p.bn_gamma[c0 + q] * inv; bsh[q] = p.bn_beta[c0 + q] - mean * bsc[q]; biv[q] = inv; bmi[q] = mean * inv;
-            }
-    }
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
                            p.dbs == (long)p.GH * p.GW);
+    // Wide-store path (bf16 output, no fused extras, 16-byte aligned rows): the wave's 64 x 64 tile is staged through LDS
+    // (free after the main loop) and leaves as 16-byte stores, 8 lanes per 128-byte row segment.  The direct form below
+    // stores 8 bytes per lane, 16 instructions per lane: measured with in-kernel stamps, that store tail was 10.7 k cycles
+    // per 256 x 128 tile (store-issue bound, ~7 B/clk/CU) - as long as five K steps of the main loop.
+    const bool wide = MODE == 0 && !OUT_F32 && !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 &&
+                      (reinterpret_cast<unsigned long long>(p.dst) & 15) == 0;
+    if (wide) {
+        __syncthreads();                                   // every wave is out of the main loop: LDS is free
+        char* stg = smem + wave * (MT * 16 * 128);         // [MT*16 rows][128 B], 16-byte chunk index XOR (row & 7)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + 4 * fq + r;
+                const bool live = m0 + wm * (MT * 16) + row < p.M;
+                bf16x4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = acc[i][q][r] + bias4[q];
+                    if (live) { s1[q] += v; s2[q] += v * v; }
+                    w[q] = (bf16)v;
+                }
+                *reinterpret_cast<bf16x4*>(stg + row * 128 + (((frow >> 1) ^ (row & 7)) << 4) + (frow & 1) * 8) = w;
+            }
+        }
+        // the same wave reads back what it wrote (LDS operations of a wave complete in order): no barrier
+        const int ch = lane & 7;
+        const int cc = n0 + wn * 64 + ch * 8;
+#pragma unroll
+        for (int k = 0; k < MT * 2; ++k) {
+            const int row = k * 8 + (lane >> 3);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const long m = m0 + wm * (MT * 16) + row;
+            if (m >= p.M || cc >= p.N) continue;
+            long dpix = m;
+            if (!fast_dst) {
+                int n = fdiv((int)m, p.d_plane);
+                int rem = (int)m - n * (p.GH * p.GW);
+                int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
+                dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+            }
+            bf16* d = reinterpret_cast<bf16*>(p.dst) + dpix * p.ld_dst + cc;
+            if (p.accumulate) {
+                const bf16x8 o = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
+            }
+            *reinterpret_cast<bf16x8*>(d) = v;
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -97,7 +129,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v[q] = acc[i][q][r] + bias4[q];
-                if (!bnr) { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
+                s1[q] += v[q]; s2[q] += v[q] * v[q];
             }
             if constexpr (OUT_F32) {
                 float* d = reinterpret_cast<float*>(p.dst) + dpix * p.ld_dst + c0;
@@ -125,34 +157,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
                     *reinterpret_cast<bf16x4*>(d) = w;
-                    if (bnr) {
-                        const bf16x4 zz = zt ? zt->v[i][r] : *reinterpret_cast<const bf16x4*>(p.bn_z + dpix * p.bn_ldz + c0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float zf = (float)zz[q];
-                            const float du = (float)w[q] * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                            s1[q] += du;                             // -> sum(du)
-                            s2[q] += du * (zf * biv[q] - bmi[q]);    // -> sum(du * zhat)
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) {
-                            const bf16 w = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                            d[q] = w;
-                            if (bnr) {
-                                const float zf = (float)p.bn_z[dpix * p.bn_ldz + c0 + q];
-                                const float du = (float)w * act_grad(zf * bsc[q] + bsh[q], p.bn_act);
-                                s1[q] += du;
-                                s2[q] += du * (zf * biv[q] - bmi[q]);
-                            }
-                        }
+                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
                 }
             }
         }
     }
-    if (p.stats || bnr) {
+    if (p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [NWV waves][2][64]
 #pragma unroll
@@ -166,36 +179,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             }
         }
         __syncthreads();
-        long long* st = bnr ? nullptr : p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
+        long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
         for (int i = tid; i < 2 * BN; i += NWV * 64) {
             const int which = i / BN, c = i - which * BN;
             const int wcol = c >> 6;
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-            if (n0 + c < p.N) {
-                long long* dst = bnr ? (which ? p.bn_sg : p.bn_sb) + n0 + c : st + (long)which * p.N + n0 + c;
-                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(v));
-            }
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
-}
-
-// Prefetch of the z values the fused BN-reduce epilogue needs (MODE 1), into registers: issued by the caller a few K
-// steps before the end of its main loop.  Plain-destination launches only (dst pixel == m).
-template <int MT>
-__device__ __forceinline__ void load_ztile(const IgemmArgs& p, ZTile4& zt, long m0, int n0, int wm, int wn, int lane) {
-    const int frow = lane & 15, fq = lane >> 4;
-    const int c0 = n0 + wn * 64 + 4 * frow;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * (MT * 16) + i * 16 + 4 * fq + r;
-            bf16x4 v = {0, 0, 0, 0};
-            if (m < p.M && c0 + 3 < p.N) v = *reinterpret_cast<const bf16x4*>(p.bn_z + m * p.bn_ldz + c0);
-            zt.v[i][r] = v;
-        }
 }
 
 // conv_patch.hip: 3x3 stride-1 layers (forward and input gradient).  Returns false when the shape does not fit its

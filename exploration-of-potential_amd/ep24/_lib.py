@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libep24.so")
+LIB_PATH = os.environ.get("EP24_LIB") or os.path.join(_HERE, "libep24.so")     # EP24_LIB: a diagnostic build (make stamps)
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "ep24.h"))
 
 _CTYPES = {

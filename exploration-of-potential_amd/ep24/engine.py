@@ -464,10 +464,6 @@ class Engine:
         self.fwd_eval = []                       # eval-mode forward (running-statistics BN, sigmoid head): SURVEY 8f N3
         self.bwd_writes = []                     # per backward launch: flat-gradient ranges it writes (for ep24.dp)
         self.bwd_gw, self.bwd_rd = [], []        # per backward launch: activation-gradient regions written / the one a BN reduce reads
-        # folding pass 1 of the BN backward into the epilogue of the dgrad that completes dy removes 101 of 122 reduce
-        # launches, but the exposed epilogue (z loads + SiLU' per element at the end of a one-round grid) costs more than
-        # the streaming kernel it replaces: +3.2 ms dgrad vs -2.8 ms reduce at YOLOX-l / B=20.  Experiment switch.
-        self.fuse_bn_reduce = os.environ.get("EP24_BNR") == "1"
         self._bwd_units = 0
         self._cur_tag = None
         self._force_side = False
@@ -610,9 +606,6 @@ class Engine:
         self._deferred = []
         self._flush_reduce()
         del _PENDING_GW[:]
-        self.bn_reduce_fused = 0
-        if self.fuse_bn_reduce:
-            self._fuse_reduce_into_dgrad()
         self.slab = torch.zeros(max(self._slab_floats, 4), dtype=torch.float32, device=self.dev)
         self.fold_w = torch.zeros(max(self._fold_w, 8), dtype=BF16, device=self.dev)
         self.fold_b = torch.zeros(max(self._fold_c, 4), dtype=torch.float32, device=self.dev)
@@ -636,37 +629,6 @@ class Engine:
             for name, args in lst:
                 out.append((name, tuple(a() if callable(a) else a for a in args)))   # Dyn stays for run time
         self.fwd, self.bwd, self.fwd_eval = fw, bw, fe
-
-    def _fuse_reduce_into_dgrad(self):
-        """Pass 1 of a layer's BN backward (the per-channel sums over dy) moves into the epilogue of the input-gradient
-        kernel that is the LAST writer of that dy, when that kernel writes exactly the layer's output gradient: it has
-        the final values in registers, so the separate reduce kernel and its read of dy disappear.  Everything else
-        (concat-wide dgrads, pooling / upsample / copy writers, network outputs) keeps the reduce kernel."""
-        drop = set()
-        for r, (name, a) in enumerate(self.bwd):
-            reg = self.bwd_rd[r]
-            if name != "bn_act_bwd_reduce" or reg is None:
-                continue
-            j, hit = r - 1, None
-            while j >= 0 and hit is None:
-                for g in self.bwd_gw[j]:
-                    if g[0] == reg[0] and g[1] < reg[2] and reg[1] < g[2]:
-                        hit = j
-                        break
-                j -= 1
-            if hit is None or hit in drop:
-                continue
-            dn, da = self.bwd[hit]
-            if dn != "conv_dgrad_bf16" or self.bwd_gw[hit] != [reg]:
-                continue
-            M, C = a[9], a[10]
-            if da[9] != C or da[6] * da[7] * da[8] != M:
-                continue
-            self.bwd[hit] = ("conv_dgrad_bnr_bf16", tuple(da) + (a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[11]))
-            drop.add(r)
-        self.bn_reduce_fused = len(drop)
-        for lst in ("bwd", "bwd_writes", "bwd_gw", "bwd_rd"):
-            setattr(self, lst, [v for i, v in enumerate(getattr(self, lst)) if i not in drop])
 
     def _add_builder(self, fn):
         fn.tag = self._cur_tag                    # which part of the network registered it (head level k / trunk)

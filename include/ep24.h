@@ -51,23 +51,16 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
                        int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
-/* The 3x3 stride-1 layers (forward and input gradient) run in the halo-patch kernel (csrc/conv_patch.hip); 0 routes them
- * through the generic tiled kernel instead (A/B timing, tests comparing the two on one shape).  Returns the previous value. */
+/* A/B switches for timing and for tests that compare two kernels on one shape (default 1).  Bit 0: the 3x3 stride-1 layers
+ * (forward and input gradient) run in the halo-patch kernel (csrc/conv_patch.hip) rather than the generic tiled kernel;
+ * bit 1: the tiled kernels store their output 8 bytes per lane instead of staging it for 16-byte stores.  Returns the
+ * previous value. */
 int ep24_conv_set_patch(int on);
 
 /* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 8 == 0 (zero padded).
  * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */
 int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
                          int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, void* stream);
-
-/* The same input gradient, and in its epilogue pass 1 of the BatchNorm backward of the layer that PRODUCED x: when dx
- * is the complete gradient of y = act(bn(z)) (this launch is its last writer), dbeta[c] += sum du and dgamma[c] += sum
- * du*zhat with du = dx * act'(bn(z)) are accumulated from the values just stored (2^-20 fixed point, as
- * ep24_bn_act_bwd_reduce), which saves that kernel's read of dx.  z [B*H*W, Cin] row stride ld_z; save = mean|invstd. */
-int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
-                             int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
-                             const void* z, int64_t ld_z, const float* save, const float* gamma, const float* beta,
-                             int64_t* dgamma, int64_t* dbeta, int act, void* stream);
 
 /* dw[co][t][ci] += sum_pixels dy[.,co] * x[.@t,ci]   fp32, row stride ld_dw between co rows (= taps*cin_valid
  * when dense), only co < cout_valid and ci < cin_valid are written.  Split over pixels with fp32 atomics.
@@ -122,6 +115,44 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 PARITY MODE of the conv graph (csrc/f32path.hip).  The reference trains in fp32 (train_24p.py:86-104: no AMP,
+ * network_blocks.py:50-51); ep24.engine.Engine(dtype=torch.float32) runs the same launch plan on fp32 activations through
+ * these entry points so that images -> SimOTA indices / loss / gradients can be compared with the CPU oracle at fp32
+ * accuracy (tests/test_gpu_fp32.py).  One thread per output element, reductions in double: not a fast path.
+ * All tensors NHWC fp32 with a row stride in elements; weights are read in place from the flat fp32 master:
+ * element (co, tap, ci) at w[co * w_co_stride + tap * w_tap_stride + ci].
+ * ------------------------------------------------------------------------------------------------ */
+int ep24_f32_stem_pack(const float* images, float* rows, int64_t ld, int B, int S, void* stream);            /* Focus + 3x3 im2col */
+/* transposed = 0: y = conv(x, w) (+ bias) with the row mapping of ep24_conv_fwd_bf16 (network_blocks.py:38-51);
+ * transposed = 1: x is dy [B,OH,OW,Cout], y is dx [B,H,W,Cin] (+)= the input gradient.  B,H,W,Cin,Cout,ksize,stride always
+ * describe the FORWARD convolution. */
+int ep24_f32_conv(const float* x, int64_t ld_x, const float* w, int64_t w_co_stride, int64_t w_tap_stride, float* y, int64_t ld_y,
+                  int64_t y_batch_rows, int64_t y_row0, const float* bias, int accumulate, int B, int H, int W, int Cin, int Cout,
+                  int ksize, int stride, int transposed, void* stream);
+int ep24_f32_conv_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, float* dw, int64_t w_co_stride,
+                        int64_t w_tap_stride, int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);   /* dw += */
+/* training-mode BatchNorm + activation (+ residual): batch statistics (two-pass, double) -> save[0]=mean, save[1]=invstd,
+ * running statistics, num_batches; then y = act(bn(z)) + residual. */
+int ep24_f32_bn_act_fwd(const float* z, int64_t ld_z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        int64_t* num_batches, float* save, float* y, int64_t ld_y, const float* residual, int64_t ld_res, int64_t M,
+                        int C, float eps, float momentum, int act, void* stream);
+/* both passes of its backward: sums [2C] double scratch; gamma_grad / beta_grad += ; dz written. */
+int ep24_f32_bn_act_bwd(const float* dy, int64_t ld_dy, const float* z, int64_t ld_z, const float* save, const float* gamma,
+                        const float* beta, double* sums, float* gamma_grad, float* beta_grad, float* dz, int64_t ld_dz, int64_t M,
+                        int C, int act, void* stream);
+int ep24_f32_spp_fwd(const float* x, int64_t ld_x, float* y5, float* y9, float* y13, int64_t ld_y, int32_t* idx, int B, int H, int W,
+                     int C, void* stream);                                        /* idx [3][B*H*W*C]: argmax pixel (y*W+x) */
+int ep24_f32_spp_bwd(const float* dy5, const float* dy9, const float* dy13, int64_t ld_dy, const int32_t* idx, float* dx,
+                     int64_t ld_dx, int accumulate, int B, int H, int W, int C, void* stream);
+int ep24_f32_upsample2_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, int B, int H, int W, int C, void* stream);
+int ep24_f32_upsample2_bwd(const float* dy, int64_t ld_dy, float* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int C,
+                           void* stream);
+int ep24_f32_rows_copy(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int accumulate, int64_t M, int C, void* stream);
+int ep24_f32_head_decode_bwd(const float* dout, const float* out, float* d_regobj, float* d_cls, int B, int A, int a0, int H, int W,
+                             float stride, int ncols, const float* d_origin, void* stream);   /* d_regobj [cells,32], d_cls [cells,ceil8(C)] */
+int ep24_f32_colsum(const float* g, int64_t ld, float* db, int64_t M, int N, void* stream);    /* db[c] += sum over rows */
 
 /* ------------------------------------------------------------------------------------------------
  * a1/a2  glue ops of the graph
