@@ -39,15 +39,16 @@ def _r8(n):
 class Buf:
     """Row-major [rows, ld] bf16 buffer with a lazily created gradient twin."""
 
-    def __init__(self, dev, rows, ld):
-        self.rows, self.ld = rows, ld
-        self.t = torch.zeros(rows * ld, dtype=BF16, device=dev)
+    def __init__(self, dev, rows, ld, dtype=BF16):
+        self.rows, self.ld, self.dtype = rows, ld, dtype
+        self.esize = 4 if dtype == torch.float32 else 2
+        self.t = torch.zeros(rows * ld, dtype=dtype, device=dev)
         self.g = None
         self.gwritten = []                       # channel intervals of the gradient already produced
 
     def grad(self):
         if self.g is None:
-            self.g = torch.zeros(self.rows * self.ld, dtype=BF16, device=self.t.device)
+            self.g = torch.zeros(self.rows * self.ld, dtype=self.dtype, device=self.t.device)
         return self.g
 
 
@@ -81,7 +82,7 @@ class Act:
         return self.buf.ld
 
     def ptr(self):
-        return self.buf.t.data_ptr() + 2 * self.c0
+        return self.buf.t.data_ptr() + self.buf.esize * self.c0
 
     def _groot(self):
         a = self
@@ -95,7 +96,7 @@ class Act:
 
     def gptr(self):
         r = self._groot()
-        return r.buf.grad().data_ptr() + 2 * r.c0
+        return r.buf.grad().data_ptr() + r.buf.esize * r.c0
 
     def slice(self, c0, C):
         assert self._alias is None
@@ -451,9 +452,15 @@ def param_home(model):
 
 # ------------------------------------------------------------------------------------------------ engine
 class Engine:
-    def __init__(self, model, batch, size):
+    def __init__(self, model, batch, size, dtype=BF16):
+        """``dtype=torch.float32`` is the PARITY MODE: the same plan (buffers, concat slots, residual aliasing, accumulate
+        flags, flat parameters) on fp32 activations through the ``ep24_f32_*`` entry points (csrc/f32path.hip) - what the
+        reference's fp32 training (train_24p.py:86-104) is compared with end to end; the product path is bf16."""
         _lib.require_gpu()
+        if dtype not in (BF16, torch.float32):
+            raise _lib.Ep24Error("ep24: activations are bfloat16 (product) or float32 (parity mode)")
         self.model, self.B, self.S = model, batch, size
+        self.dtype, self.f32 = dtype, dtype == torch.float32
         self.home = param_home(model)
         self.dev = self.home.dev
         self.C = getattr(getattr(model, "head", None), "num_classes", 0)
@@ -470,11 +477,11 @@ class Engine:
         self._deferred = []
         self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
         self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
-        self.parallel_head = os.environ.get("EP24_NO_PAR_HEAD") != "1"
+        self.parallel_head = os.environ.get("EP24_NO_PAR_HEAD") != "1" and not self.f32
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
         self._side = None
-        self.use_side = True                    # weight gradients on a second stream
+        self.use_side = not self.f32            # weight gradients on a second stream
         self.capture_side = os.environ.get("EP24_CAPTURE_SIDE") == "1"   # also inside captured graphs (experimental)
         self._events = []
         self._bwd_builders = []
@@ -490,7 +497,7 @@ class Engine:
 
     # ---- small helpers ----------------------------------------------------------------------------
     def new_act(self, C, H, W, ld=None):
-        return Act(Buf(self.dev, self.B * H * W, ld or C), 0, C, self.B, H, W)
+        return Act(Buf(self.dev, self.B * H * W, ld or C, self.dtype), 0, C, self.B, H, W)
 
     def _f(self, name, *args, ev=None):
         """Append a forward launch; `ev` = the (name, args) that replaces it in the eval-mode list (default: the same)."""
@@ -514,6 +521,8 @@ class Engine:
         F = S // 2
         self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
         swapped = isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG))
+        if swapped and self.f32:
+            raise NotImplementedError("ep24: the fp32 parity mode covers the CSPDarknet network (the BASELINE configuration)")
         c3, c4, c5 = (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels,
                                                        bb.dark5[0].conv.out_channels)
         H3, H4, H5 = S // 8, S // 16, S // 32
@@ -529,7 +538,7 @@ class Engine:
             # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
             rows = self.new_act(112, F, F)
             rows.needs_grad = False
-            self._f("stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
+            self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
             x = self.unit(bb.stem.conv, rows, stem=True)
             x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
             x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=cat_p3.slice(c3, c3))
@@ -623,7 +632,7 @@ class Engine:
                                torch.tensor(eps, dtype=torch.float32, device=self.dev), len(rows), pref[-1], cpref[-1])
         # every layer keeps its own dz (the gradient w.r.t. the raw conv output): the weight-gradient lane may lag the
         # main lane by a whole segment without a write-after-read hazard (3.4 GB at -l / B=20; there are 288)
-        self.dzbuf = torch.zeros(max(self._dz_elems, 8), dtype=BF16, device=self.dev)
+        self.dzbuf = torch.zeros(max(self._dz_elems, 8), dtype=self.dtype, device=self.dev)
         fw, bw, fe = [], [], []
         for lst, out in ((self.fwd, fw), (self.bwd, bw), (self.fwd_eval, fe)):
             for name, args in lst:
@@ -685,6 +694,8 @@ class Engine:
         wf = ptr(home.wf, seg.wf_off)              # stem: master row [108] zero padded to the im2col width
         res_p = residual.ptr() if residual is not None else None
         res_ld = residual.ld if residual is not None else 0
+        if self.f32:
+            return self._unit_f32(mod, conv, bn, seg, gam, bet, x, z, out, residual, res_p, res_ld, k_, s, act, save, sum_g)
         if self.fold_bn_eval:
             woff, coff = self._fold_w, self._fold_c
             self._fold_w += cout * seg.taps * seg.cin_pad
@@ -746,6 +757,41 @@ class Engine:
                 acc = x.gwrite()
                 self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
                                             seg.cout_pad, k_, s))
+
+        self._add_builder(build_bwd)
+        return out
+
+
+    def _unit_f32(self, mod, conv, bn, seg, gam, bet, x, z, out, residual, res_p, res_ld, k, s, act, save, sums):
+        """The unit in the fp32 parity mode: same buffers and gradient bookkeeping, weights read in place from the fp32
+        master ([Cout][T][Cin] = element (co, t, ci) at co*T*Cin + t*Cin + ci), everything on one lane."""
+        home = self.home
+        flat, gflat = home.flat, home.gflat
+        B, H, W = x.B, x.H, x.W
+        cin, cout, T = seg.cin, seg.cout, seg.taps     # stem: cin = 108 real columns of the 112-wide rows, one tap
+        M = out.M
+        wco, wt = T * cin, cin
+        w_p, gw_p = ptr(flat, seg.off), ptr(gflat, seg.off)
+        self._f("f32_conv", x.ptr(), x.ld, w_p, wco, wt, z.ptr(), z.ld, 0, 0, None, 0, B, H, W, cin, cout, k, s, 0, ev=False)
+        self._f("f32_bn_act_fwd", z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean), ptr(bn.running_var),
+                ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum),
+                act, ev=False)
+        if residual is not None:
+            residual.alias_grad(out)
+        self.unit_acts[mod if mod is not None else conv] = (x, z, out)
+
+        def build_bwd():
+            assert out.gready(), "activation without a gradient producer"
+            self._bwd_units += 1
+            dzoff = self._dz_elems
+            self._dz_elems += M * cout
+            dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 4 * dzoff)
+            self._b("f32_bn_act_bwd", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sums,
+                                       ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, act), writes=(gam, bet), reads=out)
+            self._b("f32_conv_wgrad", (x.ptr(), x.ld, dz, cout, gw_p, wco, wt, B, H, W, cin, cout, k, s), writes=(seg,))
+            if x.needs_grad:
+                acc = x.gwrite()
+                self._b("f32_conv", (dz, cout, w_p, wco, wt, x.gptr(), x.gld, 0, 0, None, acc, B, H, W, cin, cout, k, s, 1))
 
         self._add_builder(build_bwd)
         return out
@@ -1025,7 +1071,7 @@ class Engine:
             def build_copy():
                 assert x1._alias is not None and x1._groot().buf.gwritten
                 acc = raw.gwrite()
-                self._b("rows_copy", (x1.gptr(), x1.gld, raw.gptr(), raw.gld, acc, x1.M, h))
+                self._b("f32_rows_copy" if self.f32 else "rows_copy", (x1.gptr(), x1.gld, raw.gptr(), raw.gld, acc, x1.M, h))
 
             self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
@@ -1039,27 +1085,31 @@ class Engine:
         cat = self.new_act(4 * h, x.H, x.W)
         t = self.unit(mod.conv1, x, out=cat.slice(0, h))
         y5, y9, y13 = cat.slice(h, h), cat.slice(2 * h, h), cat.slice(3 * h, h)
-        idx = torch.zeros(3 * t.M * h, dtype=torch.uint8, device=self.dev)
-        scratch = torch.zeros(9 * t.M * h, dtype=torch.uint8, device=self.dev)
-        self._keep.append(scratch)
-        self._f("spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h, ptr(scratch))
+        idx = torch.zeros(3 * t.M * h, dtype=torch.int32 if self.f32 else torch.uint8, device=self.dev)
+        if self.f32:
+            self._f("f32_spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h, ev=False)
+        else:
+            scratch = torch.zeros(9 * t.M * h, dtype=torch.uint8, device=self.dev)
+            self._keep.append(scratch)
+            self._f("spp_fwd", t.ptr(), t.ld, y5.ptr(), y9.ptr(), y13.ptr(), cat.ld, ptr(idx), t.B, t.H, t.W, h, ptr(scratch))
 
         def build_bwd():
             assert y5.gready() and y9.gready() and y13.gready()
             acc = t.gwrite()
-            self._b("spp_bwd", (y5.gptr(), y9.gptr(), y13.gptr(), y5.gld, ptr(idx), t.gptr(), t.gld, acc,
-                                t.B, t.H, t.W, h))
+            self._b("f32_spp_bwd" if self.f32 else "spp_bwd", (y5.gptr(), y9.gptr(), y13.gptr(), y5.gld, ptr(idx), t.gptr(), t.gld, acc,
+                                                                t.B, t.H, t.W, h))
 
         self._add_builder(build_bwd)
         return self.unit(mod.conv2, cat)
 
     def up2(self, x, y):
-        self._f("upsample2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, x.B, x.H, x.W, x.C)
+        pre = "f32_" if self.f32 else ""
+        self._f(pre + "upsample2_fwd", x.ptr(), x.ld, y.ptr(), y.ld, x.B, x.H, x.W, x.C, ev=False if self.f32 else None)
 
         def build_bwd():
             assert y.gready()
             acc = x.gwrite()
-            self._b("upsample2_bwd", (y.gptr(), y.gld, x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
+            self._b(pre + "upsample2_bwd", (y.gptr(), y.gld, x.gptr(), x.gld, acc, x.B, x.H, x.W, x.C))
 
         self._add_builder(build_bwd)
 
@@ -1092,6 +1142,8 @@ class Engine:
         M = B * H * W
         out = self.outputs
         flat, gflat = home.flat, home.gflat
+        if self.f32:
+            return self._head_preds_f32(rf, cf, ro_seg, ro_b, cl_seg, cl_b, hch, M, a0, H, W, s)
         self._f("conv_fwd_bf16", rf.ptr(), rf.ld, ptr(home.wf, ro_seg.wf_off), ptr(out), self.ncols, 1, self.A, a0,
                 ptr(flat, ro_b.off), None, 1, B, H, W, hch, 27, 1, 1)
         self._f("conv_fwd_bf16", cf.ptr(), cf.ld, ptr(home.wf, cl_seg.wf_off), ptr(out, 27), self.ncols, 1, self.A, a0,
@@ -1135,6 +1187,32 @@ class Engine:
             self._b("conv_dgrad_bf16", (ptr(d_cl), ldc, ptr(home.wd, cl_seg.wd_off), cf.gptr(), cf.gld, cf.gwrite(), B, H,
                                         W, hch, ldc, 1, 1))
 
+        self._add_builder(build_bwd)
+
+    def _head_preds_f32(self, rf, cf, ro_seg, ro_b, cl_seg, cl_b, hch, M, a0, H, W, s):
+        """Prediction convs + decode of one level in the fp32 parity mode (weights / biases read in place from the master)."""
+        home, B, C, out = self.home, self.B, self.C, self.outputs
+        flat, gflat = home.flat, home.gflat
+        self._f("f32_conv", rf.ptr(), rf.ld, ptr(flat, ro_seg.off), hch, hch, ptr(out), self.ncols, self.A, a0, ptr(flat, ro_b.off), 0,
+                B, H, W, hch, 27, 1, 1, 0, ev=False)
+        self._f("f32_conv", cf.ptr(), cf.ld, ptr(flat, cl_seg.off), hch, hch, ptr(out, 27), self.ncols, self.A, a0, ptr(flat, cl_b.off), 0,
+                B, H, W, hch, C, 1, 1, 0, ev=False)
+        self._f("head_decode_fwd", ptr(out), B, self.A, a0, H, W, s, self.ncols, Dyn(self.dyn, "origin"), ev=False)
+        ldc = _r8(C)
+        d_ro = torch.zeros(M * 32, dtype=torch.float32, device=self.dev)
+        d_cl = torch.zeros(M * ldc, dtype=torch.float32, device=self.dev)
+
+        def build_bwd():
+            self._b("f32_head_decode_bwd", (Dyn(self.dyn, "dout"), ptr(out), ptr(d_ro), ptr(d_cl), B, self.A, a0, H, W, s, self.ncols,
+                                            Dyn(self.dyn, "d_origin")))
+            self._b("f32_colsum", (ptr(d_ro), 32, ptr(gflat, ro_b.off), M, 27), writes=(ro_b,))
+            self._b("f32_colsum", (ptr(d_cl), ldc, ptr(gflat, cl_b.off), M, C), writes=(cl_b,))
+            self._b("f32_conv_wgrad", (rf.ptr(), rf.ld, ptr(d_ro), 32, ptr(gflat, ro_seg.off), hch, hch, B, H, W, hch, 27, 1, 1), writes=(ro_seg,))
+            self._b("f32_conv_wgrad", (cf.ptr(), cf.ld, ptr(d_cl), ldc, ptr(gflat, cl_seg.off), hch, hch, B, H, W, hch, C, 1, 1), writes=(cl_seg,))
+            self._b("f32_conv", (ptr(d_ro), 32, ptr(flat, ro_seg.off), hch, hch, rf.gptr(), rf.gld, 0, 0, None, rf.gwrite(), B, H, W, hch, 27, 1, 1, 1))
+            self._b("f32_conv", (ptr(d_cl), ldc, ptr(flat, cl_seg.off), hch, hch, cf.gptr(), cf.gld, 0, 0, None, cf.gwrite(), B, H, W, hch, C, 1, 1, 1))
+
+        self._keep += [d_ro, d_cl]
         self._add_builder(build_bwd)
 
     # ---- execution ----------------------------------------------------------------------------------
@@ -1234,13 +1312,16 @@ class Engine:
         if not torch.cuda.is_current_stream_capturing():
             self.draw_dropout()                      # a captured step draws before it replays (ep24.train)
         self.zero_step_buffers()
-        self.home.pack()
+        if not self.f32:
+            self.home.pack()
         self._run(self.fwd)
         return self.outputs
 
     def forward_eval(self, images=None):
         """Eval-mode forward (BatchNorm with running statistics, sigmoid on obj / class): decoded [B,A,27+C] fp32, the
         tensor the reference's YOLOXHead returns with decode_in_inference (yolo_head_24p.py:190-210)."""
+        if self.f32:
+            raise NotImplementedError("ep24: the fp32 parity mode runs the training-mode plan only")
         if images is not None:
             self.images.copy_(images)
         self.home.pack()

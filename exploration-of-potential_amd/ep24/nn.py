@@ -402,13 +402,24 @@ class YOLOX(nn.Module):
         self.backbone = YOLOPAFPN() if backbone is None else backbone
         self.head = YOLOXHead(80) if head is None else head
         self._engines = {}
+        self.compute_dtype = torch.bfloat16
 
-    def engine(self, batch, size):
+    def set_compute_dtype(self, dtype):
+        """torch.bfloat16: the product path.  torch.float32: the fp32 parity mode of the same plan (the reference trains
+        in fp32, train_24p.py:86-104) - what end-to-end comparisons with the CPU oracle run; not a fast path."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise _lib.Ep24Error("ep24: compute dtype is torch.bfloat16 or torch.float32")
+        self.compute_dtype = dtype
+        return self
+
+    def engine(self, batch, size, dtype=None):
+        """The launch plan for [batch, 3, size, size] inputs; ``dtype=torch.float32`` selects the fp32 parity mode."""
         from .engine import Engine
-        key = (batch, size)
+        dtype = dtype or torch.bfloat16
+        key = (batch, size) if dtype == torch.bfloat16 else (batch, size, dtype)
         if key not in self._engines:
             # one parameter home (flat buffers) per model; plans for other input shapes share it
-            self._engines[key] = Engine(self, batch, size)
+            self._engines[key] = Engine(self, batch, size, dtype)
         return self._engines[key]
 
     def forward(self, x, train=False):
@@ -417,5 +428,5 @@ class YOLOX(nn.Module):
             raise _lib.Ep24Error("ep24: input images must live on the GPU (no CPU fallback on the product path)")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 32:
             raise IndexError("expected images [B,3,S,S] with S a multiple of 32, got %s" % (tuple(x.shape),))
-        eng = self.engine(x.shape[0], x.shape[2])
+        eng = self.engine(x.shape[0], x.shape[2], self.compute_dtype)
         return eng.run_module_forward(x, train)

@@ -86,7 +86,7 @@ def save(name, **arrs):
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("EP24_GOLDEN_OUT", HERE), name + ".npz")     # EP24_GOLDEN_OUT: regenerate elsewhere (drift test)
     np.savez_compressed(path, **out)
     print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
 
@@ -321,7 +321,7 @@ def gen_model(utils, models):
     store["after:stem_rv"] = model.state_dict()["backbone.backbone.stem.conv.bn.running_var"]
     model.eval()
     with torch.no_grad():
-        store["out_eval"] = model(x, train=False)[:, ::3]
+        store["out_eval"] = model(x, train=False)
     save("g7_model_tiny", **store)
 
     # -l: names / shapes / parameter count only
@@ -740,7 +740,23 @@ def gen_vgg(utils, models):
     save("g17_vgg", **store)
 
 
+def write_manifest():
+    """tests/golden/MANIFEST.json: shape, dtype and CRC-32 of every array of every committed fixture (tests/test_golden_manifest.py)."""
+    import json
+    import zlib
+    man = {}
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            z = np.load(os.path.join(HERE, f), allow_pickle=False)
+            man[f] = {k: [list(z[k].shape), str(z[k].dtype), zlib.crc32(np.ascontiguousarray(z[k]).tobytes())] for k in sorted(z.files)}
+    json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=0, sort_keys=True)
+    print("wrote MANIFEST.json: %d files, %d arrays" % (len(man), sum(len(v) for v in man.values())))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["--manifest"]:
+        write_manifest()
+        sys.exit(0)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet", "densenet", "vgg"]
     utils, models = load_reference()
