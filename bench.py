@@ -136,6 +136,12 @@ def instrumented_step(ts):
         M = B * H * W
         if k == 1 and s == 1 and not f32_out and (K <= 128 or (K <= 256 and M >= 100000)):
             return "igemm_stream_kernel"
+        N = Cout if name == "conv_fwd_bf16" else Cin
+        if k == 3 and s == 1 and N > 64 and -(-M // 256) * -(-N // 128) >= 200:
+            # csrc/conv_patch.hip launch_patch(): LDS = patch (x2 when K > 64) + three weight stages must fit 160 KB
+            pr = -(-(256 + 2 * (W + 1)) // 64) * 64
+            if (2 if K > 64 else 1) * pr * 128 + 3 * 128 * 128 <= 160 * 1024 and pr // 64 <= 21:
+                return "conv_patch_kernel"
         return "igemm_dma_kernel"
 
     convs = [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]

@@ -273,11 +273,11 @@ int rows_grid(long M, int C, int rows_per_thread, int max_blocks, int nt = 256) 
 // 8-byte pieces (the two columns of a 2x2 Focus patch) of consecutive pixels - contiguous image rows; the 12 values
 // of the item go to an LDS row image.  Phase 2: the 224-byte rows leave LDS as 16-byte chunks, consecutive lanes on
 // consecutive addresses.  (The one-chunk-per-thread form did 8 scattered 4-byte reads per lane: 0.44 ms at -l.)
-__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* rows, int B, int S, int ld) {
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* rows, int B, int IH, int IW, int ld) {
     constexpr int TP = 32;
     __shared__ __attribute__((aligned(16))) bf16 tile[TP][120];
-    const int F = S >> 1;
-    const long npix = (long)B * F * F;
+    const int FH = IH >> 1, FW = IW >> 1;
+    const long npix = (long)B * FH * FW;
     const int chunks = ld >> 3;
     for (long p0 = (long)blockIdx.x * TP; p0 < npix; p0 += (long)gridDim.x * TP) {
         for (int it = threadIdx.x; it < 9 * TP; it += 256) {
@@ -285,16 +285,16 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* img, bf16* 
             const long pix = p0 + lp;
             float v[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (pix < npix) {
-                const int n = (int)(pix / ((long)F * F));
-                const int rem = (int)(pix - (long)n * F * F);
-                const int oy = rem / F, ox = rem - oy * F;
+                const int n = (int)(pix / ((long)FH * FW));
+                const int rem = (int)(pix - (long)n * FH * FW);
+                const int oy = rem / FW, ox = rem - oy * FW;
                 const int fy = oy + tap / 3 - 1, fx = ox + tap % 3 - 1;
-                if (fy >= 0 && fy < F && fx >= 0 && fx < F) {
+                if (fy >= 0 && fy < FH && fx >= 0 && fx < FW) {
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
                         for (int yp = 0; yp < 2; ++yp) {
-                            const float2 t = *reinterpret_cast<const float2*>(img + (((long)n * 3 + ch) * S + 2 * fy + yp) * S + 2 * fx);
+                            const float2 t = *reinterpret_cast<const float2*>(img + (((long)n * 3 + ch) * IH + 2 * fy + yp) * IW + 2 * fx);
                             v[(0 * 2 + yp) * 3 + ch] = t.x;          // patch = (x parity) * 2 + (y parity): TL, BL, TR, BR
                             v[(1 * 2 + yp) * 3 + ch] = t.y;
                         }
@@ -898,11 +898,11 @@ extern "C" int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const vo
     return EP24_OK;
 }
 
-extern "C" int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int S, void* stream) {
-    EP24_REQUIRE(images && rows && S % 2 == 0 && B > 0 && ld >= 108 && ld % 8 == 0, EP24_E_ARG, "stem_pack: bad arguments");
-    long sp_blocks = ((long)B * (S / 2) * (S / 2) + 31) / 32;
+extern "C" int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int H, int W, void* stream) {
+    EP24_REQUIRE(images && rows && H % 2 == 0 && W % 2 == 0 && B > 0 && ld >= 108 && ld % 8 == 0, EP24_E_ARG, "stem_pack: bad arguments");
+    long sp_blocks = ((long)B * (H / 2) * (W / 2) + 31) / 32;
     hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)(sp_blocks > 16384 ? 16384 : sp_blocks)), dim3(256), 0, S_, images,
-                       (bf16*)rows, B, S, (int)ld);
+                       (bf16*)rows, B, H, W, (int)ld);
     EP24_LAUNCH_CHECK("ep24_stem_pack");
     return EP24_OK;
 }

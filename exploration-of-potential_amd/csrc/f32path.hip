@@ -25,21 +25,21 @@ __device__ __forceinline__ float act_grad_f32(float u, int act) {
 
 // Focus + 3x3 im2col of the stem (network_blocks.py:188-210 + the first conv): row = output pixel of the half-size map,
 // column = tap * 12 + (x parity * 2 + y parity) * 3 + channel, 108 real columns, the rest zero.
-__global__ void stem_pack_f32_kernel(const float* img, float* rows, long ld, int B, int S) {
-    const int F = S / 2;
-    const long total = (long)B * F * F * ld;
+__global__ void stem_pack_f32_kernel(const float* img, float* rows, long ld, int B, int IH, int IW) {
+    const int FH = IH / 2, FW = IW / 2;
+    const long total = (long)B * FH * FW * ld;
     for (long i = (long)blockIdx.x * NTH + threadIdx.x; i < total; i += (long)gridDim.x * NTH) {
         const int col = (int)(i % ld);
         const long pix = i / ld;
         float v = 0.f;
         if (col < 108) {
             const int tap = col / 12, j = col % 12, patch = j / 3, ch = j % 3;
-            const int n = (int)(pix / ((long)F * F));
-            const int rem = (int)(pix - (long)n * F * F);
-            const int oy = rem / F, ox = rem % F;
+            const int n = (int)(pix / ((long)FH * FW));
+            const int rem = (int)(pix - (long)n * FH * FW);
+            const int oy = rem / FW, ox = rem % FW;
             const int fy = oy + tap / 3 - 1, fx = ox + tap % 3 - 1;
-            if (fy >= 0 && fy < F && fx >= 0 && fx < F)
-                v = img[(((long)n * 3 + ch) * S + 2 * fy + (patch & 1)) * S + 2 * fx + (patch >> 1)];
+            if (fy >= 0 && fy < FH && fx >= 0 && fx < FW)
+                v = img[(((long)n * 3 + ch) * IH + 2 * fy + (patch & 1)) * IW + 2 * fx + (patch >> 1)];
         }
         rows[i] = v;
     }
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(NTH) void colsum_f32_kernel(const float* g, long ld
 #define S_ (hipStream_t) stream
 #define F32_LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(NTH), 0, S_, __VA_ARGS__)
 
-extern "C" int ep24_f32_stem_pack(const float* images, float* rows, int64_t ld, int B, int S, void* stream) {
-    EP24_REQUIRE(images && rows && S % 2 == 0 && B > 0 && ld >= 108, EP24_E_ARG, "f32_stem_pack: bad arguments");
-    F32_LAUNCH(stem_pack_f32_kernel, (long)B * (S / 2) * (S / 2) * ld, images, rows, ld, B, S);
+extern "C" int ep24_f32_stem_pack(const float* images, float* rows, int64_t ld, int B, int H, int W, void* stream) {
+    EP24_REQUIRE(images && rows && H % 2 == 0 && W % 2 == 0 && B > 0 && ld >= 108, EP24_E_ARG, "f32_stem_pack: bad arguments");
+    F32_LAUNCH(stem_pack_f32_kernel, (long)B * (H / 2) * (W / 2) * ld, images, rows, ld, B, H, W);
     EP24_LAUNCH_CHECK("ep24_f32_stem_pack");
     return EP24_OK;
 }

@@ -268,6 +268,10 @@ class ParamHome:
         self.pack_prefix = torch.tensor(pref, dtype=torch.int64, device=dev)
         self.pack_total = pref[-1]
         self.views = {}                                   # param -> (flat view, grad view, momentum view)
+        for sub in model.modules():                       # plans / homes of parts that ran on their own before are stale now
+            if sub is not model:
+                sub.__dict__.pop("_ep24_home", None)
+                sub.__dict__.pop("_ep24_sub", None)
         with torch.no_grad():
             for seg in self.order:
                 o = seg.off
@@ -284,6 +288,7 @@ class ParamHome:
                     vs[0].copy_(p.data)
                     p.data = vs[0]
                     p.grad = vs[1]
+                    p._ep24_home = self
                     self.views[p] = tuple(vs)
                     o += m
 
@@ -339,6 +344,21 @@ def csp_is_merged(m):
 def exec_order(model):
     """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
     any other container (tests build single blocks) falls back to registration order."""
+    def head_order(head):
+        for k in range(len(head.stems)):
+            yield head.stems[k]
+            if MERGE_HEAD:                            # the first 3x3 conv of the class and of the regression branch read the same tensor
+                yield ("pair_merged", head.cls_convs[k][0], head.reg_convs[k][0])
+                yield head.cls_convs[k][1]
+                yield head.reg_convs[k][1]
+            else:
+                yield from head.cls_convs[k]
+                yield from head.reg_convs[k]
+        yield head
+
+    if isinstance(model, enn.YOLOXHead):              # a head run on its own (YOLOXHead.forward)
+        yield from head_order(model)
+        return
     if not isinstance(model, enn.YOLOX):
         skip = set()
         for m in model.modules():
@@ -427,16 +447,7 @@ def exec_order(model):
     yield from csp(neck.C3_n3)
     yield neck.bu_conv1
     yield from csp(neck.C3_n4)
-    for k in range(len(head.stems)):
-        yield head.stems[k]
-        if MERGE_HEAD:                                # the first 3x3 conv of the class and of the regression branch read the same tensor
-            yield ("pair_merged", head.cls_convs[k][0], head.reg_convs[k][0])
-            yield head.cls_convs[k][1]
-            yield head.reg_convs[k][1]
-        else:
-            yield from head.cls_convs[k]
-            yield from head.reg_convs[k]
-    yield head
+    yield from head_order(head)
     if isinstance(bb, enn.ResNet):                     # fc / baseconv1..3: parameters the reference never runs (darknet.py:311-330)
         used = {id(p) for conv, bn in bb.used_units() for p in (conv.weight, bn.weight, bn.bias)}
         for p in bb.parameters():
@@ -445,8 +456,15 @@ def exec_order(model):
 
 
 def param_home(model):
+    """The flat parameter buffers a module lives in.  A module of a tree that has already been moved into flat buffers
+    (a YOLOPAFPN inside a YOLOX that has run) shares its owner's home; a module on its own gets one of its own."""
     if getattr(model, "_ep24_home", None) is None:
-        model._ep24_home = ParamHome(model)
+        ps = list(model.parameters())
+        owner = getattr(ps[0], "_ep24_home", None) if ps else None
+        if owner is not None and all(getattr(q, "_ep24_home", None) is owner for q in ps):
+            model._ep24_home = owner
+        else:
+            model._ep24_home = ParamHome(model)
     return model._ep24_home
 
 
@@ -459,7 +477,10 @@ class Engine:
         _lib.require_gpu()
         if dtype not in (BF16, torch.float32):
             raise _lib.Ep24Error("ep24: activations are bfloat16 (product) or float32 (parity mode)")
-        self.model, self.B, self.S = model, batch, size
+        self.IH, self.IW = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        if self.IH <= 0 or self.IW <= 0:
+            raise IndexError("ep24: empty input size %s" % (size,))
+        self.model, self.B, self.S = model, batch, self.IH     # S: the side of a square input (kept for callers that pass one)
         self.dtype, self.f32 = dtype, dtype == torch.float32
         self.home = param_home(model)
         self.dev = self.home.dev
@@ -516,34 +537,57 @@ class Engine:
 
     # ---- graph construction -------------------------------------------------------------------------
     def _build(self):
-        m, B, S = self.model, self.B, self.S
+        """The whole network: CSPDarknet (or a swapped backbone) -> PAFPN -> the three head levels
+        (yolox.py:24-34, yolo_pafpn.py:83-124, yolo_head_24p.py:143-210)."""
+        m, B = self.model, self.B
         bb, neck, head = m.backbone.backbone, m.backbone, m.head
-        F = S // 2
-        self.images = torch.zeros(B, 3, S, S, dtype=torch.float32, device=self.dev)
+        if self.IH % 32 or self.IW % 32:
+            raise IndexError("ep24: the input height and width must be multiples of 32 (three stride levels), got %dx%d" % (self.IH, self.IW))
+        self.images = torch.zeros(B, 3, self.IH, self.IW, dtype=torch.float32, device=self.dev)
+        x2, x1, x0 = self.build_neck_inputs(neck)
+        pans = self.build_neck(neck, x2, x1, x0)
+        self.build_head(head, pans)
+        self._finalize()
+
+    def neck_channels(self, bb):
         swapped = isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG))
         if swapped and self.f32:
             raise NotImplementedError("ep24: the fp32 parity mode covers the CSPDarknet network (the BASELINE configuration)")
-        c3, c4, c5 = (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels,
-                                                       bb.dark5[0].conv.out_channels)
-        H3, H4, H5 = S // 8, S // 16, S // 32
-        # concat buffers of the neck; producers write straight into their slot (yolo_pafpn.py:100-124)
-        cat_p4 = self.new_act(2 * c4, H4, H4)        # [up(fpn_out0) | dark4]
-        cat_p3 = self.new_act(2 * c3, H3, H3)        # [up(fpn_out1) | dark3]
-        cat_n3 = self.new_act(2 * c3, H4, H4)        # [bu_conv2(pan_out2) | fpn_out1]
-        cat_n4 = self.new_act(2 * c4, H5, H5)        # [bu_conv1(pan_out1) | fpn_out0]
-        if swapped:                                       # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
+        return (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels, bb.dark5[0].conv.out_channels)
+
+    def build_backbone(self, bb, out3=None, out4=None):
+        """images -> (dark3, dark4, dark5) (darknet.py:165-177); ``out3`` / ``out4``: concat slots of the neck to write into."""
+        B = self.B
+        if isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG)):      # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
             build = self.resnet if isinstance(bb, enn.ResNet) else self.vgg if isinstance(bb, enn.VGG) else self.densenet
-            x2, x1, x0 = build(bb, cat_p3.slice(c3, c3), cat_p4.slice(c4, c4))
-        else:
-            # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
-            rows = self.new_act(112, F, F)
-            rows.needs_grad = False
-            self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, S)
-            x = self.unit(bb.stem.conv, rows, stem=True)
-            x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
-            x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=cat_p3.slice(c3, c3))
-            x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=cat_p4.slice(c4, c4))
-            x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
+            return build(bb, out3, out4)
+        # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
+        rows = self.new_act(112, self.IH // 2, self.IW // 2)
+        rows.needs_grad = False
+        self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, self.IH, self.IW)
+        x = self.unit(bb.stem.conv, rows, stem=True)
+        x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
+        x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=out3)
+        x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=out4)
+        x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
+        return x2, x1, x0
+
+    def build_neck_inputs(self, neck, feats=None):
+        """Allocates the neck's concat buffers; the backbone (or, for a neck run on its own, nothing) fills dark3 / dark4 slots."""
+        c3, c4, c5 = self.neck_channels(neck.backbone)
+        H3, W3, H4, W4, H5, W5 = self.IH // 8, self.IW // 8, self.IH // 16, self.IW // 16, self.IH // 32, self.IW // 32
+        # concat buffers of the neck; producers write straight into their slot (yolo_pafpn.py:100-124)
+        self.cat_p4 = self.new_act(2 * c4, H4, W4)        # [up(fpn_out0) | dark4]
+        self.cat_p3 = self.new_act(2 * c3, H3, W3)        # [up(fpn_out1) | dark3]
+        self.cat_n3 = self.new_act(2 * c3, H4, W4)        # [bu_conv2(pan_out2) | fpn_out1]
+        self.cat_n4 = self.new_act(2 * c4, H5, W5)        # [bu_conv1(pan_out1) | fpn_out0]
+        self._nc = (c3, c4, c5)
+        return self.build_backbone(neck.backbone, self.cat_p3.slice(c3, c3), self.cat_p4.slice(c4, c4))
+
+    def build_neck(self, neck, x2, x1, x0):
+        """(dark3, dark4, dark5) -> (pan_out2, pan_out1, pan_out0) (yolo_pafpn.py:91-124); x2 / x1 already sit in their concat slots."""
+        c3, c4, c5 = self._nc
+        cat_p4, cat_p3, cat_n3, cat_n4 = self.cat_p4, self.cat_p3, self.cat_n3, self.cat_n4
         fpn_out0 = self.unit(neck.lateral_conv0, x0, out=cat_n4.slice(c4, c4))
         self.up2(fpn_out0, cat_p4.slice(0, c4))
         f_out0 = self.csp(neck.C3_p4, cat_p4)
@@ -556,13 +600,19 @@ class Engine:
         self.fwd_fork1 = len(self.fwd)                # pan_out1 is complete: head level 1 can start
         self.unit(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
         pan_out0 = self.csp(neck.C3_n4, cat_n4)
-        # head
-        self.A = H3 * H3 + H4 * H4 + H5 * H5
+        return pan_out2, pan_out1, pan_out0
+
+    def build_head(self, head, feats):
+        """Three feature maps -> outputs [B, A, 27 + C] fp32 and the anchor tables of the train-mode tuple (yolo_head_24p.py:143-237)."""
+        B = self.B
+        self.C = head.num_classes
+        self.ncols = 27 + self.C
+        self.A = sum(f.H * f.W for f in feats)
         self.outputs = torch.zeros(B, self.A, self.ncols, dtype=torch.float32, device=self.dev)
         a0 = 0
         self.levels = []
         self.fwd_head0 = None
-        for k, feat in enumerate((pan_out2, pan_out1, pan_out0)):
+        for k, feat in enumerate(feats):
             lo = len(self.fwd)
             self.head_level(head, k, feat, a0)
             if k == 0:
@@ -578,7 +628,6 @@ class Engine:
             self.x_shifts.append(xv.reshape(1, -1).float().to(self.dev))
             self.y_shifts.append(yv.reshape(1, -1).float().to(self.dev))
             self.exp_strides.append(torch.full((1, H * W), float(s), device=self.dev))
-        self._finalize()
 
     def _finalize(self):
         """Allocate the shared scratch, then build the backward list in reverse op order and resolve pointers."""
@@ -858,10 +907,10 @@ class Engine:
     def vgg(self, bb, out3, out4):
         """vgg19() (darknet.py:447-513): the first conv (3 -> 64 at full resolution) as im2col rows (27 -> 32 columns) x GEMM, then
         plain conv-BN-ReLU units and 2x2 max pools; dark3 / dark4 are the pooled outputs of stages 3 / 4, dark5 = conv_add."""
-        B, S = self.B, self.S
-        rows = self.new_act(32, S, S)
+        B, IH, IW = self.B, self.IH, self.IW
+        rows = self.new_act(32, IH, IW)
         rows.needs_grad = False
-        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 32, B, 3, S, S, 3, 1, 1)
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 32, B, 3, IH, IW, 3, 1, 1)
         x, feats = rows, []
         for si, stage in enumerate(bb.stages()):
             for m in stage:
@@ -887,10 +936,10 @@ class Engine:
     def resnet(self, bb, out3, out4):
         """The swapped backbone (darknet.py:389-416): stem conv 7x7/2 as im2col rows x GEMM, BN + ReLU, max pool, four
         stages; returns dark3 / dark4 / dark5 (layer2 / layer3 / layer4)."""
-        B, S = self.B, self.S
-        rows = self.new_act(152, S // 2, S // 2)             # 7*7*3 = 147 columns -> 152
+        B, IH, IW = self.B, self.IH, self.IW
+        rows = self.new_act(152, IH // 2, IW // 2)           # 7*7*3 = 147 columns -> 152
         rows.needs_grad = False
-        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, S, S, 7, 2, 3)
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, IH, IW, 7, 2, 3)
         x = self.unit(None, rows, stem=True, conv=bb.conv1, bn=bb.bn1, act=2)
         x = self.maxpool3s2(x)
         feats = []
@@ -1001,25 +1050,25 @@ class Engine:
         return cat
 
     def densenet(self, bb, out3, out4):
-        B, S = self.B, self.S
-        rows = self.new_act(152, S // 2, S // 2)
+        B, IH, IW = self.B, self.IH, self.IW
+        rows = self.new_act(152, IH // 2, IW // 2)
         rows.needs_grad = False
-        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, S, S, 7, 2, 3)
+        self._f("im2col_bf16", ptr(self.images), rows.ptr(), 152, B, 3, IH, IW, 7, 2, 3)
         x = self.unit(None, rows, stem=True, conv=bb.stem[0].conv, bn=bb.stem[0].bn, act=2)
         n_layers = sum(len(b.denseblock) for b in (bb.D1, bb.D2, bb.D3, bb.D4))
         self.drop_keep = torch.ones(n_layers, B, 32, dtype=torch.float32, device=self.dev)
         self.drop_p = 0.3
-        H = S // 4
+        H, W = IH // 4, IW // 4
         base, cat, feats = 0, None, []
         for bi, (blk, tr) in enumerate(((bb.D1, bb.T1), (bb.D2, bb.T2), (bb.D3, bb.T3), (bb.D4, None))):
             c0 = 64 if bi == 0 else cat.C // 2
-            ncat = self.new_act(c0 + 32 * len(blk.denseblock), H, H)
+            ncat = self.new_act(c0 + 32 * len(blk.denseblock), H, W)
             bstats = self._stats_slot(ncat.C)
             head = ncat.slice(0, c0)
             if bi == 0:
                 self.maxpool3s2(x, out=head)
             else:
-                t = self.new_act(c0, 2 * H, 2 * H)
+                t = self.new_act(c0, 2 * H, 2 * W)
                 self.conv_raw(tr_prev.trans[0].conv, self.pre_bn(tr_prev.trans[0].bn, cat, prev_stats, cat.C), t)
                 self.avgpool2(t, head)
             self._f("colstats", head.ptr(), head.ld, bstats, ncat.C, head.M, c0, ev=False)
@@ -1027,7 +1076,7 @@ class Engine:
             base += len(blk.denseblock)
             feats.append(cat)
             tr_prev, prev_stats = tr, bstats
-            H //= 2
+            H, W = H // 2, W // 2
         c3 = self.unit(None, feats[1], out=out3, conv=bb.baseconv1.conv, bn=bb.baseconv1.bn, act=2)
         c4 = self.unit(None, feats[2], out=out4, conv=bb.baseconv2.conv, bn=bb.baseconv2.bn, act=2)
         return c3, c4, feats[3]
@@ -1361,6 +1410,134 @@ class Engine:
                 origin_preds.append(origin[:, a0:a0 + H * W])
                 a0 += H * W
         return self.x_shifts, self.y_shifts, self.exp_strides, out, origin_preds
+
+
+# ------------------------------------------------------------------------------------------------ sub-plans
+def _to_act(act, x):
+    """NCHW tensor -> the Act's NHWC slot."""
+    v = act.buf.t.view(act.buf.rows, act.buf.ld)[:, act.c0:act.c0 + act.C]
+    v.copy_(x.permute(0, 2, 3, 1).reshape(-1, act.C))
+
+
+def _from_act(act, grad=False):
+    """The Act's (gradient's) NHWC slot -> NCHW fp32 tensor."""
+    if grad:
+        r = act._groot()
+        v = r.buf.grad().view(r.buf.rows, r.buf.ld)[:, r.c0:r.c0 + r.C]
+    else:
+        v = act.buf.t.view(act.buf.rows, act.buf.ld)[:, act.c0:act.c0 + act.C]
+    return v.reshape(act.B, act.H, act.W, act.C).permute(0, 3, 1, 2).float().contiguous()
+
+
+class SubEngine(Engine):
+    """Launch plan of ONE module of the tree run on its own - what ``BaseConv.forward`` / ``CSPLayer.forward`` /
+    ``CSPDarknet.forward`` / ``YOLOPAFPN.forward`` / ``YOLOXHead.forward`` of the reference compute
+    (network_blocks.py:50-51,179-185,139-144, darknet.py:165-177, yolo_pafpn.py:83-124, yolo_head_24p.py:143-210).
+    Same building blocks, buffers and kernels as the whole-network plan; inputs / outputs cross as NCHW fp32 tensors."""
+
+    IMAGE_KINDS = ("focus", "darknet", "pafpn")
+
+    def __init__(self, mod, kind, shapes, batch, dtype=BF16):
+        self.kind, self.shapes = kind, shapes                 # shapes: (C, H, W) of every input tensor
+        size = (shapes[0][1], shapes[0][2]) if kind in self.IMAGE_KINDS else (32, 32)
+        super().__init__(mod, batch, size, dtype)
+
+    def _build(self):
+        mod, kind, B = self.model, self.kind, self.B
+        self.inputs, self.outs = [], []
+        if kind in self.IMAGE_KINDS:
+            self.images = torch.zeros(B, 3, self.IH, self.IW, dtype=torch.float32, device=self.dev)
+        else:
+            for (C, H, W) in self.shapes:
+                self.inputs.append(self.new_act(C, H, W))
+        x = self.inputs[0] if self.inputs else None
+        home = self.home
+        if kind == "baseconv":
+            if len(home.by_param[mod.conv.weight].params) != 1:
+                raise NotImplementedError("ep24: this BaseConv runs as one merged unit with its sibling (conv1 / conv2 of a CSP layer, the "
+                                          "first convs of the head branches): call the enclosing module, or set EP24_NO_CSP_MERGE=1 EP24_NO_HEAD_MERGE=1")
+            self.outs = [self.unit(mod, x)]
+        elif kind == "focus":
+            rows = self.new_act(112, self.IH // 2, self.IW // 2)
+            rows.needs_grad = False
+            self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, self.IH, self.IW)
+            self.outs = [self.unit(mod.conv, rows, stem=True)]
+        elif kind == "bottleneck":
+            self.outs = [self.unit(mod.conv2, self.unit(mod.conv1, x), residual=x if mod.use_add else None)]
+        elif kind == "csp":
+            self.outs = [self.csp(mod, x)]
+        elif kind == "spp":
+            self.outs = [self.spp(mod, x)]
+        elif kind == "darknet":
+            self.outs = list(self.build_backbone(mod))
+        elif kind == "pafpn":
+            self.outs = list(self.build_neck(mod, *self.build_neck_inputs(mod)))
+        elif kind == "head":
+            self.build_head(mod, self.inputs)
+        else:
+            raise NotImplementedError(kind)
+        for o in self.outs:
+            o.gwrite()                                    # the caller is the consumer: it provides d(out)
+        self._finalize()
+
+    def load_inputs(self, tensors):
+        if self.kind in self.IMAGE_KINDS:
+            self.images.copy_(tensors[0])
+        else:
+            for a, x in zip(self.inputs, tensors):
+                _to_act(a, x)
+
+
+class _SubFn(torch.autograd.Function):
+    """A sub-plan as one autograd node (inputs: the module's input tensors, then its parameters)."""
+
+    @staticmethod
+    def forward(ctx, eng, n_in, *args):
+        ctx.eng, ctx.n_in = eng, n_in
+        eng.load_inputs(args[:n_in])
+        eng.forward()
+        if eng.kind == "head":
+            return (eng.outputs.clone(),)
+        return tuple(_from_act(o) for o in eng.outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        eng = ctx.eng
+        eng.home.bind_grads()
+        if eng.kind == "head":
+            eng.backward(grads[0].contiguous())
+        else:
+            for o, g in zip(eng.outs, grads):
+                r = o._groot()
+                v = r.buf.grad().view(r.buf.rows, r.buf.ld)[:, r.c0:r.c0 + r.C]
+                v.copy_(g.permute(0, 2, 3, 1).reshape(-1, o.C))
+            eng.backward(torch.zeros(1, device=eng.dev))
+        gin = tuple(_from_act(a, grad=True) for a in eng.inputs) if eng.kind not in SubEngine.IMAGE_KINDS else (None,)
+        return (None, None) + gin + (None,) * (len(ctx.needs_input_grad) - 2 - len(gin))
+
+
+def run_submodule(mod, kind, tensors, train=True):
+    """``forward`` of a module of the tree on its own.  tensors: NCHW tensors on the GPU.  Training mode (batch-statistics
+    BatchNorm, differentiable) unless ``mod.training`` is off, which runs the eval-mode list (running statistics, no grad)."""
+    _lib.require_gpu()
+    for x in tensors:
+        if not x.is_cuda or x.dim() != 4:
+            raise _lib.Ep24Error("ep24: %s.forward takes [B,C,H,W] tensors on the GPU (no CPU fallback on the product path)" % type(mod).__name__)
+    dtype = getattr(mod, "compute_dtype", BF16)
+    key = (kind, tuple(tuple(x.shape) for x in tensors), dtype)
+    cache = mod.__dict__.setdefault("_ep24_sub", {})
+    if key not in cache:
+        cache[key] = SubEngine(mod, kind, [tuple(x.shape[1:]) for x in tensors], int(tensors[0].shape[0]), dtype)
+    eng = cache[key]
+    if kind == "head":
+        use_l1 = bool(getattr(mod, "use_l1", False)) and train
+        eng.set_use_l1(use_l1)
+    if not mod.training or (kind == "head" and not train):
+        with torch.no_grad():
+            eng.load_inputs(tensors)
+            eng.forward_eval()
+            return (eng.outputs.clone(),) if kind == "head" else tuple(_from_act(o) for o in eng.outs)
+    return _SubFn.apply(eng, len(tensors), *tensors, *list(eng.home.views.keys()))
 
 
 class _NetFn(torch.autograd.Function):

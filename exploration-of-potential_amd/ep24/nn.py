@@ -19,6 +19,12 @@ def _no_eager(mod):
         "%s holds parameters only; run the network through YOLOX.forward (the HIP plan)" % type(mod).__name__)
 
 
+def _sub(mod, kind, *tensors, train=True):
+    """forward of one module of the tree on its own: a sub-plan of the same engine (ep24.engine.SubEngine)."""
+    from .engine import run_submodule
+    return run_submodule(mod, kind, tensors, train)
+
+
 class BaseConv(nn.Module):
     """conv (no bias) -> BatchNorm (eps 1e-3, momentum 0.03 as patched by Exp.get_model) -> SiLU."""
 
@@ -31,7 +37,8 @@ class BaseConv(nn.Module):
         self.act = nn.SiLU(inplace=True)
 
     def forward(self, x):
-        _no_eager(self)
+        """act(bn(conv(x))) (network_blocks.py:50-51); NCHW in / NCHW fp32 out."""
+        return _sub(self, "baseconv", x)[0]
 
 
 class Focus(nn.Module):
@@ -40,7 +47,8 @@ class Focus(nn.Module):
         self.conv = BaseConv(in_channels * 4, out_channels, ksize, stride, act=act)
 
     def forward(self, x):
-        _no_eager(self)
+        """space-to-depth + conv (network_blocks.py:199-210): images [B,3,H,W] -> [B,C,H/2,W/2]."""
+        return _sub(self, "focus", x)[0]
 
 
 class Bottleneck(nn.Module):
@@ -54,7 +62,7 @@ class Bottleneck(nn.Module):
         self.use_add = shortcut and in_channels == out_channels
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "bottleneck", x)[0]                   # network_blocks.py:91-95
 
 
 class CSPLayer(nn.Module):
@@ -67,7 +75,7 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "csp", x)[0]                          # network_blocks.py:179-185
 
 
 class SPPBottleneck(nn.Module):
@@ -81,7 +89,7 @@ class SPPBottleneck(nn.Module):
         self.conv2 = BaseConv(hidden * 4, out_channels, 1, 1, act=activation)
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "spp", x)[0]                          # network_blocks.py:139-144
 
 
 class CSPDarknet(nn.Module):
@@ -98,7 +106,10 @@ class CSPDarknet(nn.Module):
                                    CSPLayer(c * 16, c * 16, n=d, shortcut=False, act=act))
 
     def forward(self, x):
-        _no_eager(self)
+        """{"dark3", "dark4", "dark5"} feature maps of the images (darknet.py:165-177; out_features as constructed)."""
+        d3, d4, d5 = _sub(self, "darknet", x)
+        feats = {"dark3": d3, "dark4": d4, "dark5": d5}
+        return {k: v for k, v in feats.items() if k in self.out_features}
 
 
 class ResBottleneck(nn.Module):
@@ -357,7 +368,8 @@ class YOLOPAFPN(nn.Module):
         self.C3_n4 = CSPLayer(2 * c4, c5, n, False, act=act)
 
     def forward(self, x):
-        _no_eager(self)
+        """images -> (pan_out2, pan_out1, pan_out0), the tuple the head consumes (yolo_pafpn.py:83-124)."""
+        return tuple(_sub(self, "pafpn", x))
 
 
 class YOLOXHead(nn.Module):
@@ -389,7 +401,19 @@ class YOLOXHead(nn.Module):
                 conv.bias.fill_(v)
 
     def forward(self, xin, train=False):
-        _no_eager(self)
+        """xin: the three PAFPN outputs.  train=True: the 5-tuple (x_shifts, y_shifts, expanded_strides, outputs [B,A,27+C],
+        origin_preds) of yolo_head_24p.py:143-189,205-206; train=False: decoded predictions with sigmoid scores (:190-210)."""
+        from .engine import run_submodule
+        out = run_submodule(self, "head", tuple(xin), train)[0]
+        if not train:
+            return out
+        eng = self.__dict__["_ep24_sub"][("head", tuple(tuple(x.shape) for x in xin), getattr(self, "compute_dtype", torch.bfloat16))]
+        origin_preds, a0 = [], 0
+        if getattr(self, "use_l1", False):
+            for H, W, _ in eng.levels:
+                origin_preds.append(eng.origin[:, a0:a0 + H * W].clone())
+                a0 += H * W
+        return eng.x_shifts, eng.y_shifts, eng.exp_strides, out, origin_preds
 
 
 class YOLOX(nn.Module):
@@ -416,6 +440,8 @@ class YOLOX(nn.Module):
         """The launch plan for [batch, 3, size, size] inputs; ``dtype=torch.float32`` selects the fp32 parity mode."""
         from .engine import Engine
         dtype = dtype or torch.bfloat16
+        if not isinstance(size, int) and size[0] == size[1]:
+            size = int(size[0])
         key = (batch, size) if dtype == torch.bfloat16 else (batch, size, dtype)
         if key not in self._engines:
             # one parameter home (flat buffers) per model; plans for other input shapes share it
@@ -426,7 +452,7 @@ class YOLOX(nn.Module):
         _lib.require_gpu()
         if not x.is_cuda:
             raise _lib.Ep24Error("ep24: input images must live on the GPU (no CPU fallback on the product path)")
-        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 32:
-            raise IndexError("expected images [B,3,S,S] with S a multiple of 32, got %s" % (tuple(x.shape),))
-        eng = self.engine(x.shape[0], x.shape[2], self.compute_dtype)
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise IndexError("expected images [B,3,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+        eng = self.engine(x.shape[0], (x.shape[2], x.shape[3]), self.compute_dtype)
         return eng.run_module_forward(x, train)

@@ -20,9 +20,15 @@ NUM_RAYS = 24
 STRIDES = (8, 16, 32)
 
 
+def _hw(size):
+    return (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+
+
 def make_images(batch, size=640, seed=1):
+    """``size``: the side of a square input or (height, width)."""
     g = torch.Generator().manual_seed(seed)
-    return torch.rand(batch, 3, size, size, generator=g) * 255.0
+    h, w = _hw(size)
+    return torch.rand(batch, 3, h, w, generator=g) * 255.0
 
 
 def make_labels(batch, num_gt=10, size=640, seed=2, star=False, num_classes=80):
@@ -33,11 +39,12 @@ def make_labels(batch, num_gt=10, size=640, seed=2, star=False, num_classes=80):
     labels = torch.zeros(batch, MAX_LABELS, LABEL_COLS)
     ang = torch.arange(NUM_RAYS, dtype=torch.float64) * (15.0 * math.pi / 180.0)
     cosa, sina = torch.cos(ang), torch.sin(ang)
-    scale = size / 640.0
+    h, w = _hw(size)
+    scale = min(h, w) / 640.0
     for b, n in enumerate(counts):
         for i in range(n):
             cls = int(torch.randint(0, num_classes, (1,), generator=g))
-            cx, cy = (torch.rand(2, generator=g, dtype=torch.float64) * (size - 200.0) + 100.0).tolist()
+            cx, cy = (torch.rand(2, generator=g, dtype=torch.float64) * torch.tensor([w - 200.0, h - 200.0], dtype=torch.float64) + 100.0).tolist()
             r = (torch.rand(NUM_RAYS, generator=g, dtype=torch.float64) * 80.0 + 20.0) * scale
             if star:
                 # non-convex: every other ray pulled in to 35 % of its length
@@ -55,12 +62,12 @@ def anchor_grid(size=640, strides=STRIDES):
     """x_shift, y_shift, stride per anchor: level-major, row-major (y then x) inside a level
     (yolox_24p/models/yolo_head_24p.py:222-230)."""
     xs, ys, ss = [], [], []
+    h, w = _hw(size)
     for s in strides:
-        n = size // s
-        yv, xv = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+        yv, xv = torch.meshgrid(torch.arange(h // s), torch.arange(w // s), indexing="ij")
         xs.append(xv.reshape(-1).float())
         ys.append(yv.reshape(-1).float())
-        ss.append(torch.full((n * n,), float(s)))
+        ss.append(torch.full(((h // s) * (w // s),), float(s)))
     return torch.cat(xs), torch.cat(ys), torch.cat(ss)
 
 
@@ -91,8 +98,9 @@ def outputs_train_tuple(outputs, size=640):
     xs, ys, ss = anchor_grid(size)
     x_shifts, y_shifts, strides = [], [], []
     o = 0
+    h, w = _hw(size)
     for s in STRIDES:
-        n = (size // s) ** 2
+        n = (h // s) * (w // s)
         x_shifts.append(xs[o:o + n][None].to(outputs.device))
         y_shifts.append(ys[o:o + n][None].to(outputs.device))
         strides.append(ss[o:o + n][None].to(outputs.device))

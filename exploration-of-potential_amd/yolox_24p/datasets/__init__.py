@@ -20,7 +20,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
             return self._cache[idx]
         img = synth.make_images(1, self.size, seed=self.seed * 100003 + idx)[0]
         lab = synth.make_labels(1, self.num_gt, size=self.size, seed=self.seed * 100003 + 7919 + idx, num_classes=self.num_classes)[0]
-        self._cache[idx] = (img, lab, (self.size, self.size), idx)
+        hw = (self.size, self.size) if isinstance(self.size, int) else tuple(self.size)
+        self._cache[idx] = (img, lab, hw, idx)
         return self._cache[idx]
 
 

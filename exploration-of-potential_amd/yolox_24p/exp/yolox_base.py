@@ -63,13 +63,22 @@ class Exp(BaseExp):
         from datasets import SyntheticDataset
         import torch
         import os
-        self.dataset = SyntheticDataset(self.synthetic_len, self.input_size[0], self.synthetic_gts, self.num_classes)
+        self.dataset = SyntheticDataset(self.synthetic_len, tuple(self.input_size), self.synthetic_gts, self.num_classes)
         world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
         sampler = None
         if world > 1:                                     # every rank walks its own shard of the epoch
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
         return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True,
                                            sampler=sampler)
+
+    def random_resize(self, data_loader=None, epoch=None):
+        """A multiscale input size, multiple of 32, aspect ratio of input_size (exp/yolox_base.py:93-107); plans are cached per size."""
+        import random
+        size_factor = self.input_size[1] * 1.0 / self.input_size[0]
+        if not hasattr(self, "random_size"):
+            self.random_size = (int(self.input_size[0] / 32) - self.multiscale_range, int(self.input_size[0] / 32) + self.multiscale_range)
+        size = random.randint(*self.random_size)
+        return (int(32 * size), 32 * int(size * size_factor))
 
     def preprocess(self, inputs, targets, tsize):
         scale_y = tsize[0] / self.input_size[0]

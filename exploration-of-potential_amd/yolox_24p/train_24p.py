@@ -102,7 +102,7 @@ class Trainer:
         step_fn = None
         if not args.no_graph:
             step_fn = TrainStep(model, self.loss_func, lr=args.learn_rate, momentum=exp.momentum, batch=args.batch_size,
-                                size=self.input_size[0], reducer=reducer, ema=self.ema_model)
+                                size=tuple(self.input_size), reducer=reducer, ema=self.ema_model)
         print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "captured step" if step_fn else "eager API"))
         done = False
         self.epoch = self.start_epoch
@@ -135,7 +135,7 @@ class Trainer:
                     loss_all[0].backward()
                     if reducer is not None:
                         if reducer.flat is None:
-                            eng = model.engine(images.shape[0], images.shape[2])
+                            eng = model.engine(images.shape[0], (images.shape[2], images.shape[3]))
                             reducer.attach(eng.home, eng)
                         reducer.reduce_all()
                     self.optimizer.step(grad_scale=1.0 / self.world)

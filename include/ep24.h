@@ -124,7 +124,7 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
  * All tensors NHWC fp32 with a row stride in elements; weights are read in place from the flat fp32 master:
  * element (co, tap, ci) at w[co * w_co_stride + tap * w_tap_stride + ci].
  * ------------------------------------------------------------------------------------------------ */
-int ep24_f32_stem_pack(const float* images, float* rows, int64_t ld, int B, int S, void* stream);            /* Focus + 3x3 im2col */
+int ep24_f32_stem_pack(const float* images, float* rows, int64_t ld, int B, int H, int W, void* stream);            /* Focus + 3x3 im2col */
 /* transposed = 0: y = conv(x, w) (+ bias) with the row mapping of ep24_conv_fwd_bf16 (network_blocks.py:38-51);
  * transposed = 1: x is dy [B,OH,OW,Cout], y is dx [B,H,W,Cin] (+)= the input gradient.  B,H,W,Cin,Cout,ksize,stride always
  * describe the FORWARD convolution. */
@@ -159,7 +159,7 @@ int ep24_f32_colsum(const float* g, int64_t ld, float* db, int64_t M, int N, voi
  * ------------------------------------------------------------------------------------------------ */
 /* Focus + im2col for the 3x3 stem: images [B,3,S,S] fp32 NCHW -> rows [B*(S/2)^2][ld] bf16, columns
  * (kh,kw,c4) with c4 = TL,BL,TR,BR x 3 channels, 108 real + zero padding to ld (network_blocks.py:188-210). */
-int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int S, void* stream);
+int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int H, int W, void* stream);
 
 /* SPP max pools k = 5, 9, 13, stride 1, pad k/2 over x[B,H,W,C] (network_blocks.py:131-143).  Writes the
  * three pooled maps into y5/y9/y13 (row stride ld_y) and the winning window offset (dy*16+dx biased by 8)

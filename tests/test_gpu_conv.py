@@ -317,7 +317,7 @@ def test_upsample_stem_decode_sgd():
     img = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(53)) * 255
     rows = torch.zeros(2 * 8 * 8, 112, dtype=BF, device=DEV)
     imgd = img.to(DEV)
-    call("stem_pack", ptr(imgd), ptr(rows), 112, 2, S, sp())
+    call("stem_pack", ptr(imgd), ptr(rows), 112, 2, S, S, sp())
     foc = torch.cat([img[..., 0::2, 0::2], img[..., 1::2, 0::2], img[..., 0::2, 1::2], img[..., 1::2, 1::2]], 1)
     cols = F.unfold(foc, 3, padding=1).reshape(2, 12, 9, 64).permute(0, 3, 2, 1).reshape(-1, 108)   # (kh,kw) major, c minor
     assert torch.equal(rows[:, :108].float().cpu(), cols.to(BF).float())

@@ -43,7 +43,7 @@ def block_engine(mod, name, x):
                 self.images = x.to(self.dev).float().contiguous()
                 rows = self.new_act(112, H // 2, W // 2)
                 rows.needs_grad = False
-                self._f("stem_pack", self.images.data_ptr(), rows.ptr(), 112, B, H)
+                self._f("stem_pack", self.images.data_ptr(), rows.ptr(), 112, B, H, W)
                 self.xin, out = None, self.unit(mod.conv, rows, stem=True)
             else:
                 xin = self.new_act(C, H, W)

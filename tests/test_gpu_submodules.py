@@ -1,0 +1,145 @@
+"""The reference's module-level ``forward`` surface and non-square inputs (models.{YOLOPAFPN, YOLOXHead,
+CSPDarknet, BaseConv ...}; reference yolo_pafpn.py:83-124, yolo_head_24p.py:143-210, darknet.py:165-177,
+network_blocks.py:50-51,91-95,139-144,179-185; exp/yolox_base.py:22 input_size = (h, w), :93-107 random_resize).
+Every module runs as a sub-plan of the same engine; in the fp32 parity mode the results are compared with the CPU oracle
+at 1e-4, in bf16 with the golden block vectors and with the whole-network plan."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from ep24 import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+def _block(name):
+    from ep24 import nn as enn
+    return {"baseconv3": lambda: enn.BaseConv(16, 24, 3, 1), "baseconv3s2": lambda: enn.BaseConv(16, 32, 3, 2),
+            "baseconv1": lambda: enn.BaseConv(16, 8, 1, 1), "bottleneck": lambda: enn.Bottleneck(16, 16, True, 1.0),
+            "csp": lambda: enn.CSPLayer(16, 16, n=2), "csp_noshort": lambda: enn.CSPLayer(32, 16, n=1, shortcut=False),
+            "spp": lambda: enn.SPPBottleneck(16, 16), "focus": lambda: enn.Focus(3, 8, ksize=3)}[name]()
+
+
+@pytest.mark.parametrize("name", ["baseconv3", "baseconv3s2", "baseconv1", "bottleneck", "csp", "csp_noshort", "spp", "focus"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_forward_backward_vs_reference_golden(golden, name, dtype):
+    """module(x) and autograd through it, against the reference's own module run (G7 block vectors)."""
+    z = golden("g7_" + name)
+    mod = _block(name)
+    mod.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    mod.to(DEV)
+    mod.compute_dtype = dtype
+    x = t(z["x"]).to(DEV).requires_grad_(name != "focus")
+    y = mod(x)
+    tol = 2e-4 if dtype == torch.float32 else 2.5e-2
+    assert y.shape == z["y"].shape and rel_err(y, t(z["y"])) < tol, rel_err(y, t(z["y"]))
+    y.backward(t(z["gy"]).to(DEV))
+    if name != "focus" and not (name == "spp" and dtype == torch.bfloat16):     # bf16 ties reroute max-pool gradients
+        assert rel_err(x.grad, t(z["gx"])) < (1e-3 if dtype == torch.float32 else 4e-2), rel_err(x.grad, t(z["gx"]))
+    for k, p in mod.named_parameters():
+        want = t(z["g:" + k])
+        if name == "spp" and dtype == torch.bfloat16 and k.startswith("conv1"):
+            continue
+        assert rel_err(p.grad, want) < (2e-3 if dtype == torch.float32 else 5e-2), (k, rel_err(p.grad, want))
+
+
+def _paired(depth=0.33, width=0.25, seed=3):
+    from oracle import model as om
+    from ep24 import nn as enn
+    torch.manual_seed(seed)
+    ref = om.Net(depth, width)
+    m = enn.YOLOX(enn.YOLOPAFPN(depth, width), enn.YOLOXHead(80, width))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eps, mod.momentum = 1e-3, 0.03
+    m.load_state_dict(ref.state_dict(), strict=True)
+    return ref, m.to(DEV)
+
+
+def test_darknet_pafpn_head_forward_vs_oracle_fp32():
+    """CSPDarknet.forward -> dict, YOLOPAFPN.forward -> 3 maps, YOLOXHead.forward(train) -> the 5-tuple: each against the
+    oracle module with the same weights (fp32 mode, 1e-4), non-square input 256 x 320."""
+    ref, m = _paired()
+    for mod in (m, m.backbone, m.backbone.backbone, m.head):
+        mod.compute_dtype = torch.float32
+    x = synth.make_images(2, (256, 320), seed=4)
+    ref.train()
+    with torch.no_grad():
+        r_dark = ref.backbone.backbone(x)
+        r_pan = ref.backbone(x)
+        r_head = ref.head(r_pan, train=True)
+    xd = x.to(DEV)
+    dark = m.backbone.backbone(xd)
+    assert sorted(dark) == ["dark3", "dark4", "dark5"]
+    for got, want in zip((dark["dark3"], dark["dark4"], dark["dark5"]), r_dark):
+        assert got.shape == want.shape and rel_err(got, want) < 2e-4, rel_err(got, want)
+    pan = m.backbone(xd)
+    for got, want in zip(pan, r_pan):
+        assert got.shape == want.shape and rel_err(got, want) < 2e-4
+    xs, ys, ss, out, extra = m.head([p.to(DEV) for p in r_pan], train=True)
+    assert extra == [] and out.shape == r_head[3].shape == (2, 32 * 40 + 16 * 20 + 8 * 10, 107)
+    for a, b in zip(xs + ys + ss, r_head[0] + r_head[1] + r_head[2]):
+        assert torch.equal(a.cpu(), b)
+    torch.testing.assert_close(out.cpu(), r_head[3], rtol=2e-4, atol=2e-4)
+    # eval head: decoded boxes + sigmoid scores
+    m.head.eval(), ref.head.eval()
+    m.head.compute_dtype = torch.bfloat16                                   # the eval list exists for the product dtype only
+    with torch.no_grad():
+        e_ref = ref.head(r_pan, train=False)
+        e_got = m.head([p.to(DEV) for p in r_pan], train=False)
+    assert rel_err(e_got[..., 26:], e_ref[..., 26:]) < 3e-2                 # eval-mode list is the bf16-folded inference path
+
+
+def test_submodules_compose_to_the_whole_network_bf16():
+    """head(pafpn(x)) through the module-level forwards equals YOLOX.forward: same kernels on the same buffers' contents."""
+    _, m = _paired(width=0.25)
+    x = synth.make_images(2, (192, 256), seed=8).to(DEV)
+    with torch.no_grad():
+        whole = m(x, train=True)[3].clone()
+        parts = m.head(m.backbone(x), train=True)[3]
+    assert whole.shape == parts.shape == (2, 24 * 32 + 12 * 16 + 6 * 8, 107)
+    assert torch.equal(whole, parts)
+
+
+def test_rectangular_training_step_fp32_vs_oracle():
+    """(h, w) = (320, 448): whole step pieces in fp32 mode against the oracle - outputs, SimOTA indices, loss."""
+    from ep24 import loss as eloss
+    from oracle.loss import LossOracle
+    ref, m = _paired(width=0.25)
+    m.set_compute_dtype(torch.float32)
+    size = (320, 448)
+    images = synth.make_images(2, size, seed=5)
+    labels = synth.make_labels(2, [5, 8], size=size, seed=6)
+    ref.train()
+    o_in = ref(images, train=True)
+    ora = LossOracle(80)
+    o_tup = ora(o_in, labels)
+    lf = eloss.Loss_Function(80)
+    tup_in = m(images.to(DEV), train=True)
+    tup = lf(tup_in, labels.to(DEV))
+    torch.testing.assert_close(tup_in[3].detach().cpu(), o_in[3].detach(), rtol=2e-4, atol=1e-3)
+    for b in range(2):
+        cls_m, fg, ious, gt_idx, nfg = lf.assignment_of(labels, b)
+        o = ora.trace[b]
+        assert nfg == o[4] and torch.equal(fg.cpu(), o[1]) and torch.equal(gt_idx.cpu(), o[3])
+    assert abs(float(tup[0].detach()) - float(o_tup[0].detach())) <= 1e-4 * abs(float(o_tup[0].detach()))
+
+
+def test_rectangular_captured_step_bf16_runs_and_learns():
+    from ep24 import loss as eloss, train as etrain
+    _, m = _paired(width=0.25)
+    size = (256, 384)
+    ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.002, batch=2, size=size)
+    images = synth.make_images(2, size, seed=5).to(DEV)
+    labels = synth.make_labels(2, [4, 6], size=size, seed=6).to(DEV)
+    losses = []
+    for _ in range(12):
+        losses.append(float(ts.step(images, labels)[0]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
