@@ -311,11 +311,7 @@ def main():
         plain_step2 = ts.step
 
         def step_with_warp(*args):
-            warped = []
-            for im, mk, th in zip(src, msk, thetas):
-                winner, cw, box, T = dist_op._map(th, a.size, a.size, None)
-                warped.append(dist_op._warp(im, winner, cw, box, T, 114))
-                dist_op._warp(mk, winner, cw, box, T, 0)
+            warped, _masks, _boxes = dist_op.distort_batch(src, msk, thetas)      # the public batch form of sector_distort
             ein.preproc_batch(warped, (a.size, a.size), device=str(dev), out=ts.eng.images)
             return plain_step2(*args)
         ts.step = step_with_warp

@@ -88,10 +88,29 @@ class TrainTransform:
     """``TrainTransform(max_labels, flip_prob)`` of the reference (data_augment.py:131-174; the flip probability is
     stored and unused there as well).  ``__call__(image, targets, input_dim)`` handles one image, ``batch`` many."""
 
-    def __init__(self, max_labels=50, flip_prob=0.5, hsv_prob=1.0):
+    def __init__(self, max_labels=50, flip_prob=0.5, hsv_prob=1.0, fisheye=None, seed=0):
+        """``fisheye=(theta_lo, theta_hi)``: every image first goes through the sector warp (``Image_Distortion.sector_distort``,
+        yolox/demo_featuremap.py:244-328) with an angle drawn from that range, on the GPU, and the WARPED image is letterboxed -
+        the on-GPU fisheye augmentation of BASELINE config 5.  The reference has no label transform for the warp (it returns
+        the warped mask's bounding box only), so the label rows pass through unchanged: a stress configuration, as in the
+        reference's demo, not a training recipe."""
         self.max_labels, self.flip_prob = max_labels, flip_prob
+        self.fisheye = fisheye
+        self._rng = np.random.RandomState(seed)
+        self._dist = None
+
+    def warp(self, images, device="cuda:0"):
+        from .sector import Image_Distortion
+        if self._dist is None:
+            self._dist = Image_Distortion(device)
+        lo, hi = self.fisheye
+        thetas = [int(self._rng.randint(lo, hi + 1)) for _ in images]
+        dev_imgs = [torch.as_tensor(np.ascontiguousarray(im) if isinstance(im, np.ndarray) else im).to(device) for im in images]
+        return self._dist.distort_batch(dev_imgs, None, thetas)[0]
 
     def batch(self, images, targets, input_dim, out_images=None, out_labels=None):
+        if self.fisheye is not None:
+            images = self.warp(images)
         imgs, rs = preproc_batch(images, input_dim, out=out_images)
         labs = labels_batch(targets, [im.shape[:2] for im in images], rs, self.max_labels, out=out_labels)
         return imgs, labs

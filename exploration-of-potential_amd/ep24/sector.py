@@ -90,6 +90,26 @@ class Image_Distortion:
             call("sector_warp_u8", ptr(img), h, w, ptr(winner), cw, y0, x0, y1 - y0, x1 - x0, T, N_ANG, ptr(out), fill, stream_ptr())
         return out
 
+    def distort_batch(self, images, masks, thetas, custom_rows=None):
+        """``sector_distort`` for a batch, without a host synchronisation: images / masks are lists of HWC uint8 device tensors
+        (masks may be None), thetas one angle per image.  Returns (warped images, warped masks or None, boxes [n,4] int32 on
+        the device as (xmin, ymin, xmax, ymax) of the warped mask's non-zero pixels, xmax = -1 when the mask came out empty).
+        The winner map of a (Theta, rows) pair is built once and cached, so a training loop only runs the warp launches."""
+        _lib.require_gpu()
+        n = len(images)
+        outs, mouts = [], [] if masks is not None else None
+        boxes = torch.tensor([[2 ** 31 - 1, 2 ** 31 - 1, -1, -1]] * max(n, 1), dtype=torch.int32, device=self.device)
+        for i, (img, th) in enumerate(zip(images, thetas)):
+            if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_cuda:
+                raise IndexError("expected HWC uint8 images on the GPU")
+            winner, cw, box, T = self._map(th, img.shape[0], img.shape[1], custom_rows)
+            outs.append(self._warp(img.contiguous(), winner, cw, box, T, 114))
+            if masks is not None:
+                m = self._warp(masks[i].contiguous(), winner, cw, box, T, 0)
+                mouts.append(m)
+                call("mask_bbox", ptr(m), m.shape[0], m.shape[1], ptr(boxes, 4 * i), stream_ptr())
+        return outs, mouts, boxes[:n]
+
     def sector_distort(self, image, mask, Theta=60, custom_rows=None):
         _lib.require_gpu()
         as_numpy = isinstance(image, np.ndarray)
@@ -97,11 +117,7 @@ class Image_Distortion:
         msk = torch.as_tensor(mask).to(self.device).contiguous()
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise IndexError("expected HWC uint8 images")
-        winner, cw, box, T = self._map(Theta, img.shape[0], img.shape[1], custom_rows)
-        new_image = self._warp(img, winner, cw, box, T, 114)
-        new_mask = self._warp(msk, winner, cw, box, T, 0)
-        bb = torch.tensor([2 ** 31 - 1, 2 ** 31 - 1, -1, -1], dtype=torch.int32, device=self.device)
-        call("mask_bbox", ptr(new_mask), new_mask.shape[0], new_mask.shape[1], ptr(bb), stream_ptr())
-        xmin, ymin, xmax, ymax = bb.tolist()
+        (new_image,), (new_mask,), boxes = self.distort_batch([img], [msk], [Theta], custom_rows)
+        xmin, ymin, xmax, ymax = boxes[0].tolist()
         new_bbox = [xmin, ymin, xmax - xmin, ymax - ymin] if xmax >= 0 else []
         return (new_image.cpu().numpy() if as_numpy else new_image), new_bbox

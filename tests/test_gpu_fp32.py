@@ -74,8 +74,16 @@ def _paired(depth, width, seed=3):
     return ref, m.to(DEV).set_compute_dtype(torch.float32)
 
 
-@pytest.mark.parametrize("depth,width,B,S,gts", [(0.33, 0.5, 2, 640, [6, 3]), (0.33, 0.25, 3, 320, [4, 0, 9])])
-def test_images_to_assignment_loss_and_gradients_fp32(depth, width, B, S, gts):
+# (depth, width, B, S, GTs per image, tolerance scale).  The last case is BASELINE config 1 (YOLOX-l 24p forward + circle_inter
+# loss on 1x3x640x640 synthetic, the reference's CPU plumbing run) with the HIP path in the fp32 parity mode on the other side:
+# 131 conv layers with batch statistics over ONE image amplify fp32 rounding differences (torch's own fp32 conv vs a
+# double-accumulated one) about 30x more than the batch-2 half-width network, so its output tolerances are scaled; the
+# assignment indices and the 1e-4 loss bound are the same for every case.
+CASES = [(0.33, 0.5, 2, 640, [6, 3], 1.0), (0.33, 0.25, 3, 320, [4, 0, 9], 1.0), (1.0, 1.0, 1, 640, [5], 50.0)]
+
+
+@pytest.mark.parametrize("depth,width,B,S,gts,scale", CASES)
+def test_images_to_assignment_loss_and_gradients_fp32(depth, width, B, S, gts, scale):
     """The north-star parity sentence: identical synthetic inputs through the network, SimOTA and the 24-circle loss."""
     from ep24 import loss as eloss
     from oracle.loss import LossOracle
@@ -95,9 +103,16 @@ def test_images_to_assignment_loss_and_gradients_fp32(depth, width, B, S, gts):
     tup[0].backward()
     torch.cuda.synchronize()
     out, want = tup_in[3].detach().cpu(), o_in[3].detach()
-    torch.testing.assert_close(out[..., :2], want[..., :2], rtol=1e-4, atol=1e-3)            # centres (pixels)
-    torch.testing.assert_close(out[..., 2:26], want[..., 2:26], rtol=2e-4, atol=1e-4)        # radii = exp(t) * stride
-    torch.testing.assert_close(out[..., 26:], want[..., 26:], rtol=1e-4, atol=2e-4)          # logits
+    loss, oloss = float(tup[0].detach()), float(o_tup[0].detach())
+    rp = dict(ref.named_parameters())
+    gerr = {k: rel_err(p.grad, rp[k].grad) for k, p in m.named_parameters()}
+    worst = max(gerr, key=gerr.get)
+    print("centres max abs diff %.3g px, radii max rel %.3g, logits max abs %.3g, loss %.7g vs %.7g (rel %.3g), worst gradient %s %.3g"
+          % (float((out[..., :2] - want[..., :2]).abs().max()), float(((out[..., 2:26] - want[..., 2:26]).abs() / want[..., 2:26].abs()).max()),
+             float((out[..., 26:] - want[..., 26:]).abs().max()), loss, oloss, abs(loss - oloss) / abs(oloss), worst, gerr[worst]))
+    torch.testing.assert_close(out[..., :2], want[..., :2], rtol=1e-4 * scale, atol=1e-3 * scale)          # centres (pixels)
+    torch.testing.assert_close(out[..., 2:26], want[..., 2:26], rtol=2e-4 * scale, atol=1e-4 * scale)      # radii = exp(t) * stride
+    torch.testing.assert_close(out[..., 26:], want[..., 26:], rtol=1e-4 * scale, atol=2e-4 * scale)        # logits
     # SimOTA: foreground masks, matched ground truths and classes identical, image by image
     for b in range(B):
         o = ora.trace[b]
@@ -107,26 +122,20 @@ def test_images_to_assignment_loss_and_gradients_fp32(depth, width, B, S, gts):
             continue
         assert nfg == o[4], (b, nfg, o[4])
         assert torch.equal(fg.cpu(), o[1]) and torch.equal(gt_idx.cpu(), o[3]) and torch.equal(cls_m.cpu().long(), o[0].long())
-    # loss: total and the three groups within 1e-4 relative
-    assert abs(float(tup[0]) - float(o_tup[0])) <= 1e-4 * abs(float(o_tup[0])), (float(tup[0]), float(o_tup[0]))
-    torch.testing.assert_close(tup[1].detach().cpu(), o_tup[1].detach(), rtol=2e-4, atol=1e-6)
+    # loss: total within 1e-4 relative (north_star), the three groups within 2e-4
+    assert abs(loss - oloss) <= 1e-4 * abs(oloss), (loss, oloss)
+    torch.testing.assert_close(tup[1].detach().cpu(), o_tup[1].detach(), rtol=2e-4 * scale ** 0.5, atol=1e-6)
     for i in (2, 3):
-        assert abs(float(tup[i]) - float(o_tup[i])) <= 2e-4 * abs(float(o_tup[i])) + 1e-7
+        assert abs(float(tup[i].detach()) - float(o_tup[i].detach())) <= 2e-4 * scale ** 0.5 * abs(float(o_tup[i].detach())) + 1e-7
     # gradients of every parameter and the BatchNorm running statistics
-    rp = dict(ref.named_parameters())
-    worst = ("", 0.0)
-    for k, p in m.named_parameters():
-        e = rel_err(p.grad, rp[k].grad)
-        if e > worst[1]:
-            worst = (k, e)
-        assert e < 2e-3, (k, e)
+    for k, e in gerr.items():
+        assert e < 2e-3 * scale ** 0.5, (k, e)
     rsd = ref.state_dict()
     for k, v in m.state_dict().items():
         if "running_" in k:
             assert rel_err(v, rsd[k]) < 1e-4, k
         if "num_batches" in k:
             assert int(v) == int(rsd[k])
-    print("worst gradient rel err", worst)
 
 
 def test_fp32_mode_shares_parameters_with_the_bf16_plan():
