@@ -50,16 +50,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // v_exp_f32 + v_rcp_f32 (1 ulp each).  Written as a division the compiler emits the full IEEE sequence (div_scale,
 // rcp, 4 fma, div_fmas, div_fixup: ~10 instructions per element), which made the BN + SiLU kernels VALU-bound.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// activation of the BN+act blocks: act = 1 SiLU (the 24p network), 2 ReLU (the ResNet / DenseNet backbones of config 4),
-// 0 identity
+// activation of the BN+act blocks (get_activation, network_blocks.py:17-26): act = 1 SiLU (the 24p network), 2 ReLU (also the
+// ResNet / DenseNet backbones of config 4), 3 LeakyReLU(0.1), 0 identity
 __device__ __forceinline__ float act_fwd(float u, int act) {
     if (act == 1) return u * sigmoidf_(u);
+    if (act == 3) return u > 0.f ? u : 0.1f * u;
     return act == 2 ? fmaxf(u, 0.f) : u;
 }
 // d act(u) / du
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (!act) return 1.f;
     if (act == 2) return u > 0.f ? 1.f : 0.f;
+    if (act == 3) return u > 0.f ? 1.f : 0.1f;
     const float s = sigmoidf_(u);
     return s * fmaf(u, 1.f - s, 1.f);
 }

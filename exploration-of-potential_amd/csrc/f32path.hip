@@ -14,11 +14,13 @@ inline unsigned grid_for(long n) { long b = (n + NTH - 1) / NTH; return (unsigne
 
 __device__ __forceinline__ float act_fwd_f32(float u, int act) {
     if (act == 1) return u / (1.f + expf(-u));                // x * sigmoid(x), full-precision expf and division
+    if (act == 3) return u > 0.f ? u : 0.1f * u;
     return act == 2 ? fmaxf(u, 0.f) : u;
 }
 __device__ __forceinline__ float act_grad_f32(float u, int act) {
     if (!act) return 1.f;
     if (act == 2) return u > 0.f ? 1.f : 0.f;
+    if (act == 3) return u > 0.f ? 1.f : 0.1f;
     const float s = 1.f / (1.f + expf(-u));
     return s * (1.f + u * (1.f - s));
 }

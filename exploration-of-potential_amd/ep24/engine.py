@@ -714,10 +714,12 @@ class Engine:
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
-    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=1):
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
         name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none)."""
         home = self.home
+        if act is None:                            # a BaseConv carries its activation (silu / relu / lrelu); merged pairs: the first module's
+            act = getattr(mod, "act_code", 1)
         conv = mod.conv if conv is None else conv
         bn = mod.bn if bn is None else bn
         seg = home.by_param[conv.weight]
@@ -1105,7 +1107,7 @@ class Engine:
         _same_bn(mod.conv2.bn, mod.conv1.bn)
         P = self.new_act(3 * h, x.H, x.W)
         both = P.slice(h, 2 * h)
-        self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn)
+        self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn, act=mod.conv2.act_code)
         xa, za, ya = self.unit_acts.pop(mod.conv2.conv)
         self.unit_acts[mod.conv2] = (xa, za.slice(0, h), ya.slice(0, h))      # per-module views (tests walk unit_acts)
         self.unit_acts[mod.conv1] = (xa, za.slice(h, h), ya.slice(h, h))
@@ -1173,7 +1175,7 @@ class Engine:
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
             _same_bn(c0.bn, r0.bn)
-            both = self.unit(None, x, conv=c0.conv, bn=c0.bn)          # [class branch | regression branch], one GEMM (N = 2h)
+            both = self.unit(None, x, conv=c0.conv, bn=c0.bn, act=c0.act_code)   # [class branch | regression branch], one GEMM (N = 2h)
             xa, za, ya = self.unit_acts.pop(c0.conv)
             self.unit_acts[c0] = (xa, za.slice(0, hc), ya.slice(0, hc))
             self.unit_acts[r0] = (xa, za.slice(hc, hc), ya.slice(hc, hc))

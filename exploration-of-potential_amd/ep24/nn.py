@@ -14,6 +14,9 @@ import torch.nn as nn
 from . import _lib
 
 
+ACT_CODES = {"silu": 1, "relu": 2, "lrelu": 3}          # activation codes of the BN + act kernels (csrc/common.h act_fwd)
+
+
 def _no_eager(mod):
     raise NotImplementedError(
         "%s holds parameters only; run the network through YOLOX.forward (the HIP plan)" % type(mod).__name__)
@@ -30,11 +33,14 @@ class BaseConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
         super().__init__()
-        if groups != 1 or bias or act != "silu":
-            raise NotImplementedError("ep24 hot path: dense conv, no bias, SiLU (the yolox_24p -l configuration)")
+        if groups != 1 or bias:
+            raise NotImplementedError("ep24 hot path: dense conv without bias (DWConv / grouped convolutions are outside the 24p configuration)")
+        if act not in ACT_CODES:
+            raise AttributeError("Unsupported act type: {}".format(act))       # get_activation, network_blocks.py:17-26
         self.conv = nn.Conv2d(in_channels, out_channels, ksize, stride, (ksize - 1) // 2, bias=False)
         self.bn = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
-        self.act = nn.SiLU(inplace=True)
+        self.act = {"silu": nn.SiLU, "relu": nn.ReLU}[act](inplace=True) if act != "lrelu" else nn.LeakyReLU(0.1, inplace=True)
+        self.act_code = ACT_CODES[act]
 
     def forward(self, x):
         """act(bn(conv(x))) (network_blocks.py:50-51); NCHW in / NCHW fp32 out."""

@@ -143,3 +143,28 @@ def test_rectangular_captured_step_bf16_runs_and_learns():
     for _ in range(12):
         losses.append(float(ts.step(images, labels)[0]))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu", "silu"])
+def test_baseconv_activations_vs_torch(act):
+    """get_activation (network_blocks.py:17-26): silu / relu / lrelu(0.1) behind conv + BatchNorm, forward and autograd, fp32 mode."""
+    import torch.nn.functional as F
+    from ep24 import nn as enn
+    torch.manual_seed(1)
+    mod = enn.BaseConv(16, 24, 3, 1, act=act).to(DEV)
+    mod.compute_dtype = torch.float32
+    x = torch.randn(2, 16, 12, 12)
+    w, g, b = mod.conv.weight.detach().cpu().clone(), mod.bn.weight.detach().cpu().clone(), mod.bn.bias.detach().cpu().clone()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    u = F.batch_norm(F.conv2d(xr, wr, None, 1, 1), None, None, g, b, True, 0.03, 1e-3)
+    ref = {"relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1), "silu": F.silu}[act](u)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = mod(xd)
+    y.backward(gy.to(DEV))
+    assert rel_err(y, ref.detach()) < 2e-4
+    assert rel_err(xd.grad, xr.grad) < 1e-3 and rel_err(mod.conv.weight.grad, wr.grad) < 1e-3
+    with pytest.raises(AttributeError):
+        enn.BaseConv(8, 8, 1, 1, act="gelu")
