@@ -562,6 +562,21 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const bf16* src, long ld
     }
 }
 
+// fp32 <-> bf16 casts of a flat gradient bucket (the data-parallel reducer's bf16 wire format): n multiple of 4
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* src, bf16* dst, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+        reinterpret_cast<bf16x4*>(dst)[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* src, float* dst, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const bf16x4 v = reinterpret_cast<const bf16x4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- head decode
 __global__ __launch_bounds__(256) void decode_fwd_kernel(float* out, int B, int A, int a0, int H, int W, float s,
                                                          int ncols, float* origin) {
@@ -958,6 +973,20 @@ extern "C" int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_
     hipLaunchKernelGGL(rows_copy_kernel, dim3(cap_grid(M * (C / 8))), dim3(256), 0, S_, (const bf16*)src, ld_src, (bf16*)dst,
                        ld_dst, accumulate, M, C);
     EP24_LAUNCH_CHECK("ep24_rows_copy");
+    return EP24_OK;
+}
+
+extern "C" int ep24_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    EP24_REQUIRE(src && dst && n % 4 == 0 && n >= 0, EP24_E_ARG, "cast_f32_bf16: n must be a multiple of 4");
+    if (n) hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cap_grid(n / 4)), dim3(256), 0, S_, src, (bf16*)dst, (long)(n / 4));
+    EP24_LAUNCH_CHECK("ep24_cast_f32_bf16");
+    return EP24_OK;
+}
+
+extern "C" int ep24_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+    EP24_REQUIRE(src && dst && n % 4 == 0 && n >= 0, EP24_E_ARG, "cast_bf16_f32: n must be a multiple of 4");
+    if (n) hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cap_grid(n / 4)), dim3(256), 0, S_, (const bf16*)src, dst, (long)(n / 4));
+    EP24_LAUNCH_CHECK("ep24_cast_bf16_f32");
     return EP24_OK;
 }
 

@@ -178,6 +178,10 @@ int ep24_upsample2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, i
 
 /* hipMemsetAsync(p, 0, bytes) on the stream (step-start clearing of gradient / statistics buffers). */
 int ep24_memset_zero(void* p, int64_t bytes, void* stream);
+/* fp32 <-> bf16 casts of n (multiple of 4) contiguous elements: the bf16 wire format of the data-parallel gradient buckets
+ * (ep24.dp.GradReducer(comm_dtype=torch.bfloat16): half the xGMI bytes of the reference's fp32 DDP buckets, core/trainer.py:163). */
+int ep24_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int ep24_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 
 /* strided row copy / add:  dst[m, 0:C] (=|+=) src[m, 0:C]  (bf16). */
 int ep24_rows_copy(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int accumulate, int64_t M, int C,

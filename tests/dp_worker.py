@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--mode", required=True, choices=["single", "gloo", "nccl"])
     ap.add_argument("--out", required=True)
     ap.add_argument("--sim-world", type=int, default=2)
+    ap.add_argument("--bf16-wire", action="store_true", help="gradient buckets travel as bf16 (GradReducer comm_dtype)")
     a = ap.parse_args()
     from ep24 import dp
     dev = torch.device("cuda", 0)
@@ -68,7 +69,8 @@ def main():
                                 world_size=1, device_id=dev)
 
     def reducer():
-        return dp.GradReducer(bucket_bytes=256 << 10, first_bucket_bytes=64 << 10) if a.mode != "single" else None
+        return dp.GradReducer(bucket_bytes=256 << 10, first_bucket_bytes=64 << 10,
+                              comm_dtype=torch.bfloat16 if a.bf16_wire else None) if a.mode != "single" else None
 
     res = {"mode": a.mode, "rank": rank, "world": world}
     # ---- phase A: identical batches
