@@ -2,7 +2,7 @@
 # GPU box: the evidence kept under profiles/ for one round.  usage: tools/collect_profiles.sh TAG   (run through gpurun;
 # everything lands in gpurun_out/prof_TAG/, tools/summarize_profile.py turns it into the committed summaries)
 set -e
-TAG=${1:-rXX}
+TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -29,6 +29,13 @@ def main():
     out.append("")
     out.append("sum of all kernel time per step: %.1f ms" % (sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / steps))
     open(os.path.join(ROOT, "profiles", tag + "_summary.md"), "w").write("\n".join(out) + "\n")
+    import subprocess
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "exploration-of-potential_amd", "bench.py"], stdout=subprocess.PIPE, text=True).stdout.strip())
+    meta = {"tag": tag, "git_head": head + ("+local changes" if dirty else ""), "steps_in_profiled_process": steps,
+            "kernels": {short(r["Name"]): {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 3),
+                                           "ms_per_step": round(float(r["TotalDurationNs"]) / 1e6 / steps, 4)} for r in rows}}
+    json.dump(meta, open(os.path.join(ROOT, "profiles", tag + "_kernel_meta.json"), "w"), indent=1, sort_keys=True)
     if len(sys.argv) > 5:
         def agg(path):
             d = collections.defaultdict(lambda: [0, 0.0])
@@ -49,7 +56,19 @@ def main():
             fe = f[k][1] / n * 1024 * 2
             wr = w[k][1] / max(w[k][0], 1) * 1024 if k in w else 0.0
             res["kernels"][k] = {"launches": n, "fetch_bytes": round(fe), "write_bytes": round(wr), "traffic_bytes": round(fe + wr)}
+        res["git_head"] = meta["git_head"]
         json.dump(res, open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+        # the per-kernel HBM picture: PMC bytes per launch over the kernel's average duration in the graph-replayed run
+        st = {short(r["Name"]): r for r in rows}
+        tab = ["# HBM traffic per kernel (%s, %s): PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, eager pass) over the average duration" % (tag, meta["git_head"]),
+               "# of the same kernel in the graph-replayed run (rocprofv3 --kernel-trace --stats).  Peak HBM3E: 8 000 GB/s.", "",
+               "| kernel | launches | avg us | MB per launch | GB/s | % of 8 TB/s |", "|---|---|---|---|---|---|"]
+        for k, r in sorted(st.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
+            if k in res["kernels"]:
+                us = float(r["AverageNs"]) / 1e3
+                b = res["kernels"][k]["traffic_bytes"]
+                tab.append("| `%s` | %s | %.1f | %.2f | %.0f | %.0f |" % (k, r["Calls"], us, b / 1e6, b / us / 1e3, b / us / 1e3 / 80))
+        open(os.path.join(ROOT, "profiles", tag + "_hbm_table.md"), "w").write("\n".join(tab) + "\n")
 
 
 main()
