@@ -28,9 +28,6 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes; // extents for the buffer descriptors
     int c_n, c_oh, c_ow, c_pix; // byte strides of X per image / output row / output column / input pixel
     int s_dys, s_dxs, s_doff;   // what a 64-pixel step adds to (input row, input column, byte offset) before the wraps
-    int dbg_skip_epilogue;      // tools/conv_probe.py experiments only
-    int dbg_splits;
-    int dbg_noload;             // 1: dY loads dropped, 2: X loads (and their address decode) dropped
 };
 
 // Row keys of the 32-byte-block XOR permutation.  256-B rows (128 channels): one row per bank row, the 8 rows a
@@ -147,8 +144,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
     const int lo_y = p.pad - kh, lo_x = p.pad - kw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
     auto produce = [&](int slot) {
-        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W &&
-                        !(p.dbg_noload & 2);
+        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W;
         if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
         t_p += 64; t_ys += p.s_dys; t_xs += p.s_dxs; t_off += p.s_doff;
         if (t_xs >= wrap_x) { t_xs -= wrap_x; t_ys += p.stride; t_off += p.c_oh - p.OW * p.c_ow; }
@@ -167,7 +163,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         for (int j = 0; j < YI; ++j) {
             const bool ok = y_row[j] < rows_left && y_off[j] != OOB;
             int vo = ok ? y_off[j] + it * y_step : OOB;
-            if (p.dbg_noload & 1) vo = OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lptr_t)(stage + (wave * YI + j) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
@@ -240,13 +235,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     // D[row = co][col = ci]: row = 4*fq + r, col = lane & 15
     const int fr = lane & 15;
-    if (p.dbg_skip_epilogue) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
     // Epilogue: the accumulators go through LDS so that every atomic wave-instruction adds 64 CONSECUTIVE floats of
     // one dW row (256 contiguous bytes - the shape the memory-side atomic units take at full rate) instead of
     // four 64-byte pieces in four rows.
@@ -295,7 +283,6 @@ long wgrad_splits(const WgradArgs& a) {
     const long steps = (a.M + 63) / 64;
     long splits = slots / tiles;
     if (splits > steps / min_steps) splits = steps / min_steps;
-    if (a.dbg_splits > 0) splits = a.dbg_splits;
     if (splits < 1) splits = 1;
     return splits;                                          // trailing splits may be empty (they contribute zeros)
 }
@@ -308,7 +295,7 @@ void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     long splits = wgrad_splits<TCO, TCI>(a);
     a.chunk = ((steps + splits - 1) / splits) * 64;
     a.tiles = tiles;
-    a.xcd_remap = !getenv("EP24_DBG_WGRAD_NOREMAP");
+    a.xcd_remap = 1;
     dim3 grid((unsigned)(tiles * splits));
     hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
 }
@@ -336,9 +323,6 @@ int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t
       a.s_dys = doh * stride; a.s_dxs = dow * stride;
       a.s_doff = dn * a.c_n + doh * a.c_oh + dow * a.c_ow; }
     a.dy_bytes = (unsigned)(((a.M - 1) * ld_dy + Cout) * 2);
-    { const char* e = getenv("EP24_DBG_WGRAD_SKIP_EPI"); a.dbg_skip_epilogue = e && e[0] == '1';
-      const char* f = getenv("EP24_DBG_WGRAD_SPLITS"); a.dbg_splits = f ? atoi(f) : 0;
-      const char* h = getenv("EP24_DBG_WGRAD_NOLOAD"); a.dbg_noload = h ? atoi(h) : 0; }
     return EP24_OK;
 }
 
@@ -346,7 +330,6 @@ int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t
 void tile_choice(const WgradArgs& a, bool& co64, bool& ci64) {
     co64 = a.Cout <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
     ci64 = a.Cin <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
-    if (const char* g = getenv("EP24_DBG_WGRAD_TILE")) { co64 = g[0] == '6'; ci64 = g[1] == '6'; }
 }
 
 long splits_of(const WgradArgs& a) {

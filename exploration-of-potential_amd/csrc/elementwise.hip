@@ -859,8 +859,7 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
-    int fw_per = 2;
-    if (const char* e = getenv("EP24_DBG_BN_FWD")) sscanf(e, "%d", &fw_per);
+    const int fw_per = 2;                                   // chunks per lane and launch: tools/bn_probe.py sweeps of round 1
     auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : act == 3 ? bn_act_fwd_kernel<3> : bn_act_fwd_kernel<0>;
     hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
@@ -876,7 +875,6 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
     int red_cap = 256;                                      // one 512-thread block per CU: tools/bn_probe.py sweep
     int red_rows = 4;
-    if (const char* e = getenv("EP24_DBG_BN_RED")) sscanf(e, "%d,%d", &red_rows, &red_cap);
     auto kfn = act == 1 ? bn_act_bwd_reduce_kernel<4, 512, 1> : act == 2 ? bn_act_bwd_reduce_kernel<4, 512, 2> : act == 3 ? bn_act_bwd_reduce_kernel<4, 512, 3> : bn_act_bwd_reduce_kernel<4, 512, 0>;
     hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C);
@@ -891,7 +889,6 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
     int ap_rows = 16, ap_cap = 2048;
-    if (const char* e = getenv("EP24_DBG_BN_APPLY")) sscanf(e, "%d,%d", &ap_rows, &ap_cap);
     auto kfn = act == 1 ? bn_act_bwd_apply_kernel<4, 1> : act == 2 ? bn_act_bwd_apply_kernel<4, 2> : act == 3 ? bn_act_bwd_apply_kernel<4, 3> : bn_act_bwd_apply_kernel<4, 0>;
     hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,

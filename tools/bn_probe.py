@@ -61,28 +61,12 @@ def probe(M, C, kind, warm):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     passes = {"fwd": 2, "reduce": 2, "apply": 3}[kind]
-    return us, passes * bytes_t / us / 1e6
-
-
-def sweep():
-    """Grid sweeps through the EP24_DBG_BN_* knobs (rows per thread, block cap)."""
-    for M, C in [(64, 64), (32000, 256), (128000, 128), (512000, 64)]:
-        for kind, var, opts in (("fwd", "EP24_DBG_BN_FWD", ["1", "2", "4", "8", "16"]),
-                                ("reduce", "EP24_DBG_BN_RED", ["4,256", "4,512", "8,512", "16,512", "32,512", "16,256", "32,256"]),
-                                ("apply", "EP24_DBG_BN_APPLY", ["4,8192", "8,2048", "16,2048", "32,2048", "16,1024", "32,1024", "64,1024"])):
-            res = []
-            for o in opts:
-                os.environ[var] = o
-                res.append("%s:%.1f" % (o, probe(M, C, kind, False)[0]))
-            os.environ.pop(var)
-            print("%-14s %-7s %s" % ("%d,%d" % (M, C), kind, "  ".join(res)), flush=True)
+    return us, passes * bytes_t / us / 1e3
 
 
 def main():
-    if sys.argv[1:] == ["sweep"]:
-        return sweep()
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or SHAPES
-    print("%-16s %-7s %10s %10s   %10s %10s" % ("M,C", "kernel", "cold us", "GB/s", "warm us", "GB/s"))
+    print("%-16s %-7s %10s %10s   %10s %10s" % ("M,C", "kernel", "cold us", "GB/s", "warm us", "GB/s"))   # GB/s of algorithmic bytes
     for M, C in shapes:
         for kind in ("fwd", "reduce", "apply"):
             c = probe(M, C, kind, False)
