@@ -29,6 +29,12 @@ __device__ int count_gt(const float* lab /*[50][51]*/, float* scratch /*[64]*/) 
     return n;
 }
 
+#ifdef EP24_STAMPS
+// diagnostic build only (make stamps; tools/step_stress.py reads it): [0..3] how often each of four evaluations of the same
+// angle sum disagreed with the other three, [7] no majority, [8] threads, [9] disagreeing lanes outside 48..63
+__device__ unsigned long long g_cand_dbg[16];
+#endif
+
 // ------------------------------------------------------------------------------------------ a4 + a5
 __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, const float* xs, const float* ys,
                                                          const float* strides, int* num_gt, unsigned long long* in_box,
@@ -52,6 +58,9 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, co
     const float yc = ys[a] * s + 0.5f * s;
     const float rad = 2.5f * s;
     unsigned long long mb = 0ull, mc = 0ull;
+#ifdef EP24_STAMPS
+    float degA[16];
+#endif
     for (int g = 0; g < ng; ++g) {
         // pts_in_poly (losses.py:555-592): unsigned angle of every edge seen from the anchor centre, degrees
         float deg = 0.f;
@@ -65,6 +74,9 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, co
             sx = ex; sy = ey;
         }
         if (deg >= 350.f) mb |= 1ull << g;
+#ifdef EP24_STAMPS
+        if (g < 16) degA[g] = deg;
+#endif
         // centre square (losses.py:523-543): min of the four deltas strictly positive
         const float cl = xc - (gcx[g] - rad), cr = (gcx[g] + rad) - xc;
         const float ct = yc - (gcy[g] - rad), cb = (gcy[g] + rad) - yc;
@@ -72,6 +84,65 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, co
     }
     in_box[(long)b * A + a] = mb;
     in_ctr[(long)b * A + a] = mc;
+#ifdef EP24_STAMPS
+    // diagnostic build: the same polygon angle sum computed four ways; the pass that disagrees with the other three is counted
+    auto term = [&](float sx, float sy, float ex, float ey) {
+        const float cross = sx * ey - ex * sy;
+        const float dot = sx * ex + sy * ey;
+        return atan2f(fabsf(cross), dot) * 57.2957795130823208768f;
+    };
+    auto lds_nop = [&](const float* p) {             // LDS read, then a generous pause before the value may be used
+        float v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
+        return v;
+    };
+    for (int g = 0; g < ng && g < 16; ++g) {
+        float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        {   // pass 1: LDS through lds_nop
+            float sx = lds_nop(&vx[g][0]) - xc, sy = lds_nop(&vy[g][0]) - yc;
+            for (int k = 0; k < 24; ++k) {
+                const int k1 = k == 23 ? 0 : k + 1;
+                const float ex = lds_nop(&vx[g][k1]) - xc, ey = lds_nop(&vy[g][k1]) - yc;
+                d1 += term(sx, sy, ex, ey);
+                sx = ex; sy = ey;
+            }
+        }
+        {   // pass 2: the whole polygon in registers first, then arithmetic only
+            float px[24], py[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) { px[k] = lds_nop(&vx[g][k]); py[k] = lds_nop(&vy[g][k]); }
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            float sx = px[0] - xc, sy = py[0] - yc;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const int k1 = k == 23 ? 0 : k + 1;
+                const float ex = px[k1] - xc, ey = py[k1] - yc;
+                d2 += term(sx, sy, ex, ey);
+                sx = ex; sy = ey;
+            }
+        }
+        {   // pass 3: global memory
+            float sx = lab[g * LCOLS + 3] - xc, sy = lab[g * LCOLS + 4] - yc;
+            for (int k = 0; k < 24; ++k) {
+                const int k1 = k == 23 ? 0 : k + 1;
+                const float ex = lab[g * LCOLS + 3 + 2 * k1] - xc, ey = lab[g * LCOLS + 4 + 2 * k1] - yc;
+                d3 += term(sx, sy, ex, ey);
+                sx = ex; sy = ey;
+            }
+        }
+        const unsigned u0 = __float_as_uint(degA[g]), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2), u3 = __float_as_uint(d3);
+        if (u0 != u1 || u0 != u2 || u0 != u3) {
+            int which = 7;                                                    // no majority
+            if (u1 == u2 && u2 == u3) which = 0;
+            else if (u0 == u2 && u2 == u3) which = 1;
+            else if (u0 == u1 && u1 == u3) which = 2;
+            else if (u0 == u1 && u1 == u2) which = 3;
+            atomicAdd(&g_cand_dbg[which], 1ull);
+            if ((threadIdx.x & 63) < 48) atomicAdd(&g_cand_dbg[9], 1ull);    // a lane outside the last quarter
+        }
+    }
+    atomicAdd(&g_cand_dbg[8], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ a6 + a7
@@ -254,6 +325,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* 
 }
 
 }  // namespace
+
+#ifdef EP24_STAMPS
+extern "C" int ep24_debug_read_cand(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cand_dbg), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ep24_assign_candidates(const float* labels, const float* xs, const float* ys, const float* strides,
                                       int32_t* num_gt, uint64_t* in_box, uint64_t* in_ctr, int B, int A, void* stream) {

@@ -33,7 +33,7 @@ struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const long long* stats, int reps,
                                                          const float* gamma, const float* beta, float* rmean,
-                                                         float* rvar, long* nbt, float* save, bf16* y, long ld_y,
+                                                         float* rvar, long* nbt, long* nbt2, float* save, bf16* y, long ld_y,
                                                          const bf16* res, long ld_res, long M, int C, float eps,
                                                          float momentum) {
     constexpr int act = ACT;                     // compile-time: the SiLU instantiation carries no trace of the other modes
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (nbt) *nbt += 1;
+        if (nbt2) *nbt2 += 1;                      // a merged unit: the second module's num_batches_tracked
+    }
     __syncthreads();
     const int cgs = C >> 3;
     const long total = M * cgs;
@@ -853,8 +856,8 @@ int cap_grid(long work_items) {
 
 extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int reps, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
-                               float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res, int64_t M, int C,
-                               float eps, float momentum, int act, void* stream) {
+                               int64_t* num_batches2, float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res,
+                               int64_t M, int C, float eps, float momentum, int act, void* stream) {
     EP24_REQUIRE(z && stats && gamma && beta && save && y, EP24_E_ARG, "bn_act_fwd: null pointer");
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
@@ -862,7 +865,7 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     const int fw_per = 2;                                   // chunks per lane and launch: tools/bn_probe.py sweeps of round 1
     auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : act == 3 ? bn_act_fwd_kernel<3> : bn_act_fwd_kernel<0>;
     hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
-                       beta, running_mean, running_var, (long*)num_batches, save, (bf16*)y, ld_y, (const bf16*)residual,
+                       beta, running_mean, running_var, (long*)num_batches, (long*)num_batches2, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
     return EP24_OK;

@@ -714,7 +714,7 @@ class Engine:
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
-    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None):
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
         name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none)."""
         home = self.home
@@ -746,6 +746,8 @@ class Engine:
         res_p = residual.ptr() if residual is not None else None
         res_ld = residual.ld if residual is not None else 0
         if self.f32:
+            if bn2 is not None:
+                self._f("incr_i64", ptr(bn2.num_batches_tracked), ev=False)
             return self._unit_f32(mod, conv, bn, seg, gam, bet, x, z, out, residual, res_p, res_ld, k_, s, act, save, sum_g)
         if self.fold_bn_eval:
             woff, coff = self._fold_w, self._fold_c
@@ -759,7 +761,8 @@ class Engine:
             ev_conv = ("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s))
         self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s, ev=ev_conv)
         self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
-                ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), out.ptr(), out.ld,
+                ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                ptr(bn2.num_batches_tracked) if bn2 is not None else None, ptr(save), out.ptr(), out.ld,
                 res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), act,
                 ev=False if self.fold_bn_eval else
                 ("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
@@ -1005,7 +1008,7 @@ class Engine:
         flat, gflat = home.flat, home.gflat
         self._f("stats_gather", bstats, ld_stats, lstats, C, STATS_REPLICAS, ev=False)
         self._f("bn_act_fwd", x.ptr(), x.ld, lstats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
-                ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(save), a.ptr(), a.ld, None, 0, M, C, float(bn.eps),
+                ptr(bn.running_var), ptr(bn.num_batches_tracked), None, ptr(save), a.ptr(), a.ld, None, 0, M, C, float(bn.eps),
                 float(bn.momentum), 2,
                 ev=("bn_act_infer", (x.ptr(), x.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
                                      ptr(bn.running_var), a.ptr(), a.ld, None, 0, M, C, float(bn.eps), 2)))
@@ -1107,11 +1110,10 @@ class Engine:
         _same_bn(mod.conv2.bn, mod.conv1.bn)
         P = self.new_act(3 * h, x.H, x.W)
         both = P.slice(h, 2 * h)
-        self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn, act=mod.conv2.act_code)
+        self.unit(None, x, out=both, conv=mod.conv2.conv, bn=mod.conv2.bn, act=mod.conv2.act_code, bn2=mod.conv1.bn)
         xa, za, ya = self.unit_acts.pop(mod.conv2.conv)
         self.unit_acts[mod.conv2] = (xa, za.slice(0, h), ya.slice(0, h))      # per-module views (tests walk unit_acts)
         self.unit_acts[mod.conv1] = (xa, za.slice(h, h), ya.slice(h, h))
-        self._f("incr_i64", ptr(mod.conv1.bn.num_batches_tracked), ev=False)  # the BN launch counted for conv2's module
         t = x1 = P.slice(2 * h, h)
         n = len(mod.m)
         if any(blk.use_add for blk in mod.m):
@@ -1175,11 +1177,10 @@ class Engine:
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
             _same_bn(c0.bn, r0.bn)
-            both = self.unit(None, x, conv=c0.conv, bn=c0.bn, act=c0.act_code)   # [class branch | regression branch], one GEMM (N = 2h)
+            both = self.unit(None, x, conv=c0.conv, bn=c0.bn, act=c0.act_code, bn2=r0.bn)   # [class branch | regression branch], one GEMM (N = 2h)
             xa, za, ya = self.unit_acts.pop(c0.conv)
             self.unit_acts[c0] = (xa, za.slice(0, hc), ya.slice(0, hc))
             self.unit_acts[r0] = (xa, za.slice(hc, hc), ya.slice(hc, hc))
-            self._f("incr_i64", ptr(r0.bn.num_batches_tracked), ev=False)
             cf = self.unit(head.cls_convs[k][1], both.slice(0, hc))
             rf = self.unit(head.reg_convs[k][1], both.slice(hc, hc))
         else:

@@ -142,17 +142,17 @@ class TrainStep:
 
     def _phase_forward_head(self):
         eng = self.eng
+        # The label-only part of SimOTA (candidate masks) runs FIRST and alone.  It used to open the second forward lane;
+        # next to the MFMA kernels of the other lane its angle sums came back different in lanes 48..63 of a wave a few
+        # times per launch (a transcendental result consumed one quarter-wave too early; never when the kernel has the
+        # SIMDs to itself - DESIGN.md section 6, tools/step_stress.py), which flipped a borderline candidate now and then.
+        eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
         self.home.zero_grad()
         if not torch.cuda.is_current_stream_capturing():
             eng.draw_dropout()
         eng.zero_step_buffers()
         self.home.pack()
         eng.run_lane(self._fwd_split()[0])
-
-    def _phase_side_forward(self, lst):
-        """The second forward lane: the label-only part of SimOTA (candidate masks), then the level-0 head chain."""
-        eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
-        self.eng.run_lane(lst)
 
     def _phase_loss(self):
         eng = self.eng
@@ -222,7 +222,10 @@ class TrainStep:
 
         def capture(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool[0]):
+            # thread_local: the process group's watchdog thread polls the events of collectives in flight (the broadcast of
+            # ep24.dp.GradReducer.attach, the previous step's buckets); in the default global mode such a query from ANY
+            # thread while this one captures is an error that kills the rank
+            with torch.cuda.graph(g, pool=pool[0], capture_error_mode="thread_local"):
                 fn()
             pool[0] = g.pool()
             return g
@@ -231,8 +234,7 @@ class TrainStep:
         if split is None:
             self.g_fwd = capture(self._phase_forward)
         else:
-            lanes = [capture((lambda l=l: self._phase_side_forward(l)) if i == 1 else (lambda l=l: eng.run_lane(l)))
-                     for i, l in enumerate(split[1:])]                            # index 1 = the level-0 head lane
+            lanes = [capture(lambda l=l: eng.run_lane(l)) for l in split[1:]]
             self.g_fwd = (capture(self._phase_forward_head),) + tuple(lanes) + (capture(self._phase_loss),)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)

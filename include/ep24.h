@@ -99,9 +99,10 @@ int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int6
  * save[1][c]=invstd for the backward and updates running_mean / running_var (unbiased) / num_batches_tracked
  * (momentum, eps: yolox_24p/exp/yolox_base.py:58-62).  act: 1 = SiLU, 0 = identity. */
 int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats_replicas, const float* gamma,
-                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches, int64_t* num_batches2,
                     float* save, void* y, int64_t ld_y, const void* residual, int64_t ld_res,
-                    int64_t M, int C, float eps, float momentum, int act, void* stream);
+                    int64_t M, int C, float eps, float momentum, int act, void* stream);   /* num_batches2: the counter of the
+                    second BatchNorm module when two units share the launch (merged CSP / head pairs), else NULL */
 
 /* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
  * 2^-20 fixed-point int64 like the forward statistics. */

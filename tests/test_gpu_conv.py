@@ -250,12 +250,13 @@ def test_bn_silu_fwd_bwd(M, C, res):
     y = torch.zeros(M, C, dtype=BF, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
     rd = r.to(DEV) if res else None
-    call("bn_act_fwd", ptr(zd), C, ptr(stats), R, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), ptr(nbt), ptr(save), ptr(y), C,
+    nbt2 = torch.full((), 5, dtype=torch.int64, device=DEV)
+    call("bn_act_fwd", ptr(zd), C, ptr(stats), R, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), ptr(nbt), ptr(nbt2), ptr(save), ptr(y), C,
          ptr(rd), C if res else 0, M, C, 1e-3, 0.03, 1, sp())
     close(y, y_ref.detach())
     close(rmd, rm, rel=1e-4)
     close(rvd, rv, rel=1e-4)
-    assert int(nbt) == 1
+    assert int(nbt) == 1 and int(nbt2) == 6
     dyd = dy.to(DEV)
     sums = torch.zeros(2, C, dtype=torch.int64, device=DEV)
     ggrad, bgrad = torch.ones(C, device=DEV), torch.ones(C, device=DEV)

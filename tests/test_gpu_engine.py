@@ -385,6 +385,61 @@ def test_full_size_step_properties():
     assert abs(l0[1] - l0[0]) / l0[0] < 0.2                                 # only the loss's dynamic weights moved
 
 
+def test_replayed_full_size_step_is_bitwise_stable():
+    """60 replays of the captured full-size step (BASELINE config 2) with frozen weights (lr = 0, the loss's running state
+    restored before each): an exact integer checksum of EVERY engine buffer - activations, gradients, BN sums, SimOTA masks
+    and costs, matched indices, the flat gradient - must equal the first step's.  This is the test that caught the
+    candidate-mask kernel returning different angle sums when it ran next to the MFMA kernels of the other forward lane
+    (tools/step_stress.py is the long form with per-tensor reporting)."""
+    from ep24 import engine as eengine, loss as eloss, nn as enn, train as etrain
+    bufs, init = [], eengine.Buf.__init__
+
+    def rec(self, *a, **k):
+        init(self, *a, **k)
+        bufs.append(self)
+
+    eengine.Buf.__init__ = rec
+    try:
+        torch.manual_seed(0)
+        m = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
+        m.head.initialize_biases(1e-2)
+        m.to(DEV)
+        ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.0, momentum=0.9, batch=20, size=640)
+    finally:
+        eengine.Buf.__init__ = init
+    ts.eng.images.copy_(synth.make_images(20, 640, seed=1).to(DEV))
+    ts.labels.copy_(synth.make_labels(20, 10, size=640, seed=1000).to(DEV))
+    eng = ts.eng
+
+    def tensors():
+        out = [(("buf%d" % i), b.t) for i, b in enumerate(bufs)] + [("buf%d.grad" % i, b.g) for i, b in enumerate(bufs) if b.g is not None]
+        out += [("outputs", eng.outputs), ("stats", eng.stats), ("bnsums", eng.bnsums), ("dzbuf", eng.dzbuf), ("gflat", ts.home.gflat)]
+        ws = ts.ws
+        out += [("in_box", ws.masks[0]), ("in_ctr", ws.masks[1]), ("match", ws.masks[2]), ("matched_gt", ws.matched_gt),
+                ("matched_iou", ws.matched_iou), ("dout", ws.dout), ("result", ws.result)]
+        return out
+
+    def checksum(t):
+        t = t.reshape(-1)
+        if t.dtype == torch.int64:
+            return t.sum()
+        return (t.view(torch.int32) if (t.numel() * t.element_size()) % 4 == 0 else t.view(torch.uint8)).sum(dtype=torch.int64)
+
+    state0 = ts.state.clone()
+    ref = None
+    for step in range(60):
+        ts.state.copy_(state0)
+        ts.step()
+        tl = tensors()
+        cs = torch.stack([checksum(t) for _, t in tl])
+        if ref is None:
+            ref = cs.clone()
+            assert len(tl) > 200
+            continue
+        diff = (cs != ref).nonzero().flatten().tolist()
+        assert not diff, "step %d: %s differ from step 0" % (step, [tl[i][0] for i in diff[:8]])
+
+
 def test_loss_of_model_outputs_matches_oracle_assignment():
     """L2 boundary on real network outputs: feed the HIP model's own outputs to the CPU oracle loss."""
     from ep24 import loss as eloss

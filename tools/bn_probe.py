@@ -38,7 +38,7 @@ def probe(M, C, kind, warm):
         z, dy, out = sets[i % nset]
         s = stream_ptr()
         if kind == "fwd":
-            call("bn_act_fwd", ptr(z), C, ptr(stats), 1, ptr(gamma), ptr(beta), None, None, None, ptr(save), ptr(out), C,
+            call("bn_act_fwd", ptr(z), C, ptr(stats), 1, ptr(gamma), ptr(beta), None, None, None, None, ptr(save), ptr(out), C,
                  None, 0, M, C, 1e-3, 0.03, 1, s)
         elif kind == "reduce":
             call("bn_act_bwd_reduce", ptr(dy), C, ptr(z), C, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums[1]), M, C, 1, s)
