@@ -43,9 +43,10 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
     constexpr int B_BYTES = BN * 128;
     constexpr int B_INSTR = BN / 8 / NW;                     // weight-tile DMA instructions per wave and step
     static_assert(B_INSTR >= 1, "tile too narrow for its wave count");
+    static_assert(NB == 3, "nine taps per chunk: the stage of a step is its tap column, a compile-time constant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef EP24_STAMPS
     const unsigned long long st_t0 = STAMP(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_wait = 0, st_work = 0;
@@ -59,29 +60,34 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
     const int n0 = (tile_id - tile_m * tiles_n) * BN;
     const int KC = (p.K + BK - 1) / BK;
     const int PBYTES = PR * 128;
-    char* const bbase = smem + npb * PBYTES;
+    const int bb = npb * PBYTES;                             // LDS offset of the weight ring (smem is the only LDS object: offset 0)
 
     const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
     const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
     const int kmax = (p.K - lchunk * 8 + BK - 1) / BK;       // chunks kc < kmax hold real channels for this lane
+    const int ktail = (p.K & (BK - 1)) ? KC - 1 : KC;        // chunks >= ktail need the per-lane check (K not a multiple of 64)
 
     // ---- patch pieces: piece g = i*NW + wave covers patch rows 8g .. 8g+7 (1 KiB, one DMA instruction); the lane's row
-    // in piece g is pixel m0 - halo + 8g + (lane >> 3) of the flattened source
+    // in piece g is pixel m0 - halo + 8g + (lane >> 3) of the flattened source.  All offsets are 32-bit (the launcher
+    // refuses tensors of 2 GiB and more); a row before the tensor wraps to a huge unsigned value and fails the range test.
     const int NPW = PR / (8 * NW);                           // pieces per wave and chunk; NPW <= 7 * PPS: all issued by tap step 6
-    static_assert(NB == 3, "the half-step pipeline needs the three-stage weight ring");
-    const long msrc = (long)p.B * p.SH * p.SW;
-    const long prow0 = m0 - halo + (lane >> 3);
-    const long ld2 = p.ld_src * 2;
-    auto issue_patch = [&](char* pbuf, int kc, int i) {
+    const unsigned msrc = (unsigned)((long)p.B * p.SH * p.SW);
+    const int prow0 = (int)(m0 - halo) + (lane >> 3);
+    const int ld2 = (int)p.ld_src * 2;
+    const unsigned pv0 = (unsigned)prow0 * (unsigned)ld2 + lchunk * 16;   // byte offset of the lane's row in piece 0, chunk 0 (wraps like prow0)
+    auto issue_patch = [&](int pbuf_off, int kc, int i) {
         if (i >= NPW) i = NPW - 1;                             // filler: the same piece again (identical bytes), so that every
                                                                // step issues a fixed number of DMAs and the waits are immediates
-        const int g = i * NW + wave;
-        const long ps = prow0 + 8 * g;
-        const int vo = (ps >= 0 && ps < msrc && kc < kmax) ? (int)(ps * ld2) + lchunk * 16 + kc * (BK * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(pbuf + g * 1024), 16, vo, 0, 0, 0);
+        const int g = i * NW + wave;                           // scalar
+        const unsigned ps = (unsigned)(prow0 + 8 * g);
+        bool ok = ps < msrc;
+        if (kc >= ktail) ok = ok && kc < kmax;
+        const int vo = ok ? (int)(pv0 + (unsigned)(8 * g * ld2 + kc * (BK * 2))) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(smem + pbuf_off + g * 1024), 16, vo, 0, 0, 0);
     };
-    // ---- weight tile rows (relabelled inside each 64 span, as in the tiled kernel)
+    // ---- weight tile rows (relabelled inside each 64 span, as in the tiled kernel); rows beyond N keep an offset that
+    // stays out of range whatever is added to it
     int wvoff[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
@@ -89,13 +95,15 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
         const int r = (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
         wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : OOB;
     }
-    auto issue_b = [&](int step_, int wslot, int kc) {
-        const int b_s = (wslot * p.K + kc * BK) * 2;
-        char* st = bbase + (step_ % NB) * B_BYTES;
+    // tile (tap t, chunk kc) into ring stage `stage`; nothing is issued beyond the last chunk
+    auto issue_b = [&](int stage, int t, int kc) {
+        if (kc >= KC) return;
+        const int b_s = (t * p.K + kc * BK) * 2;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const int vo = (kc < kmax && wvoff[i] != OOB) ? wvoff[i] + b_s : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(st + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+            int vo = wvoff[i] == OOB ? OOB : wvoff[i] + b_s;
+            if (kc >= ktail) vo = kc < kmax ? vo : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(smem + bb + stage * B_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
     };
 
@@ -106,68 +114,71 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: whole patch of chunk 0 (the weight tiles of the first steps follow below)
-    for (int i = 0; i < NPW; ++i) issue_patch(smem, 0, i);
+    // ---- prologue: whole patch of chunk 0, then the weight tiles of steps 0 and 1
+    for (int i = 0; i < NPW; ++i) issue_patch(0, 0, i);
+    issue_b(0, 0, 0);
+    issue_b(1, 1, 0);
 
     // taps in row-major order; forward reads pixel (y + ty - 1, x + tx - 1), the input gradient (y + 1 - ty, x + 1 - tx):
     // p.oy[0] tells which (the host builds both tables with weight slot t = tap t)
     const int sgn = p.oy[0] < 0 ? 1 : -1;
-    // Weight tiles run D = NB - 1 steps ahead in a ring of NB stages and are retired with a COUNTED vmcnt: per step a
-    // wave issues [weight tile of step j + D][patch pieces of step j], so when step j starts everything except the
-    // D - 1 younger weight tiles and the previous step's patch pieces must have landed.  Raw s_barrier: a
-    // __syncthreads() would drain every DMA in flight.
-    int fetch_t = 0, fetch_kc = 0;                            // (tap, chunk) of the next weight tile to issue
-    auto issue_next_b = [&]() {
-        issue_b(fetch_t + 9 * fetch_kc, fetch_t, fetch_kc);    // beyond the last chunk: zero fill into a stage nobody reads again
-        if (++fetch_t == 9) { fetch_t = 0; ++fetch_kc; }
-    };
-    issue_next_b();                                            // steps 0 and 1 (the patch of chunk 0 was issued before them)
-    issue_next_b();
 
-    // ---- per-lane fragment rows and their tap masks (computed while the first DMAs are in flight)
-    int qb[MT];
+    // ---- per-lane tap masks of the four fragment rows (computed while the first DMAs are in flight), and per fragment
+    // the taps for which ANY lane of the wave is masked: the others skip the masking instructions altogether (a 16-pixel
+    // run touches an image border for one tap in five at W = 80)
     unsigned vm[MT];
+    unsigned need[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int r = wm * 64 + i * 16 + frow;
-        qb[i] = r + halo;
-        const long m = m0 + r;
+        const long m = m0 + wm * 64 + i * 16 + frow;
         unsigned mk = 0;
         if (m < p.M) {
             const int mm = (int)m;
             const int n = fdiv(mm, p.d_plane);
             const int rem = mm - n * (p.GH * p.GW);
             const int y = fdiv(rem, p.d_gw), x = rem - y * p.GW;
-            const int sg = p.oy[0] < 0 ? 1 : -1;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int iy = y + sg * (t / 3 - 1), ix = x + sg * (t % 3 - 1);
+                const int iy = y + sgn * (t / 3 - 1), ix = x + sgn * (t % 3 - 1);
                 if (iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
             }
         }
         vm[i] = mk;
+        unsigned nd = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (__ballot(!((mk >> t) & 1u)) != 0ull) nd |= 1u << t;
+        need[i] = __builtin_amdgcn_readfirstlane(nd);
     }
 
-
-    // fragments of one 32-deep k half: A rows from the patch at this tap's row shift (masked), B rows from a weight stage
-    auto read_half = [&](bf16x8 (&fa)[MT], bf16x8 (&fb)[NT], const char* pb, const char* lb, int t, int sh, int ks) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int q = qb[i] + sh;
-            fa[i] = *reinterpret_cast<const bf16x8*>(pb + q * 128 + (((ks * 4 + fq) ^ (q & 7)) << 4));
-        }
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-            fb[q] = *reinterpret_cast<const bf16x8*>(lb + swz(wn * 64 + q * 16 + frow, ks * 4 + fq));
+    // ---- LDS read addresses.  A: fragment row i of the wave sits at patch row arow0 + 16 i + shift(tap); 16 i and the
+    // k half leave the swizzle key (row & 7) alone, so one address per tap serves the four rows through the instruction's
+    // offset field and the second k half is that address with bit 6 flipped.  B: constant per lane; stage, fragment and
+    // k half are offset-field constants (the stage of a step is its tap column).
+    const int arow0 = wm * 64 + frow + halo;
+    const int bo0 = bb + (wn * 64 + frow) * 128 + ((fq ^ (frow & 7)) << 4);
+    auto a_off = [&](int pbuf_off, int sh) {                  // ks = 0 address of a tap whose row shift is sh
+        const int q0 = arow0 + sh;
+        return pbuf_off + q0 * 128 + ((fq ^ (q0 & 7)) << 4);
     };
-    // rows a tap takes from across an image border are zeroed; applied right before the MFMAs that use the fragments (the
-    // reads were issued half a step earlier, so this does not wait for the LDS)
+    auto read_a = [&](bf16x8 (&fa)[MT], int off) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(smem + off + i * 2048);
+    };
+    auto read_b = [&](bf16x8 (&fb)[NT], int off, int stage) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(smem + off + stage * B_BYTES + q * 2048);
+    };
+    // rows a tap takes from across an image border are zeroed, right before the MFMAs that use the fragments
     auto mask_half = [&](bf16x8 (&fa)[MT], int t) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            v4i v = __builtin_bit_cast(v4i, fa[i]);
-            v &= -(int)((vm[i] >> t) & 1u);
-            fa[i] = __builtin_bit_cast(bf16x8, v);
+            if ((need[i] >> t) & 1u) {
+                asm volatile("" ::: "memory");                 // keeps this a scalar branch (no select over the whole wave)
+                v4i v = __builtin_bit_cast(v4i, fa[i]);
+                v &= -(int)((vm[i] >> t) & 1u);
+                fa[i] = __builtin_bit_cast(bf16x8, v);
+            }
         }
     };
     auto mma = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fb)[NT]) {
@@ -177,7 +188,6 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
             for (int q = 0; q < NT; ++q)
                 acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
     };
-    auto shift_of = [&](int t) { return sgn * ((t / 3 - 1) * p.SW + (t % 3 - 1)); };
 
     // Software pipeline, half a step deep: when step j starts, the fragments of its first k half are already in registers
     // (read during step j-1, behind its MFMAs), so the MFMA pipe starts right after the barrier instead of waiting for
@@ -185,53 +195,73 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
     // second's.  For that the weight tile of step j+1 must be visible during step j: the wait at the start of step j
     // covers it (it was issued FIRST in step j-1; only that step's patch pieces may still be in flight).
     // Issue order per step: [weight tile of step j+2][PPS patch pieces in tap steps 0..6 of a chunk that has a successor].
+    // Weight tiles are retired with a COUNTED vmcnt and a raw s_barrier: a __syncthreads() would drain every DMA in flight.
+    // The tap loop is 3 rows x 3 unrolled columns: tap column, ring stage and every LDS offset of a step are constants,
+    // which took the loop from 253 to ~130 instructions per 32 MFMAs (it was issue-bound: 104 vector + 98 scalar
+    // instructions per step next to the MFMAs of two waves per SIMD).
     wait_vmcnt_c<0>();
     __builtin_amdgcn_s_barrier();
     bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-    read_half(fa0, fb0, smem, bbase, 0, shift_of(0), 0);
-    int step = 0;
-    const int n_steps = 9 * KC;
+    int offa = a_off(0, sgn * (-p.SW - 1));                   // tap 0 of chunk 0
+    read_a(fa0, offa);
+    read_b(fb0, bo0, 0);
 #ifdef EP24_STAMPS
     const unsigned long long st_t1 = STAMP();
 #endif
     for (int kc = 0; kc < KC; ++kc) {
-        const char* pb = smem + ((npb == 2) ? (kc & 1) : 0) * PBYTES;
-        char* const pnext = smem + ((kc + 1) & 1) * PBYTES;
+        const int pcur = (npb == 2) ? (kc & 1) * PBYTES : 0;
+        const int pnext = ((kc + 1) & 1) * PBYTES;
         const bool more = kc + 1 < KC;                       // another chunk follows: its patch pieces are issued in these steps
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t, ++step) {
+        for (int ty = 0; ty < 3; ++ty) {
+            const int shrow = sgn * (ty - 1) * p.SW;
+            auto tap_step = [&](auto txc) {
+                constexpr int tx = decltype(txc)::value;
+                const int t = ty * 3 + tx;
 #ifdef EP24_STAMPS
-            const unsigned long long st_a = STAMP();
+                const unsigned long long st_a = STAMP();
 #endif
-            if (more && t >= 1 && t <= 7) wait_vmcnt_c<PPS>(); else wait_vmcnt_c<0>();
-            __builtin_amdgcn_s_barrier();      // weight tile of step j+1 (and at tap 8 the next chunk's patch) landed for every
+                // taps 1..7 of a chunk with a successor: the pieces issued in the previous step may stay in flight
+                const bool counted = more && (tx == 1 || (tx == 0 ? ty != 0 : ty != 2));
+                if (counted) wait_vmcnt_c<PPS>(); else wait_vmcnt_c<0>();
+                __builtin_amdgcn_s_barrier();  // weight tile of step j+1 (and at tap 8 the next chunk's patch) landed for every
                                                // wave; nobody still reads the stage / patch buffer refilled below
 #ifdef EP24_STAMPS
-            const unsigned long long st_b = STAMP();
-            st_wait += st_b - st_a;
+                const unsigned long long st_b = STAMP();
+                st_wait += st_b - st_a;
 #endif
-            issue_next_b();
-            if (more && t <= 6) {
+                // weight tile of step j+2: tap t+2 of this chunk, or tap t-7 of the next
+                if (tx == 0 || ty < 2) issue_b((tx + 2) % 3, t + 2, kc);
+                else issue_b((tx + 2) % 3, t - 7, kc + 1);
+                if (more && (ty < 2 || tx == 0)) {             // tap steps 0..6
 #pragma unroll
-                for (int i = 0; i < PPS; ++i) issue_patch(pnext, kc + 1, t * PPS + i);
-            }
-            const char* lb = bbase + (step % NB) * B_BYTES;
-            read_half(fa1, fb1, pb, lb, t, shift_of(t), 1);
-            mask_half(fa0, t);
-            mma(fa0, fb0);
-            if (step + 1 < n_steps) {
-                const int tn = t == 8 ? 0 : t + 1;
-                read_half(fa0, fb0, t == 8 ? pnext : pb, bbase + ((step + 1) % NB) * B_BYTES, tn, shift_of(tn), 0);
-            }
-            mask_half(fa1, t);
-            mma(fa1, fb1);
+                    for (int i = 0; i < PPS; ++i) issue_patch(pnext, kc + 1, t * PPS + i);
+                }
+                read_a(fa1, offa ^ 64);
+                read_b(fb1, bo0 ^ 64, tx);
+                mask_half(fa0, t);
+                mma(fa0, fb0);
+                if (tx < 2 || ty < 2 || more) {                // not the last step: first k half of the next tap
+                    offa = (tx < 2) ? a_off(pcur, shrow + sgn * tx)                              // same row, next column
+                                    : (ty < 2 ? a_off(pcur, shrow + sgn * (p.SW - 1))            // first column of the next row
+                                              : a_off(pnext, sgn * (-p.SW - 1)));                // tap 0 of the next chunk
+                    read_a(fa0, offa);
+                    read_b(fb0, bo0, (tx + 1) % 3);
+                }
+                mask_half(fa1, t);
+                mma(fa1, fb1);
 #ifdef EP24_STAMPS
-            st_work += STAMP() - st_b;
+                st_work += STAMP() - st_b;
 #endif
+            };
+            tap_step(std::integral_constant<int, 0>{});
+            tap_step(std::integral_constant<int, 1>{});
+            tap_step(std::integral_constant<int, 2>{});
         }
     }
 #ifdef EP24_STAMPS
     const unsigned long long st_t2 = STAMP();
+    const int n_steps = 9 * KC;
 #endif
     igemm_epilogue<BN, false, MT, 0, NW>(p, acc, m0, n0, tile_m, smem);
 #ifdef EP24_STAMPS
