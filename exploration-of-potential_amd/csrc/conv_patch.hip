@@ -224,11 +224,15 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
                 // taps 1..7 of a chunk with a successor: the pieces issued in the previous step may stay in flight
                 const bool counted = more && (tx == 1 || (tx == 0 ? ty != 0 : ty != 2));
                 if (counted) wait_vmcnt_c<PPS>(); else wait_vmcnt_c<0>();
+#ifdef EP24_STAMPS
+                const unsigned long long st_m = STAMP();
+                st_work += st_m - st_a;                        // diagnostic build: "work" column = the counted DMA wait alone
+#endif
                 __builtin_amdgcn_s_barrier();  // weight tile of step j+1 (and at tap 8 the next chunk's patch) landed for every
                                                // wave; nobody still reads the stage / patch buffer refilled below
 #ifdef EP24_STAMPS
                 const unsigned long long st_b = STAMP();
-                st_wait += st_b - st_a;
+                st_wait += st_b - st_m;                        // "wait" column = the barrier alone
 #endif
                 // weight tile of step j+2: tap t+2 of this chunk, or tap t-7 of the next
                 if (tx == 0 || ty < 2) issue_b((tx + 2) % 3, t + 2, kc);
@@ -250,9 +254,6 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
                 }
                 mask_half(fa1, t);
                 mma(fa1, fb1);
-#ifdef EP24_STAMPS
-                st_work += STAMP() - st_b;
-#endif
             };
             tap_step(std::integral_constant<int, 0>{});
             tap_step(std::integral_constant<int, 1>{});
@@ -265,8 +266,8 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
 #endif
     igemm_epilogue<BN, false, MT, 0, NW>(p, acc, m0, n0, tile_m, smem);
 #ifdef EP24_STAMPS
-    if (blockIdx.x < 64 && tid == 0) {
-        unsigned long long* o = g_stamps + blockIdx.x * 8;
+    if (blockIdx.x < 32 && lane == 0 && (wave == 0 || wave == NW - 1)) {     // the oldest and the youngest wave of a workgroup
+        unsigned long long* o = g_stamps + (blockIdx.x * 2 + (wave != 0)) * 8;
         o[0] = st_t1 - st_t0; o[1] = st_t2 - st_t1; o[2] = STAMP() - st_t2; o[3] = st_wait; o[4] = st_work;
         o[5] = __builtin_amdgcn_s_memrealtime() - st_r0; o[6] = STAMP() - st_t0; o[7] = n_steps;
     }

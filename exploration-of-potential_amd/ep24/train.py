@@ -6,6 +6,8 @@ gradient clearing, weight packing, forward list, SimOTA + loss + loss gradient, 
 all-reduce), fused SGD - is a fixed sequence of launches on static buffers, captured once and replayed;
 the host only copies the next batch into the static input buffers and reads the loss when it wants to.
 """
+import os
+
 import torch
 
 from . import _lib, loss as eloss
@@ -89,7 +91,6 @@ class TrainStep:
         # replays each lane as a chain of captured segments (no launch gaps: 28.7 ms/step at YOLOX-l / B=20);
         # False launches the same lanes from the host with per-layer events (29.4 ms)
         self.graph_backward = graph_backward
-        import os
         self.parallel_forward = graph_backward and not os.environ.get("EP24_NO_PAR_FWD")
         self.forward_lanes = int(os.environ.get("EP24_FWD_LANES", 2))
         self.world = 1 if reducer is None else reducer.world
@@ -185,7 +186,6 @@ class TrainStep:
         bucket boundaries are cut points too."""
         n = len(self.eng.bwd)
         fr = (0.12, 0.24, 0.36, 0.48, 0.58, 0.68, 0.76, 0.83, 0.89, 0.93, 0.96, 0.98, 0.99, 0.995)
-        import os
         if os.environ.get("EP24_BWD_CUTS"):
             e = os.environ["EP24_BWD_CUTS"]
             fr = [(i + 1) / int(e[1:]) for i in range(int(e[1:]) - 1)] if e[0] == "u" else [float(v) for v in e.split(",")]

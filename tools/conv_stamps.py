@@ -32,12 +32,13 @@ def main():
         torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * 512)()
         assert rd(buf, 512) == 0
-        rows = [buf[i * 8:(i + 1) * 8] for i in range(64)]
-        med = [sorted(r[k] for r in rows)[32] for k in range(8)]
-        n = max(med[7], 1)
-        clk = med[6] / max(med[5], 1) * 0.1
-        print("%-20s %5d %9d %6d %9d | %22.0f %5.0f | %9.2f | %9.1f" % ("%d,%d,%d,%d" % (B, H, Cin, Cout), n, med[0], med[1], med[2],
-                                                                      med[3] / n, med[4] / n, clk, med[5] / 100.0), flush=True)
+        for which, name in ((0, "wave 0"), (1, "wave 7")):       # the oldest and the youngest wave of the workgroup
+            rows = [buf[(i * 2 + which) * 8:(i * 2 + which + 1) * 8] for i in range(32)]
+            med = [sorted(r[k] for r in rows)[16] for k in range(8)]
+            n = max(med[7], 1)
+            clk = med[6] / max(med[5], 1) * 0.1
+            print("%-20s %5d %9d %6d %9d | %22.0f %5.0f | %9.2f | %9.1f  %s" % ("%d,%d,%d,%d" % (B, H, Cin, Cout), n, med[0], med[1], med[2],
+                                                                          med[3] / n, med[4] / n, clk, med[5] / 100.0, name), flush=True)
 
 
 main()
