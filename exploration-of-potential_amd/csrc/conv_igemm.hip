@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int B_INSTR = BN * 8 / 64 / 4;             // 4 or 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run
     // of tiles (N fastest): the N tiles of one M tile and neighbouring M tiles share their operands in one L2
@@ -80,24 +80,31 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : OOB;
     }
     const int kmax = (p.K - lchunk * 8 + BK - 1) / BK;       // chunks kc < kmax hold real channels for this lane
+    const int ktail = (p.K & (BK - 1)) ? KC - 1 : KC;        // chunks >= ktail need that per-lane check (K not a multiple of 64)
 
     int is_t = 0, is_kc = 0;                                 // (tap, channel chunk) of the next tile to issue
     auto issue = [&](int buf) {
-        // channel-chunk outer, tap inner: the 9 taps of a chunk re-read the same ~27 KB window (L1 / L2 hits)
+        // channel-chunk outer, tap inner: the 9 taps of a chunk re-read the same ~27 KB window (L1 / L2 hits).
+        // The offsets are selected with bit operations: written as `cond ? offset : OOB` the compiler emitted a divergent
+        // branch around every DMA (two DMA instructions, exec masking, ~90 scalar instructions per K step).
         const int t = is_t, kc = is_kc;
         if (++is_t == p.T) { is_t = 0; ++is_kc; }
-        const bool kok = kc < kmax;
+        const bool tail = kc >= ktail;                       // wave-uniform, false for every layer of the YOLOX-l path
+        const int ktm = tail ? -(int)(kc < kmax) : -1;
         const int a_s = p.toff[t] + kc * (BK * 2);
-        const int b_s = (p.wslot[t] * p.K + kc * BK) * 2;
+        const unsigned b_s = (unsigned)((p.wslot[t] * p.K + kc * BK) * 2);
         char* stage = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            int vo = (kok && ((vmask[i] >> t) & 1u)) ? rowoff[i] + a_s : OOB;
+            const int m = -(int)((vmask[i] >> t) & 1u) & ktm;                     // all ones: the tap is inside the image for this row
+            const int vo = ((rowoff[i] + a_s) & m) | (OOB & ~m);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(stage + (wave * A_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            int vo = kok ? wvoff[i] + b_s : OOB;
+            // rows beyond N carry OOB: adding the tile offset keeps them beyond every extent (unsigned, < 2^32)
+            const int v = (int)((unsigned)wvoff[i] + b_s);
+            const int vo = (v & ktm) | (OOB & ~ktm);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(stage + A_BYTES + (wave * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
         }
     };
