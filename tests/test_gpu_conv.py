@@ -108,6 +108,8 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s
     (20, 40, 256, 256, 3, 1), (20, 80, 128, 128, 3, 1), (20, 20, 512, 512, 3, 1), (20, 80, 256, 256, 3, 1), (4, 160, 64, 64, 3, 1),
     (20, 40, 512, 1024, 3, 2), (20, 80, 256, 512, 3, 2), (20, 20, 2048, 1024, 1, 1), (20, 20, 1024, 512, 1, 1),
     (20, 40, 512, 256, 1, 1), (20, 80, 128, 128, 1, 1), (20, 80, 256, 256, 1, 1), (2, 320, 112, 64, 1, 1),
+    # not on the YOLOX-l path: the halo-patch kernel with a K tail (96 = 64 + 32 channels) and an N tail (192 = 128 + 64)
+    (20, 80, 96, 192, 3, 1), (10, 80, 160, 136, 3, 1),
 ]
 
 
