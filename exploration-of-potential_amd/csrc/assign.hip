@@ -146,12 +146,21 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, co
 }
 
 // ------------------------------------------------------------------------------------------ a6 + a7
+// Only the candidates of an image (anchors inside some GT box or centre square: a few per cent, in runs along x) have a
+// cost row, and a row costs 24 lens evaluations per GT.  One thread per anchor left most lanes of every wave idle while one
+// or two of them walked all the GTs (360 us per step at B = 20).  Here a workgroup compacts the candidates among its 128
+// anchors into LDS (the class-sum term, once per candidate), then all its threads share the (candidate, GT) pairs.  The
+// arithmetic of a pair is unchanged, expression by expression, so pw / cost are bit-identical to the per-anchor form.
 __global__ __launch_bounds__(128) void cost_kernel(const float* outputs, int ncols, const float* labels,
                                                    const int* num_gt, const unsigned long long* in_box,
                                                    const unsigned long long* in_ctr, float* pw, float* cost, int A, int C) {
     __shared__ float gr[G_MAX][24], gcx[G_MAX], gcy[G_MAX];
-    __shared__ float spr[24][128];                                  // this thread's 24 predicted radii, k-major
+    __shared__ float spr[24][128];                                  // a candidate's 24 predicted radii, k-major
+    __shared__ float s_pcx[128], s_pcy[128], s_so[128], s_s0[128];
+    __shared__ unsigned long long s_both[128];
+    __shared__ int s_anchor[128];
     __shared__ int gcls[G_MAX];
+    __shared__ int s_cnt[2];
     const int b = blockIdx.y;
     const int ng = num_gt[b];
     const float* lab = labels + (long)b * G_MAX * LCOLS;
@@ -164,32 +173,47 @@ __global__ __launch_bounds__(128) void cost_kernel(const float* outputs, int nco
     for (int g = threadIdx.x; g < ng; g += 128) {
         gcx[g] = lab[g * LCOLS + 1]; gcy[g] = lab[g * LCOLS + 2]; gcls[g] = (int)lab[g * LCOLS];
     }
-    __syncthreads();
+    // ---- compaction: slot of this thread's anchor among the candidates of the workgroup (anchor order is kept)
     const int a = blockIdx.x * 128 + threadIdx.x;
-    if (a >= A) return;
-    const unsigned long long mb = in_box[(long)b * A + a], mc = in_ctr[(long)b * A + a];
-    if ((mb | mc) == 0ull) return;                                  // not a candidate (fg_mask false)
-    const float* o = outputs + ((long)b * A + a) * ncols;
-    for (int k = 0; k < 24; ++k) spr[k][threadIdx.x] = o[2 + k];
-    const float pcx = o[0], pcy = o[1];
-    const float so = 1.0f / (1.0f + expf(-o[26]));
-    // sum over classes of the "target 0" BCE term: -max(log1p(-p), -100), p = sqrt(sigmoid(cls)*sigmoid(obj))
-    float s0 = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + c]))) * so);
-        s0 += -fmaxf(log1pf(-p), -100.f);
+    unsigned long long mb = 0ull, mc = 0ull;
+    if (a < A) { mb = in_box[(long)b * A + a]; mc = in_ctr[(long)b * A + a]; }
+    const bool cand = (mb | mc) != 0ull;                            // fg_mask
+    const unsigned long long bal = __ballot(cand);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    const int slot = (wv ? s_cnt[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
+    const int nc = s_cnt[0] + s_cnt[1];
+    if (cand) {
+        const float* o = outputs + ((long)b * A + a) * ncols;
+        for (int k = 0; k < 24; ++k) spr[k][slot] = o[2 + k];
+        s_pcx[slot] = o[0]; s_pcy[slot] = o[1];
+        const float so = 1.0f / (1.0f + expf(-o[26]));
+        // sum over classes of the "target 0" BCE term: -max(log1p(-p), -100), p = sqrt(sigmoid(cls)*sigmoid(obj))
+        float s0 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + c]))) * so);
+            s0 += -fmaxf(log1pf(-p), -100.f);
+        }
+        s_so[slot] = so; s_s0[slot] = s0; s_both[slot] = mb & mc; s_anchor[slot] = a;
     }
-    for (int g = 0; g < ng; ++g) {
-        const float ddx = gcx[g] - pcx, ddy = gcy[g] - pcy;
+    __syncthreads();
+    // ---- the (candidate, GT) pairs of the workgroup, GT fastest
+    const int npair = nc * ng;
+    for (int pi = threadIdx.x; pi < npair; pi += 128) {
+        const int c = pi / ng, g = pi - c * ng;
+        const int an = s_anchor[c];
+        const float* o = outputs + ((long)b * A + an) * ncols;
+        const float ddx = gcx[g] - s_pcx[c], ddy = gcy[g] - s_pcy[c];
         const float d = sqrtf(ddx * ddx + ddy * ddy);
         float acc = 0.f;
-        for (int k = 0; k < 24; ++k) acc += 1.0f - ray_giou(gr[g][k], spr[k][threadIdx.x], d);
+        for (int k = 0; k < 24; ++k) acc += 1.0f - ray_giou(gr[g][k], spr[k][c], d);
         const float v = acc / 24.0f / 2.0f;                        // boxes.py:238-241
-        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + gcls[g]]))) * so);
-        const float cls_cost = s0 - (-fmaxf(log1pf(-p), -100.f)) + (-fmaxf(logf(p), -100.f));
-        const bool both = ((mb & mc) >> g) & 1ull;
+        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + gcls[g]]))) * s_so[c]);
+        const float cls_cost = s_s0[c] - (-fmaxf(log1pf(-p), -100.f)) + (-fmaxf(logf(p), -100.f));
+        const bool both = (s_both[c] >> g) & 1ull;
         const float cst = cls_cost + 3.0f * (-logf(v + 1e-8f)) + 100000.0f * (both ? 0.0f : 1.0f);   // losses.py:420-424
-        const long idx = ((long)b * G_MAX + g) * A + a;
+        const long idx = ((long)b * G_MAX + g) * A + an;
         pw[idx] = v;
         cost[idx] = cst;
     }
