@@ -22,7 +22,7 @@ def read():
     assert rd(buf, 512) == 0
     rows = [buf[i * 16:i * 16 + 8] for i in range(32)]        # wave 0 of the first 32 workgroups
     med = [sorted(r[k] for r in rows)[16] for k in range(8)]
-    return med[6] / max(med[5], 1) * 0.1, med[1] / max(med[7], 1), med[7]
+    return med[6] / max(med[5], 1) * 0.1, med[1] / max(med[7], 1), med[7], med[0], med[2], med[3] / max(med[7], 1), med[4] / max(med[7], 1), med[5] / 100.0
 
 
 torch.manual_seed(0)
@@ -36,8 +36,9 @@ for i in range(120):
     ts.step()
     if i % 40 == 39:
         torch.cuda.synchronize()
-        clk, cyc, n = read()
-        print("in the step (after %3d steps): clock %.2f GHz, %4.0f cycles per K step, %d steps in the stamped launch" % (i + 1, clk, cyc, n), flush=True)
+        clk, cyc, n, pro, epi, bar, dma, us = read()
+        print("in the step (after %3d steps): clock %.2f GHz, %4.0f cycles per K step (barrier %3.0f, DMA wait %3.0f), %d steps; prologue %5d epilogue %5d cycles; kernel %.1f us" % (
+            i + 1, clk, cyc, bar, dma, n, pro, epi, us), flush=True)
 del ts, m
 torch.cuda.empty_cache()
 for B, H, Cin, Cout in [(20, 80, 128, 128), (20, 40, 256, 256), (20, 80, 256, 256)]:
@@ -49,5 +50,6 @@ for B, H, Cin, Cout in [(20, 80, 128, 128), (20, 40, 256, 256), (20, 80, 256, 25
     for _ in range(20000 if H == 40 else 8000):
         call("conv_fwd_bf16", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, stream_ptr())
     torch.cuda.synchronize()
-    clk, cyc, n = read()
-    print("alone, back to back %-16s: clock %.2f GHz, %4.0f cycles per K step" % ("%d,%d,%d,%d" % (B, H, Cin, Cout), clk, cyc), flush=True)
+    clk, cyc, n, pro, epi, bar, dma, us = read()
+    print("alone, back to back %-16s: clock %.2f GHz, %4.0f cycles per K step (barrier %3.0f, DMA wait %3.0f), %d steps; prologue %5d epilogue %5d cycles; kernel %.1f us" % (
+        "%d,%d,%d,%d" % (B, H, Cin, Cout), clk, cyc, bar, dma, n, pro, epi, us), flush=True)
