@@ -213,7 +213,9 @@ int ep24_colsum_slab(const void* g, int64_t ld, float* slab, int64_t M, int N, v
  *        (yolox_24p/models/losses.py:360-592, yolox_24p/utils/boxes.py:102-243)
  * ------------------------------------------------------------------------------------------------ */
 /* a4+a5 (pts_in_poly + get_in_boxes_info, losses.py:497-592).  labels [B,50,51] fp32; xs/ys/strides [A].
- * Out: num_gt[B] int32 (rows with sum>0, losses.py:190), in_box[B*A], in_ctr[B*A] uint64 bitmasks over GTs. */
+ * Out: num_gt[B] int32 (rows with sum>0, losses.py:190), in_box[B*A], in_ctr[B*A] uint64 bitmasks over GTs.
+ * Launch it on its own: next to MFMA kernels of another stream its angle sums were measured to come back different in
+ * lanes 48..63 of a wave now and then; ep24.train runs it first in the step, before anything else. */
 int ep24_assign_candidates(const float* labels, const float* xs, const float* ys, const float* strides,
                            int32_t* num_gt, uint64_t* in_box, uint64_t* in_ctr, int B, int A, void* stream);
 /* a6+a7 (bboxes_iou + class cost + total cost, boxes.py:166-243, losses.py:396-424) for every candidate
