@@ -148,43 +148,51 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* labels, co
 // ------------------------------------------------------------------------------------------ a6 + a7
 // Only the candidates of an image (anchors inside some GT box or centre square: a few per cent, in runs along x) have a
 // cost row, and a row costs 24 lens evaluations per GT.  One thread per anchor left most lanes of every wave idle while one
-// or two of them walked all the GTs (360 us per step at B = 20).  Here a workgroup compacts the candidates among its 128
-// anchors into LDS (the class-sum term, once per candidate), then all its threads share the (candidate, GT) pairs.  The
-// arithmetic of a pair is unchanged, expression by expression, so pw / cost are bit-identical to the per-anchor form.
-__global__ __launch_bounds__(128) void cost_kernel(const float* outputs, int ncols, const float* labels,
-                                                   const int* num_gt, const unsigned long long* in_box,
-                                                   const unsigned long long* in_ctr, float* pw, float* cost, int A, int C) {
+// or two of them walked all the GTs (360 us per step at B = 20).  Here a workgroup of 256 threads compacts the candidates
+// among its 64 anchors into LDS (the class-sum term, once per candidate), then all its threads share the (candidate, GT)
+// pairs: four threads per anchor where the candidates are dense, an immediate exit where there are none.  The arithmetic
+// of a pair is unchanged, expression by expression, so pw / cost are bit-identical to the per-anchor form (ray_giou only
+// skips the lens of circle pairs that do not properly intersect, whose value it never used).
+constexpr int COST_APB = 64;                                       // anchors per workgroup (one wave compacts them)
+constexpr int COST_NT = 256;                                       // threads that share the workgroup's (candidate, GT) pairs
+
+__global__ __launch_bounds__(COST_NT) void cost_kernel(const float* outputs, int ncols, const float* labels,
+                                                       const int* num_gt, const unsigned long long* in_box,
+                                                       const unsigned long long* in_ctr, float* pw, float* cost, int A, int C) {
     __shared__ float gr[G_MAX][24], gcx[G_MAX], gcy[G_MAX];
-    __shared__ float spr[24][128];                                  // a candidate's 24 predicted radii, k-major
-    __shared__ float s_pcx[128], s_pcy[128], s_so[128], s_s0[128];
-    __shared__ unsigned long long s_both[128];
-    __shared__ int s_anchor[128];
+    __shared__ float spr[24][COST_APB];                             // a candidate's 24 predicted radii, k-major
+    __shared__ float s_pcx[COST_APB], s_pcy[COST_APB], s_so[COST_APB], s_s0[COST_APB];
+    __shared__ unsigned long long s_both[COST_APB];
+    __shared__ int s_anchor[COST_APB];
     __shared__ int gcls[G_MAX];
-    __shared__ int s_cnt[2];
+    __shared__ int s_nc;
     const int b = blockIdx.y;
     const int ng = num_gt[b];
+    // ---- compaction by the first wave: slot of an anchor among the candidates of the workgroup (anchor order is kept)
+    int slot = -1;
+    unsigned long long mb = 0ull, mc = 0ull;
+    const int a = blockIdx.x * COST_APB + threadIdx.x;
+    if (threadIdx.x < COST_APB) {
+        if (a < A) { mb = in_box[(long)b * A + a]; mc = in_ctr[(long)b * A + a]; }
+        const bool cand = (mb | mc) != 0ull;                        // fg_mask
+        const unsigned long long bal = __ballot(cand);
+        if (cand) slot = __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+        if (threadIdx.x == 0) s_nc = __popcll(bal);
+    }
+    __syncthreads();
+    const int nc = s_nc;
+    if (nc == 0) return;                                            // uniform: most workgroups of an image end here
     const float* lab = labels + (long)b * G_MAX * LCOLS;
-    for (int i = threadIdx.x; i < ng * 24; i += 128) {
+    for (int i = threadIdx.x; i < ng * 24; i += COST_NT) {
         const int g = i / 24, k = i - g * 24;
         const float dx = lab[g * LCOLS + 3 + 2 * k] - lab[g * LCOLS + 1];
         const float dy = lab[g * LCOLS + 4 + 2 * k] - lab[g * LCOLS + 2];
         gr[g][k] = sqrtf(dx * dx + dy * dy);                      // torch.norm over (x,y) (boxes.py:189-197)
     }
-    for (int g = threadIdx.x; g < ng; g += 128) {
+    for (int g = threadIdx.x; g < ng; g += COST_NT) {
         gcx[g] = lab[g * LCOLS + 1]; gcy[g] = lab[g * LCOLS + 2]; gcls[g] = (int)lab[g * LCOLS];
     }
-    // ---- compaction: slot of this thread's anchor among the candidates of the workgroup (anchor order is kept)
-    const int a = blockIdx.x * 128 + threadIdx.x;
-    unsigned long long mb = 0ull, mc = 0ull;
-    if (a < A) { mb = in_box[(long)b * A + a]; mc = in_ctr[(long)b * A + a]; }
-    const bool cand = (mb | mc) != 0ull;                            // fg_mask
-    const unsigned long long bal = __ballot(cand);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    const int slot = (wv ? s_cnt[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
-    const int nc = s_cnt[0] + s_cnt[1];
-    if (cand) {
+    if (slot >= 0) {
         const float* o = outputs + ((long)b * A + a) * ncols;
         for (int k = 0; k < 24; ++k) spr[k][slot] = o[2 + k];
         s_pcx[slot] = o[0]; s_pcy[slot] = o[1];
@@ -198,10 +206,11 @@ __global__ __launch_bounds__(128) void cost_kernel(const float* outputs, int nco
         s_so[slot] = so; s_s0[slot] = s0; s_both[slot] = mb & mc; s_anchor[slot] = a;
     }
     __syncthreads();
-    // ---- the (candidate, GT) pairs of the workgroup, GT fastest
+    // ---- the (candidate, GT) pairs of the workgroup, candidate fastest: the lanes of a wave hold neighbouring anchors against
+    // ONE GT, so they agree on "far from it" and skip the lens arithmetic of ray_giou together
     const int npair = nc * ng;
-    for (int pi = threadIdx.x; pi < npair; pi += 128) {
-        const int c = pi / ng, g = pi - c * ng;
+    for (int pi = threadIdx.x; pi < npair; pi += COST_NT) {
+        const int g = pi / nc, c = pi - g * nc;
         const int an = s_anchor[c];
         const float* o = outputs + ((long)b * A + an) * ncols;
         const float ddx = gcx[g] - s_pcx[c], ddy = gcy[g] - s_pcy[c];
@@ -371,7 +380,7 @@ extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* la
                                 int num_classes, void* stream) {
     EP24_REQUIRE(outputs && labels && num_gt && in_box && in_ctr && pw && cost, EP24_E_ARG, "assign_cost: null pointer");
     EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "assign_cost: ncols=%d != 27+%d", ncols, num_classes);
-    hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(A, 128), B), dim3(128), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
+    hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(A, COST_APB), B), dim3(COST_NT), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
                        (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, pw, cost, A, num_classes);
     EP24_LAUNCH_CHECK("ep24_assign_cost");
     return EP24_OK;

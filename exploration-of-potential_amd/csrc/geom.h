@@ -18,17 +18,20 @@ __device__ __forceinline__ float ray_giou(float r1 /*gt*/, float r2 /*pred*/, fl
     const float pi = EP24_PI_F;
     const float rmin = fminf(r1, r2), rmax = fmaxf(r1, r2);
     const float rmin2 = rmin * rmin, rmax2 = rmax * rmax, d2 = d * d;
-    float c1 = (rmin2 + d2 - rmax2) / (2.0f * rmin * d + 1e-8f);
-    float c2 = (rmax2 + d2 - rmin2) / (2.0f * rmax * d + 1e-8f);
-    c1 = fminf(fmaxf(c1, -0.99f), 0.99f);
-    c2 = fminf(fmaxf(c2, -0.99f), 0.99f);
-    const float a1 = acosf(c1), a2 = acosf(c2);
-    const float lens = a1 * rmin2 + a2 * rmax2 - rmin * d * sinf(a1);
     const bool contained = fabsf(r1 - r2) >= d;
     const bool disjoint = d >= r1 + r2;
     float inter = contained ? pi * rmin2 : 0.0f;
     if (disjoint) inter = 0.0f;
-    if (!(contained || disjoint)) inter = lens;
+    if (!(contained || disjoint)) {
+        // the lens of two properly intersecting circles: the only case that needs the two acos and the sin, so a wave whose
+        // pairs are all far apart (most (candidate, GT) pairs of SimOTA) skips them - the value is not used otherwise
+        float c1 = (rmin2 + d2 - rmax2) / (2.0f * rmin * d + 1e-8f);
+        float c2 = (rmax2 + d2 - rmin2) / (2.0f * rmax * d + 1e-8f);
+        c1 = fminf(fmaxf(c1, -0.99f), 0.99f);
+        c2 = fminf(fmaxf(c2, -0.99f), 0.99f);
+        const float a1 = acosf(c1), a2 = acosf(c2);
+        inter = a1 * rmin2 + a2 * rmax2 - rmin * d * sinf(a1);
+    }
     const float area1 = pi * (r1 * r1), area2 = pi * (r2 * r2);
     const float uni = area1 + area2 - inter;
     const float iou = inter / (uni + 1e-6f);
