@@ -146,17 +146,20 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
 // Streaming kernel for 1x1 stride-1 layers with K <= 256 (forward and input-gradient).  These layers are HBM
 // bound (K/2 .. K FLOP per byte), and as 2-4 K-step tiles of the tiled kernels every workgroup spent its life in
 // prologue / DMA round trip / epilogue.  Here the weight tile [BN][K] is loaded into LDS ONCE per workgroup and
-// every wave streams its own 64-row blocks of the activation matrix straight from global memory into MFMA
+// every wave streams its own 32-row blocks of the activation matrix straight from global memory into MFMA
 // A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
 // block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
-// registers until the end.  Waves of a workgroup share the rows (WN waves, 64 columns each) through L1.
+// registers until the end.
+// A wave multiplies its rows with ALL BN columns of the tile (BN / 64 spans of 64): in round 1 the waves of a workgroup
+// split the columns and each fetched the same rows, so a row went through the vector-memory path once per 64 columns
+// and per N tile - the kernel ran at 5 TB/s for N = 64 but 3.1 for 128 x 128 and 2.5 for 256 x 256, the HBM share of a
+// saturated load path.
 template <int BN, int H, int EPI = 0>                          // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
-    constexpr int WN = BN / 64, WM = 4 / WN, MT = 2, RG = WM * MT * 16;   // 32-row blocks per wave: ~170 VGPRs, 3 waves per SIMD
+    constexpr int SP = BN / 64, NTW = SP * 4, MT = 2, RG = 4 * MT * 16;       // 4 waves x 32 rows per unit
     constexpr int OOB = 0x7FFFFFF0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
     const int n_tiles = (p.N + BN - 1) / BN;
     // workgroup L runs on XCD L & 7: the n_tiles workgroups that walk the same rows get the same XCD (shared L2)
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     auto load = [&](bf16x8 (&A)[MT][4], long u) {
         const long g = rb + (u / H) * bpn;
         const int h = (int)(u % H);
-        const long r0 = g * RG + wm * (MT * 16);
+        const long r0 = g * RG + wave * (MT * 16);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const long row = r0 + i * 16 + frow;
@@ -202,21 +205,22 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         }
     };
 
-    f32x4 acc[MT][4];
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const int c0 = n0 + wn * 64 + 4 * frow;
-    constexpr bool infer = EPI == 2;                        // eval mode: y = act(acc + bias) + residual
-    float ibias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (infer) {
+    f32x4 acc[MT][NTW];
+    float s1[NTW], s2[NTW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < p.N) ibias[q] = p.bias[c0 + q];
+    for (int q = 0; q < NTW; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+    constexpr bool infer = EPI == 2;                        // eval mode: y = act(acc + bias) + residual
+    float ibias[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int c = n0 + (q >> 2) * 64 + 4 * frow + (q & 3);
+        ibias[q] = (infer && c < p.N) ? p.bias[c] : 0.f;
     }
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < NTW; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     auto compute = [&](bf16x8 (&A)[MT][4], long u) {
         const int h = (int)(u % H);
@@ -225,50 +229,57 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         for (int ks = 0; ks < 4; ++ks) {
             const int kk = h * 4 + ks;
             if (kk < nks) {
-                bf16x8 fb[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    fb[q] = *reinterpret_cast<const bf16x8*>(smem + (kk >> 1) * (BN * 128) + swz(wn * 64 + q * 16 + frow, (kk & 1) * 4 + fq));
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int sp = 0; sp < SP; ++sp) {
+                    bf16x8 fb[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], fb[q], acc[i][q], 0, 0, 0);
+                        fb[q] = *reinterpret_cast<const bf16x8*>(smem + (kk >> 1) * (BN * 128) + swz(sp * 64 + q * 16 + frow, (kk & 1) * 4 + fq));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[i][sp * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], fb[q], acc[i][sp * 4 + q], 0, 0, 0);
+                }
             }
         }
         if (h != H - 1) return;
         const long g = rb + (u / H) * bpn;
-        const long r0 = g * RG + wm * (MT * 16);
+        const long r0 = g * RG + wave * (MT * 16);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long m = r0 + i * 16 + 4 * fq + r;
                 if (m >= p.M) continue;
-                float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = acc[i][q][r];
-                    if (infer) {
-                        v[q] = act_fwd(v[q] + ibias[q], p.epi_act);
-                        if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
-                    } else { s1[q] += v[q]; s2[q] += v[q] * v[q]; }
-                }
-                bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
-                if (c0 + 3 < p.N) {
-                    if (p.accumulate) {
-                        bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
+                for (int sp = 0; sp < SP; ++sp) {
+                    const int c0 = n0 + sp * 64 + 4 * frow;
+                    float v[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = acc[i][sp * 4 + q][r];
+                        if (infer) {
+                            v[q] = act_fwd(v[q] + ibias[sp * 4 + q], p.epi_act);
+                            if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
+                        } else { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }
                     }
-                    bf16x4 w;
+                    bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
+                    if (c0 + 3 < p.N) {
+                        if (p.accumulate) {
+                            bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
-                    *reinterpret_cast<bf16x4*>(d) = w;
-                } else {
+                            for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                        }
+                        bf16x4 w;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                        for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                        *reinterpret_cast<bf16x4*>(d) = w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
+                    }
                 }
             }
         }
@@ -285,25 +296,25 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 
     if (p.stats) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][64]; the weight tile is no longer needed
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][BN]; the weight tile is no longer needed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NTW; ++q) {
             float a = s1[q], b = s2[q];
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             if (fq == 0) {
-                red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+                const int c = (q >> 2) * 64 + 4 * frow + (q & 3);
+                red[(wave * 2 + 0) * BN + c] = a;
+                red[(wave * 2 + 1) * BN + c] = b;
             }
         }
         __syncthreads();
         long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, c = i - which * BN;
-            const int wcol = c >> 6;
             float v = 0.f;
 #pragma unroll
-            for (int r = 0; r < WM; ++r) v += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+            for (int r = 0; r < 4; ++r) v += red[(r * 2 + which) * BN + c];
             if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 
 template <int BN, int H>
 void launch_stream(const IgemmArgs& a, hipStream_t stream) {
-    constexpr int RG = (4 / (BN / 64)) * 32;
+    constexpr int RG = 128;
     const int n_tiles = ep24_cdiv(a.N, BN);
     const long n_groups = (a.M + RG - 1) / RG;
     // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
@@ -319,7 +330,7 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
     const int npan = (a.K + 63) / 64;
     size_t lds = (size_t)npan * BN * 128;
-    if (lds < 2048) lds = 2048;
+    if (lds < 4096) lds = 4096;                                // the statistics fold: [4 waves][2][BN] floats
     if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
     else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
 }
@@ -351,6 +362,8 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
         (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0) {
+        // 128-wide tiles where N fills them (a 256-wide tile - one pass of the rows for N = 256 - needs 400 registers and a whole CU
+        // per workgroup: 68 against 50 us on 80x80x256->256 with cold operands, tools/stream_ab.py)
         if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
         else          { if (a.K > 128) launch_stream<64, 2>(a, stream); else launch_stream<64, 1>(a, stream); }
         EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
