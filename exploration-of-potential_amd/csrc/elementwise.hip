@@ -498,6 +498,113 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const bf16* dy5, const bf1
     }
 }
 
+// The routing done separably in LDS.  A k x k max pool is a row pass after a column pass, and the stored 2-D winner code of an
+// output (y, x) is (dy, dx) = (row offset chosen in column x, column offset chosen in row y + dy).  One workgroup per (image,
+// 8-channel group) stages the three incoming gradients and codes of the whole H x W map (72 bytes per pixel), then per pool:
+//   vertical    g_h[r][x] = sum over y in the window with dy(y, x) = r - y of dy_pool[y][x]   (fp32, in LDS; the dx of those
+//               outputs is the same for all of them - it is the row pass's choice at (r, x) - and is kept next to the sum)
+//   horizontal  dx[r][c] += sum over x in the window with that choice = c - x of g_h[r][x]
+// 2 x (5 + 9 + 13) window positions per pixel instead of 25 + 81 + 169: the gather above spent 229 us per step at -l (compute
+// bound on byte compares, not on memory).  Sums are associated differently (per column first), so results agree with the gather
+// to fp32 rounding of a handful of terms, not bit for bit; the order is fixed, so they are reproducible.
+__global__ __launch_bounds__(256) void spp_bwd_lds_kernel(const bf16* dy5, const bf16* dy9, const bf16* dy13, long ld_dy,
+                                                          const uint8_t* idx, bf16* dx, long ld_dx, int accumulate, int B,
+                                                          int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) char spp_lds[];
+    const int HW = H * W;
+    bf16x8* gv = reinterpret_cast<bf16x8*>(spp_lds);                          // [3][HW] gradients of the 5 / 9 / 13 pools
+    uint2* cv = reinterpret_cast<uint2*>(spp_lds + (size_t)3 * HW * 16);      // [3][HW] winner codes, one byte per channel
+    float* gh = reinterpret_cast<float*>(spp_lds + (size_t)3 * HW * 24);      // [HW][8] column sums of the pool in work
+    uint2* ds = reinterpret_cast<uint2*>(spp_lds + (size_t)3 * HW * 24 + (size_t)HW * 32);   // [HW] dx + 8 per channel, 0xFF = none
+    const int cg = blockIdx.x, n = blockIdx.y;
+    const long plane = (long)B * HW * C;
+    const long base = (long)n * HW;
+    for (int q = threadIdx.x; q < HW; q += 256) {
+        const long op = base + q;
+        gv[q] = *reinterpret_cast<const bf16x8*>(dy5 + op * ld_dy + cg * 8);
+        gv[HW + q] = *reinterpret_cast<const bf16x8*>(dy9 + op * ld_dy + cg * 8);
+        gv[2 * HW + q] = *reinterpret_cast<const bf16x8*>(dy13 + op * ld_dy + cg * 8);
+        const uint8_t* ip = idx + op * C + cg * 8;
+        cv[q] = *reinterpret_cast<const uint2*>(ip);
+        cv[HW + q] = *reinterpret_cast<const uint2*>(ip + plane);
+        cv[2 * HW + q] = *reinterpret_cast<const uint2*>(ip + 2 * plane);
+    }
+    __syncthreads();
+    constexpr int NPASS = 4;                                                   // pixels per thread: H * W <= 1024
+    float acc[NPASS][8];
+#pragma unroll
+    for (int t = 0; t < NPASS; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (int pool = 2; pool >= 0; --pool) {                                    // 13, 9, 5: the gather's order per window position
+        const int R = 2 * pool + 2;
+        // ---- vertical
+        for (int q = threadIdx.x; q < HW; q += 256) {
+            const int r = q / W, x = q - r * W;
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned char sel[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sel[j] = 0xFF;
+            for (int dy = -R; dy <= R; ++dy) {
+                const int y = r - dy;
+                if (y < 0 || y >= H) continue;
+                const int o = y * W + x;
+                const uint2 c = cv[pool * HW + o];
+                const bf16x8 t = gv[pool * HW + o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned byte = ((j < 4 ? c.x : c.y) >> (8 * (j & 3))) & 0xFFu;
+                    if ((int)(byte >> 4) == dy + 8) { s[j] += (float)t[j]; sel[j] = (unsigned char)(byte & 15u); }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gh[q * 8 + j] = s[j];
+            uint2 d;
+            d.x = sel[0] | (sel[1] << 8) | (sel[2] << 16) | ((unsigned)sel[3] << 24);
+            d.y = sel[4] | (sel[5] << 8) | (sel[6] << 16) | ((unsigned)sel[7] << 24);
+            ds[q] = d;
+        }
+        __syncthreads();
+        // ---- horizontal
+#pragma unroll
+        for (int t = 0; t < NPASS; ++t) {
+            const int q = threadIdx.x + 256 * t;
+            if (q < HW) {
+                const int r = q / W, c = q - r * W;
+                for (int dxo = -R; dxo <= R; ++dxo) {
+                    const int x = c - dxo;
+                    if (x < 0 || x >= W) continue;
+                    const int o = r * W + x;
+                    const uint2 d = ds[o];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned byte = ((j < 4 ? d.x : d.y) >> (8 * (j & 3))) & 0xFFu;
+                        if ((int)byte == dxo + 8) acc[t][j] += gh[o * 8 + j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NPASS; ++t) {
+        const int q = threadIdx.x + 256 * t;
+        if (q < HW) {
+            bf16* d = dx + (base + q) * ld_dx + cg * 8;
+            float out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = acc[t][j];
+            if (accumulate) {
+                float o[8];
+                load8(d, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] += o[j];
+            }
+            store8(d, out);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- upsample / copy
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const bf16* x, long ld_x, bf16* y, long ld_y, int B, int H,
                                                             int W, int C) {
@@ -944,8 +1051,13 @@ extern "C" int ep24_spp_fwd(const void* x, int64_t ld_x, void* y5, void* y9, voi
 extern "C" int ep24_spp_bwd(const void* dy5, const void* dy9, const void* dy13, int64_t ld_dy, const uint8_t* idx, void* dx,
                             int64_t ld_dx, int accumulate, int B, int H, int W, int C, void* stream) {
     EP24_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0, EP24_E_ARG, "spp_bwd: bad arguments");
-    hipLaunchKernelGGL(spp_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy5,
-                       (const bf16*)dy9, (const bf16*)dy13, ld_dy, idx, (bf16*)dx, ld_dx, accumulate, B, H, W, C);
+    const size_t lds = (size_t)H * W * 112;                     // the whole map of one (image, channel group) in LDS
+    if (lds <= 64 * 1024 && H * W <= 1024)
+        hipLaunchKernelGGL(spp_bwd_lds_kernel, dim3(C / 8, B), dim3(256), lds, S_, (const bf16*)dy5, (const bf16*)dy9, (const bf16*)dy13,
+                           ld_dy, idx, (bf16*)dx, ld_dx, accumulate, B, H, W, C);
+    else
+        hipLaunchKernelGGL(spp_bwd_kernel, dim3(cap_grid((long)B * H * W * (C / 8))), dim3(256), 0, S_, (const bf16*)dy5,
+                           (const bf16*)dy9, (const bf16*)dy13, ld_dy, idx, (bf16*)dx, ld_dx, accumulate, B, H, W, C);
     EP24_LAUNCH_CHECK("ep24_spp_bwd");
     return EP24_OK;
 }
