@@ -323,6 +323,11 @@ int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t
       a.s_dys = doh * stride; a.s_dxs = dow * stride;
       a.s_doff = dn * a.c_n + doh * a.c_oh + dow * a.c_ow; }
     a.dy_bytes = (unsigned)(((a.M - 1) * ld_dy + Cout) * 2);
+#ifdef EP24_STAMPS
+    // diagnostic build only: EP24_WGRAD_NOLOAD=1 makes every tile load out of range (zero fill, same instruction stream) - what
+    // the kernel would cost with no fill traffic at all
+    if (getenv("EP24_WGRAD_NOLOAD")) a.x_bytes = a.dy_bytes = 0;
+#endif
     return EP24_OK;
 }
 
