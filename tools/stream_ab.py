@@ -56,7 +56,7 @@ def main():
                     call("conv_dgrad_bf16", ptr(dys[s]), Cout, ptr(wd), ptr(dxs[s]), Cin, 0, B, H, W, Cin, Cout, 1, 1, stream_ptr())
             t = min(graph_time(run) for _ in range(2))
             mb = M * (Cin + Cout) * 2 / 1e6
-            print("%-8s %-22s %10.1f   %.2f TB/s" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), t, mb / t / 1e6 * 1e6 / 1e6), flush=True)
+            print("%-8s %-22s %10.1f   %.2f TB/s" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), t, mb / t), flush=True)
 
 
 main()
