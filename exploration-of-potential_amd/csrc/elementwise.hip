@@ -38,8 +38,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
                                                          float momentum) {
     constexpr int act = ACT;                     // compile-time: the SiLU instantiation carries no trace of the other modes
     extern __shared__ float lds[];
+    // rows of 8 constants padded to 9 floats: a thread reads the 8 of ITS channel group, and with a lane stride of 9 words the
+    // 64 lanes of a wave fall on 64 different banks (an 8-word stride put lanes l and l + 8 on one bank: SQ_LDS_BANK_CONFLICT was
+    // 83 % of the LDS-active cycles and those 13 % of the kernel's CU-busy cycles, profiles/r02_pmc_sq.json)
+    const int CP = C + (C >> 3);
     float* sc = lds;
-    float* sh = lds + C;
+    float* sh = lds + CP;
+    auto pad = [](int c) { return c + (c >> 3); };
     for (int c = threadIdx.x; c < C; c += 256) {
         long long i1 = 0, i2 = 0;
         for (int r = 0; r < reps; ++r) {
@@ -51,8 +56,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
         var = var < 0.f ? 0.f : var;
         const float invstd = rsqrtf(var + eps);
         const float s_ = gamma[c] * invstd;
-        sc[c] = s_;
-        sh[c] = beta[c] - mean * s_;
+        sc[pad(c)] = s_;
+        sh[pad(c)] = beta[c] - mean * s_;
         if (blockIdx.x == 0) {
             save[c] = mean;
             save[C + c] = invstd;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
     const int g_fixed = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cgs);
     float rsc[8], rsh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { rsc[j] = sc[g_fixed * 8 + j]; rsh[j] = sh[g_fixed * 8 + j]; }
+    for (int j = 0; j < 8; ++j) { rsc[j] = sc[g_fixed * 9 + j]; rsh[j] = sh[g_fixed * 9 + j]; }
     const long m_fixed = ((long)blockIdx.x * 256 + threadIdx.x) / cgs, m_step = stride / cgs;
     int it = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += U * stride, ++it) {
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 8 + j];
-                const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 8 + j];
+                const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 9 + j];
+                const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 9 + j];
                 const float u = fmaf((float)v[k][j], a_, b_);
                 o[j] = (bf16)(act_fwd(u, act) + (res ? (float)r[k][j] : 0.f));
             }
@@ -971,7 +976,7 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
     const int fw_per = 2;                                   // chunks per lane and launch: tools/bn_probe.py sweeps of round 1
     auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : act == 3 ? bn_act_fwd_kernel<3> : bn_act_fwd_kernel<0>;
-    hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * C * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
+    hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * (C + C / 8) * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, (long*)num_batches2, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum);
     EP24_LAUNCH_CHECK("ep24_bn_act_fwd");
