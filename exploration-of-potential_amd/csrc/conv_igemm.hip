@@ -7,15 +7,15 @@
 // Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel 4j+t) so every
 // lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
 #include <stdlib.h>
+#include <atomic>
 #include "igemm.h"
 
 using namespace ep24_igemm;
 
 namespace {
 
-// ep24_conv_set_patch(0) routes the 3x3 stride-1 layers through the generic tiled kernel again (A/B measurements, tests that
-// compare the two kernels on one shape); read once per launch, no environment lookups on the launch path
-int g_use_patch = 1, g_narrow_epi = 0;
+// kernel_opts of the _ex entry points (include/ep24.h): per call, no process-wide state
+constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_TWO_STAGE = 16;   // bits 2-3: ring depth override (A/B), bit 4: two-stage loop
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
@@ -24,7 +24,12 @@ int g_use_patch = 1, g_narrow_epi = 0;
 // SOURCE address: LDS unit U = row*8 + pchunk is fetched from (row, pchunk ^ (row & 7)); padding taps and the
 // M / N / K tails use an out-of-range buffer offset, for which the DMA writes zeros.  Two LDS stages, one barrier per K-step: the DMA of tile t+1 is
 // in flight while tile t feeds the MFMAs.
-template <int BN, bool OUT_F32, int EPI = 0>                // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+// NS = 2: two stages, one __syncthreads() (vmcnt(0) + barrier) per K step - a step costs max(MFMA time, one DMA round trip).
+// NS > 2: a ring of NS stages with NS - 1 tiles in flight, retired by a COUNTED vmcnt and a raw s_barrier (every step issues the
+// same number of DMA instructions - beyond the last tile they are out-of-range zero fills into a stage nobody reads - so the
+// count is an immediate): the layers whose K loop is a handful of steps (1x1 convs with K = 256 .. 2048, the stride-2 parity
+// classes) pay the round trip once instead of once per step.  Same products in the same order: results are bit-identical.
+template <int BN, bool OUT_F32, int EPI = 0, int NS = 2>    // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         const int t = is_t, kc = is_kc;
         if (++is_t == p.T) { is_t = 0; ++is_kc; }
         const bool tail = kc >= ktail;                       // wave-uniform, false for every layer of the YOLOX-l path
-        const int ktm = tail ? -(int)(kc < kmax) : -1;
+        int ktm = tail ? -(int)(kc < kmax) : -1;
+        if (NS > 2 && kc >= KC) ktm = 0;                     // ring filler beyond the last tile: every offset out of range
         const int a_s = p.toff[t] + kc * (BK * 2);
         const unsigned b_s = (unsigned)((p.wslot[t] * p.K + kc * BK) * 2);
         char* stage = smem + buf * STAGE;
@@ -116,11 +122,29 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
 
-    issue(0);
+    if constexpr (NS == 2) issue(0);
+    else {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);       // NS - 1 tiles in flight (fillers if the loop is shorter)
+    }
+    int st = 0;                                              // ring stage of tile `it`
+#pragma unroll 1
     for (int it = 0; it < n_iter; ++it) {
-        __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
-        if (it + 1 < n_iter) issue((it + 1) & 1);
-        const char* la = smem + (it & 1) * STAGE;
+        const char* la;
+        if constexpr (NS == 2) {
+            __syncthreads();                   // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
+            if (it + 1 < n_iter) issue((it + 1) & 1);
+            la = smem + (it & 1) * STAGE;
+        } else {
+            // this wave's DMAs of tile `it` have landed when at most the (NS - 2) younger tiles' are outstanding; after the
+            // barrier every wave's have, and everybody is done reading stage (it - 1) % NS, which the next issue refills
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (A_INSTR + B_INSTR)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(st == 0 ? NS - 1 : st - 1);
+            __builtin_amdgcn_sched_barrier(0);     // without it the register allocator rotates the accumulators through copies (96 v_accvgpr moves per step)
+            la = smem + st * STAGE;
+            st = st + 1 == NS ? 0 : st + 1;
+        }
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -335,11 +359,37 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
 }
 
-template <int BN, bool F32>
-void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
-    constexpr size_t lds = 2 * (BM * 128 + BN * 128);
-    if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(tiles), dim3(256), lds, stream, a);
+template <typename K>
+int big_lds(K kfn, size_t lds) {                 // more than 64 KB of dynamic LDS: the attribute, once per device and instantiation
+    if (lds <= 64 * 1024) return EP24_OK;
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv: hipGetDevice failed");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", dev, hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return EP24_OK;
+}
+
+template <int BN, bool F32, int NS = 2>
+int launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
+    constexpr size_t lds = NS * (BM * 128 + BN * 128);
+    if (a.epi_infer && !F32) {
+        hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
+        return EP24_OK;
+    }
+    if (int rc = big_lds(igemm_dma_kernel<BN, F32, 0, NS>, lds)) return rc;
+    hipLaunchKernelGGL((igemm_dma_kernel<BN, F32, 0, NS>), dim3(tiles), dim3(256), lds, stream, a);
+    return EP24_OK;
+}
+
+// Ring depth of the tiled kernel for a shape (2 = the two-stage loop).  Set from tools/ring_ab.py measurements.
+int ring_stages(const IgemmArgs& a, bool wide) {
+    (void)a; (void)wide;
+    return 2;
 }
 
 // The kernels address their operands with 32-bit byte offsets through buffer descriptors (out-of-range = zero fill is how
@@ -353,15 +403,17 @@ int check_extents(const IgemmArgs& a) {
     return EP24_OK;
 }
 
-int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
-    if (int rc = check_extents(a)) return rc;
-    a.narrow_epi = g_narrow_epi;
+// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming)
+int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, bool dry = false, int* kernel_id = nullptr) {
+    if (!dry) { if (int rc = check_extents(a)) return rc; }
+    a.narrow_epi = (kernel_opts & KOPT_NARROW_EPI) ? 1 : 0;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
         (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0) {
+        if (dry) { *kernel_id = 2; return EP24_OK; }
         // 128-wide tiles where N fills them (a 256-wide tile - one pass of the rows for N = 256 - needs 400 registers and a whole CU
         // per workgroup: 68 against 50 us on 80x80x256->256 with cold operands, tools/stream_ab.py)
         if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
@@ -370,41 +422,42 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream) {
         return EP24_OK;
     }
     // 3x3 stride-1 (forward and input gradient): the halo-patch kernel, when the shape fits its LDS budget
-    if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer && g_use_patch &&
-        launch_patch(a, stream)) {
-        EP24_LAUNCH_CHECK("ep24_conv_patch");
-        return EP24_OK;
+    if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer &&
+        !(kernel_opts & KOPT_TILED)) {
+        int prc = EP24_OK;
+        if (launch_patch(a, stream, dry, &prc)) {
+            if (dry) { *kernel_id = 1; return EP24_OK; }
+            if (prc) return prc;
+            EP24_LAUNCH_CHECK("ep24_conv_patch");
+            return EP24_OK;
+        }
     }
+    if (dry) { *kernel_id = 0; return EP24_OK; }
     // 128-wide N tiles unless that leaves at most one workgroup per CU (the 20x20 level at B = 20): 64-wide tiles then
     // double the workgroups (+3 .. +27 % on those layers)
     const bool wide = a.N > 64 && (long)ep24_cdiv(a.M, BM) * ep24_cdiv(a.N, 128) > 256;
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, wide ? 128 : 64);
     for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
-    if (wide) {
-        if (out_f32) launch_variant<128, true>(a, tiles, stream);
-        else launch_variant<128, false>(a, tiles, stream);
-    } else {
-        if (out_f32) launch_variant<64, true>(a, tiles, stream);
-        else launch_variant<64, false>(a, tiles, stream);
-    }
+    // ring depth: kernel_opts bits 2-3 choose it for A/B runs (1: three stages, 2: four); 0 = the dispatch rule
+    int ns = ring_stages(a, wide);
+    if ((kernel_opts >> 2) & 3) ns = 2 + ((kernel_opts >> 2) & 3);
+    if (kernel_opts & KOPT_TWO_STAGE) ns = 2;
+    int rc = EP24_OK;
+    if (out_f32) rc = wide ? launch_variant<128, true>(a, tiles, stream) : launch_variant<64, true>(a, tiles, stream);
+    else if (wide) rc = ns == 4 ? launch_variant<128, false, 4>(a, tiles, stream) : ns == 3 ? launch_variant<128, false, 3>(a, tiles, stream) : launch_variant<128, false>(a, tiles, stream);
+    else rc = ns == 4 ? launch_variant<64, false, 4>(a, tiles, stream) : ns == 3 ? launch_variant<64, false, 3>(a, tiles, stream) : launch_variant<64, false>(a, tiles, stream);
+    if (rc) return rc;
     EP24_LAUNCH_CHECK("ep24_conv_igemm");
     return EP24_OK;
 }
 
 }  // namespace
 
-extern "C" int ep24_conv_set_patch(int on) {
-    const int old = g_use_patch | (g_narrow_epi << 1);
-    g_use_patch = on & 1;
-    g_narrow_epi = (on >> 1) & 1;
-    return old;
-}
-
-extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
-                                  int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,
-                                  int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
-                                  void* stream) {
-    EP24_REQUIRE(x && w && y, EP24_E_ARG, "conv_fwd: null pointer");
+static int conv_fwd_impl(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                         int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,
+                         int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                         int kernel_opts, void* stream, bool dry = false, int* kernel_id = nullptr) {
+    EP24_REQUIRE(dry || (x && w && y), EP24_E_ARG, "conv_fwd: null pointer");
     EP24_REQUIRE(Cin % 8 == 0 && Cin > 0, EP24_E_ARG, "conv_fwd: Cin=%d must be a multiple of 8", Cin);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
                  "conv_fwd: k=%d s=%d unsupported", ksize, stride);
@@ -422,7 +475,22 @@ extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, vo
     a.dbs = y_batch_rows > 0 ? y_batch_rows : (long)OH * OW; a.dp0 = y_row0;
     a.accumulate = 0; a.bias = bias; a.stats = (long long*)stats; a.stats_replicas = stats ? stats_replicas : 1;
     a.M = (long)B * OH * OW;
-    return launch(a, y_f32 != 0, (hipStream_t)stream);
+    return launch(a, y_f32 != 0, (hipStream_t)stream, kernel_opts, dry, kernel_id);
+}
+
+extern "C" int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                                  int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,
+                                  int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                  void* stream) {
+    return conv_fwd_impl(x, ld_x, w, y, ld_y, y_f32, y_batch_rows, y_row0, bias, stats, stats_replicas, B, H, W, Cin, Cout, ksize, stride, 0, stream);
+}
+
+extern "C" int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                                     int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats,
+                                     int stats_replicas, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                     int kernel_opts, void* stream) {
+    return conv_fwd_impl(x, ld_x, w, y, ld_y, y_f32, y_batch_rows, y_row0, bias, stats, stats_replicas, B, H, W, Cin, Cout, ksize, stride,
+                         kernel_opts, stream);
 }
 
 // Eval-mode unit in one launch: BatchNorm's running statistics are folded into the packed weights and a bias
@@ -450,10 +518,10 @@ extern "C" int ep24_conv_fwd_infer_bf16(const void* x, int64_t ld_x, const void*
     return launch(a, false, (hipStream_t)stream);
 }
 
-extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
-                                    int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
-                                    void* stream) {
-    EP24_REQUIRE(dy && wt && dx, EP24_E_ARG, "conv_dgrad: null pointer");
+static int conv_dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
+                           int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                           int kernel_opts, void* stream, bool dry = false, int* kernel_id = nullptr) {
+    EP24_REQUIRE(dry || (dy && wt && dx), EP24_E_ARG, "conv_dgrad: null pointer");
     EP24_REQUIRE(Cout_k % 8 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 8", Cout_k);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
                  "conv_dgrad: k=%d s=%d unsupported", ksize, stride);
@@ -472,8 +540,9 @@ extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* w
         for (int t = 0; t < a.T; ++t) { a.oy[t] = pad - t / ksize; a.ox[t] = pad - t % ksize; a.wslot[t] = t; }
         a.dsy = a.dsx = 1; a.dy0 = a.dx0 = 0;
         a.M = (long)B * H * W;
-        return launch(a, false, (hipStream_t)stream);
+        return launch(a, false, (hipStream_t)stream, kernel_opts, dry, kernel_id);
     }
+    if (dry) { *kernel_id = 0; return EP24_OK; }          // the parity classes of a stride-2 input gradient: the tiled kernel
     // stride 2: input pixels of parity (ph,pw) only see taps with (p + pad - k) even; one launch per class
     EP24_REQUIRE(H % 2 == 0 && W % 2 == 0, EP24_E_UNSUPPORTED, "conv_dgrad s2: odd spatial size %dx%d", H, W);
     // a 1x1 stride-2 conv reaches only the even pixels: as first writer it would leave the other three quarters of dx stale
@@ -493,8 +562,30 @@ extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* w
                 }
             c.M = (long)B * c.GH * c.GW;
             if (c.T == 0) continue;   // (k=1, odd parity): nothing reaches these pixels; caller zero-fills via accumulate=0 path below
-            int rc = launch(c, false, (hipStream_t)stream);
+            int rc = launch(c, false, (hipStream_t)stream, kernel_opts);
             if (rc) return rc;
         }
     return EP24_OK;
+}
+
+extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
+                                    int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                                    void* stream) {
+    return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, 0, stream);
+}
+
+extern "C" int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
+                                       int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
+                                       int kernel_opts, void* stream) {
+    return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, kernel_opts, stream);
+}
+
+extern "C" int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias) {
+    int id = -1;
+    const float* fake_bias = has_bias ? reinterpret_cast<const float*>(16) : nullptr;      // only tested for null
+    const int c8 = (Cout + 7) / 8 * 8;
+    const int rc = dgrad ? conv_dgrad_impl(nullptr, c8, nullptr, nullptr, (Cin + 3) / 4 * 4, 0, B, H, W, Cin, c8, ksize, stride, 0, nullptr, true, &id)
+                         : conv_fwd_impl(nullptr, Cin, nullptr, nullptr, y_f32 ? Cout : (Cout + 3) / 4 * 4, y_f32, 0, 0, fake_bias, nullptr, 1, B, H, W, Cin, Cout,
+                                         ksize, stride, 0, nullptr, true, &id);
+    return rc ? rc : id;
 }

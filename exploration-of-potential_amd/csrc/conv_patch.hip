@@ -16,6 +16,7 @@
 // multiplied; the weight tile of the next tap is one step ahead in a two-stage ring.  One barrier per tap step.
 // A fragments come from the resident patch, so the reads of step j+1 do not wait for any DMA.
 // Tile mapping, LDS row swizzle (on the DMA source side), channel relabelling and the epilogue are the tiled kernel's.
+#include <atomic>
 #include <type_traits>
 #include "igemm.h"
 
@@ -275,20 +276,32 @@ __global__ __launch_bounds__((BMP / 64) * (BN / 64) * 64) void conv_patch_kernel
 }
 
 template <int BMP, int BN, int NB, int PPS>
-void launch_pps(const IgemmArgs& a, int PR, int halo, int npb, size_t lds, hipStream_t stream) {
+int launch_pps(const IgemmArgs& a, int PR, int halo, int npb, size_t lds, hipStream_t stream) {
     constexpr int NT_ = (BMP / 64) * (BN / 64) * 64;
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, BMP) * (unsigned)ep24_cdiv(a.N, BN);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BMP, BN, NB, PPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    // more than 64 KB of dynamic LDS needs the attribute on the function, once per DEVICE (a process that launches on a second
+    // device would otherwise fail there with a generic launch error); the set is cheap and idempotent, a mutex-free bitmask of
+    // the devices already done keeps it off the launch path
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv_patch: hipGetDevice failed");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv_patch_kernel<BMP, BN, NB, PPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv_patch: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KB) failed on device %d: %s", dev,
+                     hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_release);
+    }
     hipLaunchKernelGGL((conv_patch_kernel<BMP, BN, NB, PPS>), dim3(tiles), dim3(NT_), lds, stream, a, PR, halo, npb);
+    return EP24_OK;
 }
 
 template <int BMP, int BN, int NB>
-void launch_cfg(const IgemmArgs& a, int PR, int halo, int npb, size_t lds, hipStream_t stream) {
+int launch_cfg(const IgemmArgs& a, int PR, int halo, int npb, size_t lds, hipStream_t stream) {
     const int npw = PR / (8 * (BMP / 64) * (BN / 64));
-    if (npw <= 7) launch_pps<BMP, BN, NB, 1>(a, PR, halo, npb, lds, stream);
-    else if (npw <= 14) launch_pps<BMP, BN, NB, 2>(a, PR, halo, npb, lds, stream);
-    else launch_pps<BMP, BN, NB, 3>(a, PR, halo, npb, lds, stream);
+    if (npw <= 7) return launch_pps<BMP, BN, NB, 1>(a, PR, halo, npb, lds, stream);
+    if (npw <= 14) return launch_pps<BMP, BN, NB, 2>(a, PR, halo, npb, lds, stream);
+    return launch_pps<BMP, BN, NB, 3>(a, PR, halo, npb, lds, stream);
 }
 
 }  // namespace
@@ -305,9 +318,13 @@ namespace ep24_igemm {
 // -6 % time on 40x40x256->256, -4 % on 80x80x128->128, -2.5 % on 80x80x256->256, -4 % on 256->512; with 128-row tiles
 // (the 20x20 level, one wave per SIMD) and with 64-wide N (160x160x64) it LOSES 13 - 30 %, so those shapes stay with the
 // tiled kernel, as does anything whose patch does not fit the LDS next to the three-stage weight ring.
-bool launch_patch(const IgemmArgs& a, hipStream_t stream) {
+bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
+    // The kernel does not read the tap tables: it derives every shift from sgn = (oy[0] < 0 ? +1 : -1) and assumes the row-major
+    // layout oy[t] = sgn * (t / 3 - 1), ox[t] = sgn * (t % 3 - 1), weight slot t (forward: sgn +1, input gradient: -1).  Any other
+    // nine-tap table goes to the tiled kernel, which does read them.
+    const int sgn = a.oy[0] < 0 ? 1 : -1;
     for (int t = 0; t < 9; ++t)
-        if (a.oy[t] < -1 || a.oy[t] > 1 || a.ox[t] < -1 || a.ox[t] > 1 || a.wslot[t] != t) return false;
+        if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return false;
     if (a.K % 8 != 0 || a.N <= 64) return false;
     if ((long)ep24_cdiv(a.M, 256) * ep24_cdiv(a.N, 128) < 200) return false;      // would leave CUs idle
     const int halo = a.SW + 1;
@@ -316,7 +333,7 @@ bool launch_patch(const IgemmArgs& a, hipStream_t stream) {
     const int pr = (256 + 2 * halo + 8 * nw - 1) / (8 * nw) * (8 * nw);
     const size_t lds = (size_t)npb * pr * 128 + 3 * (size_t)128 * 128;
     if (lds > 160 * 1024 || pr / (8 * nw) > 21) return false;
-    launch_cfg<256, 128, 3>(a, pr, halo, npb, lds, stream);
+    if (!dry) *rc = launch_cfg<256, 128, 3>(a, pr, halo, npb, lds, stream);
     return true;
 }
 

@@ -26,7 +26,7 @@ struct IgemmArgs {
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernels
     FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
     long M;
-    int narrow_epi;                 // A/B switch (ep24_conv_set_patch bit 1): the 8-byte-per-lane epilogue stores
+    int narrow_epi;                 // A/B option (kernel_opts bit 1 of the _ex entry points): the 8-byte-per-lane epilogue stores
 };
 
 constexpr int BM = 128;
@@ -193,6 +193,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 
 // conv_patch.hip: 3x3 stride-1 layers (forward and input gradient).  Returns false when the shape does not fit its
 // LDS budget (the caller then uses the generic tiled kernel).
-bool launch_patch(const IgemmArgs& a, hipStream_t stream);
+// dry = true only answers whether the shape is taken; *rc receives the error code of a failed launch set-up.
+bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 
 }  // namespace ep24_igemm

@@ -12,8 +12,6 @@ is cut where a bucket's last writer has run, and each bucket's all-reduce is iss
 while the next backward segment (its own hipGraph) keeps the compute stream busy.  No collective sits inside
 a captured graph.  Works unchanged with the gloo backend on CPU tensors (tests).
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -25,17 +23,13 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        if os.environ.get("EP24_BUCKET_MB"):
-            bucket_bytes = int(os.environ["EP24_BUCKET_MB"]) << 20
         self.bucket_bytes = bucket_bytes
         # the head of the buffer (stem, dark2: few parameters) is what backward finishes LAST, and the all-reduce of that
         # bucket is the only one nothing overlaps: it is kept small so that the exposed tail is a fraction of a 32 MB ring pass
         self.first_bucket_bytes = min(first_bucket_bytes, bucket_bytes)
         # wire format of the buckets: None / torch.float32 = the gradients as they are (the reference's DDP), torch.bfloat16 =
         # cast to bf16, SUM-reduce, cast back (half the xGMI bytes: 108 instead of 217 MB per step for YOLOX-l; the sum of
-        # `world` bf16 values is rounded once more than the fp32 sum - opt-in: EP24_DP_BF16=1 or comm_dtype)
-        if comm_dtype is None and os.environ.get("EP24_DP_BF16") == "1":
-            comm_dtype = torch.bfloat16
+        # `world` bf16 values is rounded once more than the fp32 sum): a constructor argument, no environment switch
         self.comm_dtype = comm_dtype if comm_dtype in (torch.bfloat16,) else None
         self._wire = None
         self.flat = None

@@ -18,12 +18,11 @@ backward) over pre-allocated NHWC bf16 buffers:
 The lists contain no host synchronisation, no allocation and no shape-dependent Python, so a training step
 is captured into a hipGraph (``ep24.train.TrainStep``).
 """
-import os
-
 import torch
 
 from . import _lib, nn as enn
 from ._lib import call, ptr, stream_ptr
+from .options import PlanOptions, get_options
 
 BF16 = torch.bfloat16
 WGRAD_REDUCE_GROUP = 16        # layers per weight-gradient reduce launch
@@ -158,15 +157,12 @@ class VecSeg:
         self.off = None
 
 
-MERGE_CSP = not os.environ.get("EP24_NO_CSP_MERGE")
-MERGE_CSP_SHORTCUT = not os.environ.get("EP24_NO_CSP_MERGE_SHORTCUT")
-MERGE_HEAD = not os.environ.get("EP24_NO_HEAD_MERGE")     # the backbone's CSP layers too (one gradient copy each)
-
-
 class ParamHome:
-    """Flat fp32 parameter / gradient / momentum buffers + packed bf16 weight copies for one model."""
+    """Flat fp32 parameter / gradient / momentum buffers + packed bf16 weight copies for one model.  ``options``
+    (ep24.options.PlanOptions) decides which units are merged, i.e. the layout; every plan of the model shares it."""
 
-    def __init__(self, model):
+    def __init__(self, model, options=None):
+        self.options = options if options is not None else get_options(model)
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.Ep24Error("ep24: move the model to the GPU before running it (model.to('cuda'))")
@@ -174,7 +170,7 @@ class ParamHome:
         self.convs, self.vecs, self.order, self.by_param = [], [], [], {}
         self.merged_bn = []                               # (bn of conv2, bn of conv1) of the merged CSP units
         stems = {m.conv for m in model.modules() if isinstance(m, enn.Focus)}
-        for mod in exec_order(model):
+        for mod in exec_order(model, self.options):
             if isinstance(mod, tuple) and mod[0] == "unit":          # (conv, bn) pair of a swapped backbone
                 _, conv, bn_, stem = mod
                 w = conv.weight
@@ -330,24 +326,25 @@ class ParamHome:
 def _same_bn(a, b):
     """Two BatchNorm modules that share one launch must agree on everything but their parameters and statistics."""
     if (a.eps, a.momentum, a.num_features) != (b.eps, b.momentum, b.num_features):
-        raise _lib.Ep24Error("ep24: merged units need identical BatchNorm eps / momentum / width (%s vs %s); set EP24_NO_CSP_MERGE=1 "
-                             "EP24_NO_HEAD_MERGE=1 to run them separately" % ((a.eps, a.momentum), (b.eps, b.momentum)))
+        raise _lib.Ep24Error("ep24: merged units need identical BatchNorm eps / momentum / width (%s vs %s); run them separately with "
+                             "ep24.options.set_options(model, PlanOptions(merge_csp=False, merge_head=False))" % ((a.eps, a.momentum), (b.eps, b.momentum)))
 
 
-def csp_is_merged(m):
+def csp_is_merged(m, opts):
     """CSP layers without shortcut bottlenecks (the neck's four and dark5's) run conv1 and conv2 - two 1x1 convs over the
     same input - as ONE GEMM with one BatchNorm launch: their weights, BN parameters and running statistics sit next to each
     other in the flat buffers (order conv2, conv1: the layout of the concatenation the block builds)."""
-    return MERGE_CSP and len(m.m) > 0 and (MERGE_CSP_SHORTCUT or not any(b.use_add for b in m.m))
+    return opts.merge_csp and len(m.m) > 0 and (opts.merge_csp_shortcut or not any(b.use_add for b in m.m))
 
 
-def exec_order(model):
+def exec_order(model, opts=None):
+    opts = opts if opts is not None else get_options(model)
     """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
     any other container (tests build single blocks) falls back to registration order."""
     def head_order(head):
         for k in range(len(head.stems)):
             yield head.stems[k]
-            if MERGE_HEAD:                            # the first 3x3 conv of the class and of the regression branch read the same tensor
+            if opts.merge_head:                       # the first 3x3 conv of the class and of the regression branch read the same tensor
                 yield ("pair_merged", head.cls_convs[k][0], head.reg_convs[k][0])
                 yield head.cls_convs[k][1]
                 yield head.reg_convs[k][1]
@@ -364,7 +361,7 @@ def exec_order(model):
         for m in model.modules():
             if m in skip:
                 continue
-            if isinstance(m, enn.CSPLayer) and csp_is_merged(m):
+            if isinstance(m, enn.CSPLayer) and csp_is_merged(m, opts):
                 yield ("csp_merged", m)
                 skip |= {m.conv1, m.conv2}
                 continue
@@ -383,7 +380,7 @@ def exec_order(model):
         return
 
     def csp(m):
-        if csp_is_merged(m):
+        if csp_is_merged(m, opts):
             yield ("csp_merged", m)
         else:
             yield m.conv1
@@ -498,17 +495,20 @@ class Engine:
         self._deferred = []
         self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
         self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
-        self.parallel_head = os.environ.get("EP24_NO_PAR_HEAD") != "1" and not self.f32
+        self.options = get_options(model)        # per-model plan options (ep24.options): no process-wide switches
+        if self.options.layout() != self.home.options.layout():
+            raise _lib.Ep24Error("ep24: this model's parameters are laid out for %r; the merge options cannot change afterwards" % (self.home.options,))
+        self.parallel_head = self.options.parallel_head and not self.f32
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
         self._side = None
         self.use_side = not self.f32            # weight gradients on a second stream
-        self.capture_side = os.environ.get("EP24_CAPTURE_SIDE") == "1"   # also inside captured graphs (experimental)
+        self.capture_side = self.options.capture_side   # also inside captured graphs (experimental)
         self._events = []
         self._bwd_builders = []
         self.pre_bn_inputs = {}                  # BatchNorm module -> the Act its pre-activation form reads (tests)
         # eval mode: BatchNorm folded into the conv (ep24_fold_bn + ep24_conv_fwd_infer_bf16): one launch per unit instead of two
-        self.fold_bn_eval = not os.environ.get("EP24_NO_FOLD")
+        self.fold_bn_eval = self.options.fold_bn_eval
         self._fold_units, self._fold_w, self._fold_c = [], 0, 0
         self.dyn = {"origin": None, "d_origin": None}   # run-time pointers (incoming gradient, L1-branch buffers)
         self.origin = None                       # [B,A,26] raw regression outputs, filled while use_l1 is on
@@ -520,13 +520,21 @@ class Engine:
     def new_act(self, C, H, W, ld=None):
         return Act(Buf(self.dev, self.B * H * W, ld or C, self.dtype), 0, C, self.B, H, W)
 
+    def _kopt(self, name, args):
+        """conv_fwd_bf16 / conv_dgrad_bf16 with the plan's kernel options (PlanOptions.conv_kernel_opts != 0: the _ex entry points)."""
+        if self.options.conv_kernel_opts and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
+            return name + "_ex", tuple(args) + (self.options.conv_kernel_opts,)
+        return name, tuple(args)
+
     def _f(self, name, *args, ev=None):
         """Append a forward launch; `ev` = the (name, args) that replaces it in the eval-mode list (default: the same)."""
+        name, args = self._kopt(name, args)
         self.fwd.append((name, args))
         if ev is not False:                          # ev=False: a training-only launch (batch statistics, dropout)
             self.fwd_eval.append(ev if ev is not None else (name, args))
 
     def _b(self, name, args, writes=(), reads=None):
+        name, args = self._kopt(name, args)
         if self._force_side and name[0] != "@" and not name.startswith("side:"):
             name = "side:" + name
         self.bwd.append((name, args))
@@ -852,7 +860,7 @@ class Engine:
 
     def csp(self, mod, x, out=None):
         """CSPLayer: cat(m(conv1(x)), conv2(x)) -> conv3 (network_blocks.py:179-185)."""
-        if csp_is_merged(mod):
+        if csp_is_merged(mod, self.options):
             return self.csp_merged(mod, x, out)
         h = self.home.by_param[mod.conv1.conv.weight].cout
         cat = self.new_act(2 * h, x.H, x.W)
@@ -1173,7 +1181,7 @@ class Engine:
         self.levels.append((H, W, s))
         self._cur_tag = ("head", k)
         x = self.unit(head.stems[k], feat)
-        if MERGE_HEAD:
+        if self.options.merge_head:
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
             _same_bn(c0.bn, r0.bn)
@@ -1458,7 +1466,7 @@ class SubEngine(Engine):
         if kind == "baseconv":
             if len(home.by_param[mod.conv.weight].params) != 1:
                 raise NotImplementedError("ep24: this BaseConv runs as one merged unit with its sibling (conv1 / conv2 of a CSP layer, the "
-                                          "first convs of the head branches): call the enclosing module, or set EP24_NO_CSP_MERGE=1 EP24_NO_HEAD_MERGE=1")
+                                          "first convs of the head branches): call the enclosing module, or build the model with PlanOptions(merge_csp=False, merge_head=False)")
             self.outs = [self.unit(mod, x)]
         elif kind == "focus":
             rows = self.new_act(112, self.IH // 2, self.IW // 2)

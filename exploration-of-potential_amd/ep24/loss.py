@@ -43,7 +43,7 @@ class LossWorkspace:
 
 def assign_candidates(ws, labels, xs, ys, strides):
     """a4+a5: the geometric candidate masks depend on the labels and the anchor grid only, so a captured step runs them
-    ahead of the forward pass (ep24.train: first thing on the main lane, never next to another kernel)."""
+    ahead of the forward pass (ep24.train: first thing on the main lane)."""
     in_box, in_ctr = ws.masks[0], ws.masks[1]
     call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ws.B, ws.A,
          stream_ptr())

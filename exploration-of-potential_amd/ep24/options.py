@@ -1,0 +1,77 @@
+"""Per-model plan options.
+
+Everything that changes WHICH kernels a plan launches, how its parameters are laid out or how a captured step is cut into
+lanes is an explicit, immutable option object attached to the model it applies to - never a process-wide switch or an
+environment variable read inside the library: two engines in one process (a test that compares two plans, two threads that
+each build a model) cannot see each other's settings.
+
+    from ep24.options import PlanOptions, set_options
+    set_options(model, PlanOptions(merge_csp=False))      # before the model's first forward / TrainStep
+
+``PlanOptions.parse("merge_csp=0,forward_lanes=3")`` is the text form tools and ``bench.py --plan`` use for A/B runs.
+"""
+from dataclasses import dataclass, fields, replace
+from typing import ClassVar, Optional, Tuple
+
+
+@dataclass(frozen=True)
+class PlanOptions:
+    # ---- parameter layout + launch lists (ep24.engine) ----
+    merge_csp: bool = True             # conv1 + conv2 of a CSP layer as ONE GEMM with one BatchNorm launch
+    merge_csp_shortcut: bool = True    # ... also in the backbone's CSP layers with shortcuts (one gradient copy each)
+    merge_head: bool = True            # the first 3x3 conv of the head's class / regression branches as one GEMM (N = 2h)
+    parallel_head: bool = True         # backward of head levels 1, 2 on the weight-gradient lane
+    capture_side: bool = False         # cross-stream edges inside captured graphs (experimental; faulted on ROCm 7.2)
+    fold_bn_eval: bool = True          # eval mode: BatchNorm folded into the conv (one launch per unit)
+    conv_kernel_opts: int = 0          # bit 0: 3x3 stride-1 layers through the generic tiled kernel, bit 1: 8-byte epilogue stores
+    # ---- captured step (ep24.train.TrainStep) ----
+    parallel_forward: bool = True      # level-0 head chain on a second forward lane
+    forward_lanes: int = 2
+    bwd_cuts: Optional[Tuple[float, ...]] = None   # fractions of the backward list where its graph segments are cut (None: default)
+
+    LAYOUT_FIELDS: ClassVar[tuple] = ("merge_csp", "merge_csp_shortcut", "merge_head")     # these decide the flat parameter layout
+
+    def with_(self, **kw):
+        return replace(self, **kw)
+
+    def layout(self):
+        return tuple(getattr(self, k) for k in self.LAYOUT_FIELDS)
+
+    @classmethod
+    def parse(cls, text):
+        """"key=value,key=value" -> PlanOptions (booleans as 0/1; bwd_cuts as u<N> for N uniform segments or a:b:c fractions)."""
+        kw = {}
+        types = {f.name: f.type for f in fields(cls)}
+        for item in filter(None, (text or "").split(",")):
+            k, _, v = item.partition("=")
+            k = k.strip()
+            if k not in types:
+                raise ValueError("unknown plan option %r (known: %s)" % (k, ", ".join(sorted(types))))
+            if k == "bwd_cuts":
+                kw[k] = (tuple((i + 1) / int(v[1:]) for i in range(int(v[1:]) - 1)) if v[0] == "u"
+                         else tuple(float(x) for x in v.split(":")))
+            elif k in ("forward_lanes", "conv_kernel_opts"):
+                kw[k] = int(v)
+            else:
+                kw[k] = v.strip() not in ("0", "false", "False", "")
+        return cls(**kw)
+
+
+DEFAULT = PlanOptions()
+
+
+def set_options(model, options):
+    """Attach ``options`` to ``model`` (the root module a plan is built for).  The merge options decide the flat parameter
+    layout, so they must be set before the model's parameters move into flat buffers (its first forward / TrainStep); the other
+    options apply to plans built afterwards (plans already built keep theirs)."""
+    home = model.__dict__.get("_ep24_home")
+    if home is not None and home.options.layout() != options.layout():
+        from ._lib import Ep24Error
+        raise Ep24Error("ep24: the merge options must be set before the model first runs (its parameters already live in flat "
+                        "buffers laid out for %r)" % (home.options,))
+    model.__dict__["_ep24_options"] = options
+    return model
+
+
+def get_options(model):
+    return model.__dict__.get("_ep24_options", DEFAULT)

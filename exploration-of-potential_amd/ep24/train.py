@@ -6,8 +6,6 @@ gradient clearing, weight packing, forward list, SimOTA + loss + loss gradient, 
 all-reduce), fused SGD - is a fixed sequence of launches on static buffers, captured once and replayed;
 the host only copies the next batch into the static input buffers and reads the loss when it wants to.
 """
-import os
-
 import torch
 
 from . import _lib, loss as eloss
@@ -91,8 +89,9 @@ class TrainStep:
         # replays each lane as a chain of captured segments (no launch gaps: 28.7 ms/step at YOLOX-l / B=20);
         # False launches the same lanes from the host with per-layer events (29.4 ms)
         self.graph_backward = graph_backward
-        self.parallel_forward = graph_backward and not os.environ.get("EP24_NO_PAR_FWD")
-        self.forward_lanes = int(os.environ.get("EP24_FWD_LANES", 2))
+        opts = self.eng.options                          # per-model plan options (ep24.options.PlanOptions)
+        self.parallel_forward = graph_backward and opts.parallel_forward
+        self.forward_lanes = int(opts.forward_lanes)
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
             reducer.attach(self.home, eng)
@@ -143,10 +142,11 @@ class TrainStep:
 
     def _phase_forward_head(self):
         eng = self.eng
-        # The label-only part of SimOTA (candidate masks) runs FIRST and alone.  It used to open the second forward lane;
-        # next to the MFMA kernels of the other lane its angle sums came back different in lanes 48..63 of a wave a few
-        # times per launch (a transcendental result consumed one quarter-wave too early; never when the kernel has the
-        # SIMDs to itself - DESIGN.md section 6, tools/step_stress.py), which flipped a borderline candidate now and then.
+        # The label-only part of SimOTA (candidate masks) runs first: it depends on nothing but the labels.  (In round 2 it
+        # opened the second forward lane, and next to the MFMA kernels of the other lane its angle sums came back different
+        # in lanes 48..63 of a wave now and then.  Root cause, round 3: a v_pk_mul_f32 with swapped operand halves emitted by
+        # the SLP vectoriser - tools/hazard_probe.hip; the library is built without it and the kernel is
+        # correct on any stream, tests/test_gpu_hazard.py.  The placement stays: nothing needs the masks earlier.)
         eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
         self.home.zero_grad()
         if not torch.cuda.is_current_stream_capturing():
@@ -186,9 +186,8 @@ class TrainStep:
         bucket boundaries are cut points too."""
         n = len(self.eng.bwd)
         fr = (0.12, 0.24, 0.36, 0.48, 0.58, 0.68, 0.76, 0.83, 0.89, 0.93, 0.96, 0.98, 0.99, 0.995)
-        if os.environ.get("EP24_BWD_CUTS"):
-            e = os.environ["EP24_BWD_CUTS"]
-            fr = [(i + 1) / int(e[1:]) for i in range(int(e[1:]) - 1)] if e[0] == "u" else [float(v) for v in e.split(",")]
+        if self.eng.options.bwd_cuts is not None:
+            fr = self.eng.options.bwd_cuts
         cuts = {0, n} | {int(n * f) for f in fr}
         ready = {}
         if self.reducer is not None:

@@ -52,7 +52,8 @@ class Trainer:
         self.device = torch.device("cuda", dev.index if dev.index is not None else local)
         self.input_size = exp.input_size
         self.file_name = os.path.join(exp.output_dir, exp.exp_name)
-        self.current_step = 0
+        self.current_step = 0                             # global step (epoch * max_iter + iter): schedule / TensorBoard axis
+        self.run_steps = 0                                # steps of THIS run: what --steps limits
         os.makedirs(self.file_name, exist_ok=True)
         if not args.synthetic:
             print("note: the COCO24P loader of the reference reads hard-coded paths (datasets/coco24p.py:19-20) and is out of "
@@ -90,6 +91,9 @@ class Trainer:
                 self.start_epoch = int(ck.get("start_epoch", 0))
         if args.start_epoch is not None:
             self.start_epoch = args.start_epoch
+        # progress = epoch * max_iter + iter, as the reference's schedulers / loggers count it: a resumed run continues the
+        # learning-rate schedule and the TensorBoard axis where the checkpoint stopped instead of restarting the warm-up
+        self.current_step = self.resumed_step(self.start_epoch, self.max_iter)
         self.tblogger = SummaryWriter(self.file_name) if (SummaryWriter and self.rank == 0) else None
         self.lr_scheduler = exp.get_lr_scheduler(args.learn_rate, self.max_iter) if args.sched else None
         self.ema_model = None
@@ -116,16 +120,15 @@ class Trainer:
                 model.head.use_l1 = self.loss_func.use_l1 = True
                 if step_fn is not None:
                     step_fn.set_use_l1(True)
-            for images, labels, _info, _ids in self.train_loader:
+            for images, labels in self.batches():
                 self.current_step += 1
+                self.run_steps += 1
                 if self.lr_scheduler is not None:
                     lr = self.lr_scheduler.update_lr(self.current_step)
                     for group in self.optimizer.param_groups:
                         group["lr"] = lr
                     if step_fn is not None:
                         step_fn.set_lr(lr)
-                images = images.to(self.device, non_blocking=True)
-                labels = labels.to(self.device, non_blocking=True)
                 images, labels = exp.preprocess(images, labels, self.input_size)
                 if step_fn is not None:
                     res = step_fn.step(images, labels)
@@ -145,7 +148,7 @@ class Trainer:
                 seen += images.shape[0]
                 if self.current_step % args.log_interval == 0:
                     self.TB_data(res, seen * self.world / (time.time() - t0))
-                if args.steps and self.current_step >= args.steps:
+                if args.steps and self.run_steps >= args.steps:
                     done = True
                     break
             if self.rank == 0:
@@ -154,6 +157,28 @@ class Trainer:
                 break
         if self.world > 1:
             torch.distributed.destroy_process_group()
+
+    @staticmethod
+    def resumed_step(start_epoch, max_iter):
+        """Global step a run that starts at ``start_epoch`` continues from (reference: epoch * max_iter + iter)."""
+        return int(start_epoch) * int(max_iter)
+
+    def batches(self):
+        """One epoch of (images, labels) on the device.  Default: the loader's tensors, uploaded on the compute stream (what the
+        reference's loop does, train_24p.py:86-88).  ``--prefetch``: the reference's ``DataPrefetcher`` (data/data_prefetcher.py:16-51)
+        in its ep24 form - the next batch is uploaded (and, for raw uint8 batches, letterboxed by ``TrainTransform.batch``) on a side
+        stream while the current step runs."""
+        if not self.args.prefetch:
+            for images, labels, _info, _ids in self.train_loader:
+                yield images.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True)
+            return
+        from ep24.input import DataPrefetcher, TrainTransform
+        pf = DataPrefetcher(self.train_loader, tuple(self.input_size), TrainTransform(max_labels=50))
+        while True:
+            images, labels = pf.next()
+            if images is None:
+                return
+            yield images, labels
 
     def TB_data(self, res, ips):
         """One D2H copy of the packed result vector: [0] loss, [1..24] weighted IOU losses, [25] conf, [26] cls,
@@ -201,6 +226,7 @@ def make_parser():
     p.add_argument("--sched", action="store_true", help="follow exp.get_lr_scheduler (yoloxwarmcos) instead of a constant rate")
     p.add_argument("--ema", action="store_true", help="keep a ModelEMA copy of the model (saved as ema_model)")
     p.add_argument("--l1", action="store_true", help="switch use_l1 on from epoch exp.L1_epoch")
+    p.add_argument("--prefetch", action="store_true", help="upload (and letterbox) the next batch on a side stream: ep24.input.DataPrefetcher")
     return p
 
 

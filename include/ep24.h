@@ -51,11 +51,22 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
                        int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 
-/* A/B switches for timing and for tests that compare two kernels on one shape (default 1).  Bit 0: the 3x3 stride-1 layers
- * (forward and input gradient) run in the halo-patch kernel (csrc/conv_patch.hip) rather than the generic tiled kernel;
- * bit 1: the tiled kernels store their output 8 bytes per lane instead of staging it for 16-byte stores.  Returns the
- * previous value. */
-int ep24_conv_set_patch(int on);
+/* The same two entry points with an explicit kernel choice PER CALL (A/B timing, tests that compare two kernels on one shape;
+ * there is no process-wide switch).  kernel_opts bit 0: the 3x3 stride-1 layers run in the generic tiled kernel instead of the
+ * halo-patch kernel (csrc/conv_patch.hip); bit 1: the tiled kernels store their output 8 bytes per lane instead of staging
+ * it for 16-byte stores; bits 2-3: LDS ring depth of the tiled kernel (1: three stages, 2: four) instead of the dispatch rule's;
+ * bit 4: its two-stage loop.  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
+int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
+                          int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
+                          int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream);
+int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
+                            int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, int kernel_opts, void* stream);
+
+/* Which device kernel ep24_conv_fwd_bf16 (dgrad = 0) / ep24_conv_dgrad_bf16 (dgrad = 1, stride 1) launches for a shape - the
+ * library's own dispatch rule, for reports (bench.py attributes launch times to kernels with it).  Returns 0 =
+ * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch), 2 = igemm_stream_kernel (1x1 streaming), < 0 on error.
+ * y_f32 / has_bias as in ep24_conv_fwd_bf16 (both 0 for dgrad). */
+int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias);
 
 /* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 8 == 0 (zero padded).
  * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */
@@ -79,6 +90,13 @@ int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, in
 int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
                               int64_t ld_dw, int cout_valid, int cin_valid,
                               int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+/* The weight-gradient entry points with an explicit kernel choice per call (A/B timing and bit-equality tests; kernel_opts bits 2-3:
+ * LDS ring depth 3 / 4 instead of the dispatch rule's, bit 4: the two-stage loop).  The number of pixel splits - the slab size -
+ * depends on the ring depth, so ep24_conv_wgrad_splits_ex takes the same kernel_opts. */
+int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
+                                 int64_t ld_dw, int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
+                                 int stride, int kernel_opts, void* stream);
+int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts);
 int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream);
 
 /* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad
@@ -214,8 +232,10 @@ int ep24_colsum_slab(const void* g, int64_t ld, float* slab, int64_t M, int N, v
  * ------------------------------------------------------------------------------------------------ */
 /* a4+a5 (pts_in_poly + get_in_boxes_info, losses.py:497-592).  labels [B,50,51] fp32; xs/ys/strides [A].
  * Out: num_gt[B] int32 (rows with sum>0, losses.py:190), in_box[B*A], in_ctr[B*A] uint64 bitmasks over GTs.
- * Launch it on its own: next to MFMA kernels of another stream its angle sums were measured to come back different in
- * lanes 48..63 of a wave now and then; ep24.train runs it first in the step, before anything else. */
+ * Safe on any stream next to any other kernel.  (Round 2 measured different angle sums in lanes 48..63 of a wave when MFMA
+ * kernels of another stream shared the SIMDs; the cause was a packed fp32 multiply with swapped operand halves that the
+ * vectoriser had emitted - tools/hazard_probe.hip - and the library is built without such instructions since round 3:
+ * DESIGN.md section 4, tests/test_abi.py::test_no_half_swapped_packed_fp32, tests/test_gpu_hazard.py.) */
 int ep24_assign_candidates(const float* labels, const float* xs, const float* ys, const float* strides,
                            int32_t* num_gt, uint64_t* in_box, uint64_t* in_ctr, int B, int A, void* stream);
 /* a6+a7 (bboxes_iou + class cost + total cost, boxes.py:166-243, losses.py:396-424) for every candidate

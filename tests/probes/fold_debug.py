@@ -26,9 +26,8 @@ if os.environ.get("TRAIN_FIRST"):
 m.eval()
 outs = {}
 for fold in (0, 1):
-    os.environ.pop("EP24_NO_FOLD", None)
-    if not fold:
-        os.environ["EP24_NO_FOLD"] = "1"
+    from ep24.options import PlanOptions, set_options
+    set_options(m, PlanOptions(fold_bn_eval=bool(fold)))
     m._engines = {}
     eng = m.engine(2, 128)
     eng.forward_eval(x)

@@ -102,14 +102,19 @@ def test_conv_fwd_dgrad_wgrad(B, H, Cin, Cout, k, s):
 
 
 # The layers that carry ~80 % of YOLOX-l-24p's FLOPs at the BASELINE size (B = 20, 640 x 640: SURVEY.md 8d shape list), plus the
-# shapes that select every production instantiation: the halo-patch kernel with 256x128 / 128x128 / 256x64 tiles, the wide and
-# narrow tiled kernel (stride 2, K > 256 1x1), the streaming kernel with one and two K halves, the 112-column stem.
-HOT_SHAPES = [  # B, H, Cin, Cout, k, s
+# shapes that select every production instantiation: the halo-patch kernel (one tile shape, 256 x 128; the 20x20x512 and 160x160x64
+# cases fall back to the tiled kernel, so both kernel settings run the same code there), the wide and narrow tiled kernel (stride 2,
+# K > 256 1x1), the streaming kernel with one and two K halves, the 112-column stem.  An entry may carry W as a 7th value.
+HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     (20, 40, 256, 256, 3, 1), (20, 80, 128, 128, 3, 1), (20, 20, 512, 512, 3, 1), (20, 80, 256, 256, 3, 1), (4, 160, 64, 64, 3, 1),
     (20, 40, 512, 1024, 3, 2), (20, 80, 256, 512, 3, 2), (20, 20, 2048, 1024, 1, 1), (20, 20, 1024, 512, 1, 1),
     (20, 40, 512, 256, 1, 1), (20, 80, 128, 128, 1, 1), (20, 80, 256, 256, 1, 1), (2, 320, 112, 64, 1, 1),
     # not on the YOLOX-l path: the halo-patch kernel with a K tail (96 = 64 + 32 channels) and an N tail (192 = 128 + 64)
     (20, 80, 96, 192, 3, 1), (10, 80, 160, 136, 3, 1),
+    # non-square inputs whose pixel count is NOT a multiple of the 256-row tile (multiscale / rectangular training sizes produce
+    # them: 480 x 672 -> 60 x 84): rows m >= M of the last tile, the `live` guard of the statistics in the wide epilogue,
+    # out-of-range patch pieces, with two patch buffers (K = 128, LDS exactly 160 KB) and with one (K = 64)
+    (20, 60, 128, 128, 3, 1, 84), (12, 52, 64, 128, 3, 1, 100),
 ]
 
 
@@ -127,18 +132,22 @@ def _torch_conv_ref(x, w, gy, s, pad):
     raise RuntimeError("no fp32 reference")
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,k,s", HOT_SHAPES)
-def test_conv_hot_shapes(B, H, Cin, Cout, k, s):
+@pytest.mark.parametrize("shape", HOT_SHAPES, ids=lambda t: "x".join(str(v) for v in t))
+def test_conv_hot_shapes(shape):
+    B, H, Cin, Cout, k, s = shape[:6]
+    W = shape[6] if len(shape) > 6 else H
     call, ptr, sp = _abi()
     from ep24 import _lib
     fn = _lib.lib().fn
-    W = H
     pad = (k - 1) // 2
     x = rnd(B, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
-    OH = (H + 2 * pad - k) // s + 1
-    gy = rnd(B, Cout, OH, OH, seed=3)
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    gy = rnd(B, Cout, OH, OW, seed=3)
     y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
+    M = B * OH * OW
+    if len(shape) > 6:
+        assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == 1, "meant to exercise the patch kernel's M tail"
 
     xd = nhwc(x).to(DEV)
     wf = w.permute(0, 2, 3, 1).contiguous().to(DEV)
@@ -147,20 +156,17 @@ def test_conv_hot_shapes(B, H, Cin, Cout, k, s):
     R = 8
     outs = {}
     for patch in (1, 0):                                                  # halo-patch kernel, then the generic tiled kernel
-        fn["ep24_conv_set_patch"](patch)
-        try:
-            y = torch.zeros(B, OH, OH, Cout, dtype=BF, device=DEV)
-            stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
-            call("conv_fwd_bf16", ptr(xd), Cin, ptr(wf), ptr(y), Cout, 0, 0, 0, None, ptr(stats), R, B, H, W, Cin, Cout, k, s, sp())
-            dx = torch.full((B, H, W, Cin), 7.0, dtype=BF, device=DEV)
-            if not (k == 1 and s == 2):
-                call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, k, s, sp())
-            base = rnd(B, H, W, Cin, seed=5).to(DEV)
-            dx2 = base.clone()
-            call("conv_dgrad_bf16", ptr(gyd), Cout, ptr(wd), ptr(dx2), Cin, 1, B, H, W, Cin, Cout, k, s, sp())
-            torch.cuda.synchronize()
-        finally:
-            fn["ep24_conv_set_patch"](1)
+        ko = 0 if patch else 1                                            # kernel_opts bit 0 of the _ex entry points: per call, no global switch
+        y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
+        stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
+        call("conv_fwd_bf16_ex", ptr(xd), Cin, ptr(wf), ptr(y), Cout, 0, 0, 0, None, ptr(stats), R, B, H, W, Cin, Cout, k, s, ko, sp())
+        dx = torch.full((B, H, W, Cin), 7.0, dtype=BF, device=DEV)
+        if not (k == 1 and s == 2):
+            call("conv_dgrad_bf16_ex", ptr(gyd), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, k, s, ko, sp())
+        base = rnd(B, H, W, Cin, seed=5).to(DEV)
+        dx2 = base.clone()
+        call("conv_dgrad_bf16_ex", ptr(gyd), Cout, ptr(wd), ptr(dx2), Cin, 1, B, H, W, Cin, Cout, k, s, ko, sp())
+        torch.cuda.synchronize()
         close(y.permute(0, 3, 1, 2), y_ref)
         st = stats.sum(0).cpu().double().div(2 ** 20).float()
         close(st[0], y_ref.sum((0, 2, 3)), rel=2e-3)

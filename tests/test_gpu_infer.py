@@ -65,16 +65,16 @@ def _tiny():
 
 
 @pytest.mark.parametrize("fold", [False, True])
-def test_eval_forward_matches_train_forward_when_running_stats_equal_batch_stats(fold, monkeypatch):
+def test_eval_forward_matches_train_forward_when_running_stats_equal_batch_stats(fold):
     """With momentum 1 a train-mode pass leaves running_mean = batch mean and running_var = unbiased batch variance;
     after rescaling the variance to the biased one the eval-mode network (running statistics) must reproduce the
     train-mode activations: same decoded boxes, obj / class = sigmoid of the train-mode logits.  The two-launch eval form
     (conv, then BN on the stored bf16 conv output) rounds exactly where training does; the default folded form (BN inside
     the weights, one launch per unit) rounds the scaled weights instead, so it is compared at bf16-network tolerance and
     before the head's exp()."""
-    if not fold:
-        monkeypatch.setenv("EP24_NO_FOLD", "1")
+    from ep24.options import PlanOptions, set_options
     m = _tiny()
+    set_options(m, PlanOptions(fold_bn_eval=fold))          # per-model option (no environment switch)
     B, S = 4, 128
     for mod in m.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):

@@ -52,8 +52,11 @@ def test_trainer_runs_and_checkpoint_round_trips(tmp_path):
     # resume: parameters (incl. the predictor biases) and momentum come back; zero further steps would change nothing,
     # so run with lr 0 for one step and compare what is saved
     out2 = str(tmp_path / "run2")
-    env_log = _train(out2, "--steps", "1", "-c", path, "--resume", "-l", "0.0")
-    assert "step 1" in env_log
+    # (--prefetch: the batch comes through ep24.input.DataPrefetcher on its side stream)
+    env_log = _train(out2, "--steps", "1", "-c", path, "--resume", "-l", "0.0", "--prefetch")
+    # the global step continues at start_epoch * max_iter (64 synthetic images / batch 4 = 16 iterations per epoch), as the
+    # reference counts progress (epoch * max_iter + iter): the schedule and the TensorBoard axis do not restart
+    assert "step 17 " in env_log, env_log[-2000:]
     ck2 = torch.load(os.path.join(out2, "yolox_24p", "last_epoch_ckpt.pth"), map_location="cpu")
     assert ck2["start_epoch"] == 2                                  # resumed at epoch 1
     for k, v in ck["model"].items():

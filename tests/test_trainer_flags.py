@@ -42,3 +42,50 @@ def test_backbone_swap_exp_files():
             assert abs(float(model.head.cls_preds[0].bias[0]) + 4.59512) < 1e-4
     finally:
         sys.path.remove(Y24)
+
+
+def test_resume_continues_the_lr_schedule():
+    """A run resumed at epoch e follows the yoloxwarmcos schedule where an uninterrupted run would be (the reference derives
+    progress from epoch * max_iter + iter, utils/lr_scheduler.py:20-27); --steps still counts the steps of the run itself."""
+    sys.path.insert(0, Y24)
+    try:
+        import importlib
+        mod = importlib.import_module("train_24p")
+        from exp import get_exp
+        exp = get_exp(os.path.join(Y24, "load_train", "yolox_24p_train.py"))
+        max_iter = 16
+        sched = exp.get_lr_scheduler(0.01, max_iter)
+        uninterrupted = [sched.update_lr(i) for i in range(1, 4 * max_iter + 1)]
+        for start_epoch in (0, 1, 3):
+            step = mod.Trainer.resumed_step(start_epoch, max_iter)
+            assert step == start_epoch * max_iter
+            resumed = [sched.update_lr(step + i) for i in range(1, 6)]
+            assert resumed == uninterrupted[step:step + 5]
+        # warm-up really is over at epoch 3 of this schedule's 5 warm-up epochs?  no - so the resumed rate must differ from a restart
+        assert sched.update_lr(mod.Trainer.resumed_step(3, max_iter) + 1) != sched.update_lr(1)
+        a = mod.make_parser().parse_args(["--prefetch"])
+        assert a.prefetch is True and mod.make_parser().parse_args([]).prefetch is False
+    finally:
+        sys.path.remove(Y24)
+
+
+def test_plan_options_are_per_model_objects():
+    """What changes kernels or plans is an immutable option object attached to a model (ep24.options), not a process global."""
+    sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
+    from ep24.options import DEFAULT, PlanOptions, get_options, set_options
+    import torch
+    o = PlanOptions.parse("merge_csp=0,forward_lanes=3,bwd_cuts=u4,conv_kernel_opts=1")
+    assert (o.merge_csp, o.merge_head, o.forward_lanes, o.bwd_cuts, o.conv_kernel_opts) == (False, True, 3, (0.25, 0.5, 0.75), 1)
+    assert PlanOptions.parse("") == DEFAULT and PlanOptions.parse("bwd_cuts=0.5:0.9").bwd_cuts == (0.5, 0.9)
+    try:
+        PlanOptions.parse("no_such_option=1")
+        raise AssertionError("unknown option accepted")
+    except ValueError:
+        pass
+    a, b = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    set_options(a, o)
+    assert get_options(a) is o and get_options(b) is DEFAULT          # another model in the same process is untouched
+    src = open(os.path.join(ROOT, "exploration-of-potential_amd", "ep24", "engine.py")).read() + \
+        open(os.path.join(ROOT, "exploration-of-potential_amd", "ep24", "train.py")).read() + \
+        open(os.path.join(ROOT, "exploration-of-potential_amd", "ep24", "dp.py")).read()
+    assert "os.environ" not in src                                     # no environment switches on the product path

@@ -55,19 +55,20 @@ def main():
         sums = torch.zeros(2, Cin, dtype=torch.int64, device=DEV)
         fl = 2.0 * B * H * W * Cin * Cout * 9
         for kind in kinds:
+            ko = [0]                                     # kernel_opts of the _ex entry points: bit 0 tiled kernel, bit 1 narrow epilogue
+
             def run():
                 if kind == "fwd":
-                    call("conv_fwd_bf16", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, stream_ptr())
+                    call("conv_fwd_bf16_ex", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
                 elif kind == "dgrad":
-                    call("conv_dgrad_bf16", ptr(dy), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, 3, 1, stream_ptr())
+                    call("conv_dgrad_bf16_ex", ptr(dy), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
                 else:
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
             for rnd in range(2):
-                for mode in (2, 0, 3, 1):
-                    fn["ep24_conv_set_patch"](mode)
+                for mode in (2, 0, 3, 1):                # old numbering of the columns: bit 0 = patch kernel, bit 1 = narrow epilogue
+                    ko[0] = (0 if mode & 1 else 1) | (mode & 2)
                     res.setdefault(mode, []).append(graph_time(run))
-            fn["ep24_conv_set_patch"](1)
             print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f   best %.0f TF" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[2]), min(res[0]), min(res[3]), min(res[1]),
                                                                     fl / min(min(v) for v in res.values()) / 1e6), flush=True)
 

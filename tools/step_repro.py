@@ -8,11 +8,13 @@ from ep24 import loss as eloss, nn as enn, train as etrain, synth
 DEV = torch.device("cuda", 0)
 
 
-def run(lr, steps, **kw):
+def run(lr, steps, plan="", **kw):
+    from ep24.options import PlanOptions, set_options
     torch.manual_seed(0)
     m = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
     m.head.initialize_biases(1e-2)
     m.to(DEV)
+    set_options(m, PlanOptions.parse(plan))
     lf = eloss.Loss_Function(80)
     ts = etrain.TrainStep(m, lf, lr=lr, momentum=0.9, batch=20, size=640, **kw)
     ts.eng.images.copy_(synth.make_images(20, 640, seed=1).to(DEV))
@@ -23,11 +25,8 @@ def run(lr, steps, **kw):
     return losses, float(out.sum()), float(out.abs().sum())
 
 
-for tag, kw, env in (("graph 2-lane", {}, {}), ("graph 2-lane", {}, {}), ("eager", dict(use_graph=False), {}),
-                     ("graph 1-lane fwd", {}, {"EP24_NO_PAR_FWD": "1"}), ("graph no-graph-bwd", dict(graph_backward=False), {}),
-                     ("graph 2-lane lr0", {}, {})):
-    os.environ.update(env)
+for tag, kw, plan in (("graph 2-lane", {}, ""), ("graph 2-lane", {}, ""), ("eager", dict(use_graph=False), ""),
+                      ("graph 1-lane fwd", {}, "parallel_forward=0"), ("graph no-graph-bwd", dict(graph_backward=False), ""),
+                      ("graph 2-lane lr0", {}, "")):
     lr = 0.0 if tag.endswith("lr0") else 0.001
-    print(tag, run(lr, 2, **kw), flush=True)
-    for k in env:
-        del os.environ[k]
+    print(tag, run(lr, 2, plan=plan, **kw), flush=True)

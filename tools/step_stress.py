@@ -20,7 +20,7 @@ ap.add_argument("--depth", type=float, default=1.0)
 ap.add_argument("--batch", type=int, default=20)
 ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--eager", action="store_true")
-ap.add_argument("--patch-flags", type=int, default=1, help="ep24_conv_set_patch: bit0 halo-patch kernel, bit1 narrow epilogue")
+ap.add_argument("--kernel-opts", type=int, default=0, help="PlanOptions.conv_kernel_opts: bit0 tiled kernel instead of the halo-patch kernel, bit1 narrow epilogue")
 a = ap.parse_args()
 DEV = torch.device("cuda", 0)
 
@@ -35,12 +35,12 @@ def _rec(self, *args, **kw):
 
 eengine.Buf.__init__ = _rec
 
-from ep24 import _lib
-_lib.lib().fn["ep24_conv_set_patch"](a.patch_flags)
+from ep24.options import PlanOptions, set_options
 torch.manual_seed(0)
 m = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width), enn.YOLOXHead(80, a.width))
 m.head.initialize_biases(1e-2)
 m.to(DEV)
+set_options(m, PlanOptions(conv_kernel_opts=a.kernel_opts))
 lf = eloss.Loss_Function(80)
 ts = etrain.TrainStep(m, lf, lr=0.0, momentum=0.9, batch=a.batch, size=a.size, use_graph=not a.eager)
 ts.eng.images.copy_(synth.make_images(a.batch, a.size, seed=1).to(DEV))
