@@ -7,7 +7,7 @@
 // Output channels are relabelled inside each wave's 64-wide span (MFMA column j of n-tile t <-> channel 4j+t) so every
 // lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
 #include <stdlib.h>
-#include <atomic>
+#include <type_traits>
 #include "igemm.h"
 
 using namespace ep24_igemm;
@@ -15,7 +15,7 @@ using namespace ep24_igemm;
 namespace {
 
 // kernel_opts of the _ex entry points (include/ep24.h): per call, no process-wide state
-constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_TWO_STAGE = 16;   // bits 2-3: ring depth override (A/B), bit 4: two-stage loop
+constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_PER_CLASS = 4;     // bit 2: a stride-2 input gradient as one launch per parity class
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
@@ -24,13 +24,15 @@ constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_TWO_STAGE = 16;   // bit
 // SOURCE address: LDS unit U = row*8 + pchunk is fetched from (row, pchunk ^ (row & 7)); padding taps and the
 // M / N / K tails use an out-of-range buffer offset, for which the DMA writes zeros.  Two LDS stages, one barrier per K-step: the DMA of tile t+1 is
 // in flight while tile t feeds the MFMAs.
-// NS = 2: two stages, one __syncthreads() (vmcnt(0) + barrier) per K step - a step costs max(MFMA time, one DMA round trip).
-// NS > 2: a ring of NS stages with NS - 1 tiles in flight, retired by a COUNTED vmcnt and a raw s_barrier (every step issues the
-// same number of DMA instructions - beyond the last tile they are out-of-range zero fills into a stage nobody reads - so the
-// count is an immediate): the layers whose K loop is a handful of steps (1x1 convs with K = 256 .. 2048, the stride-2 parity
-// classes) pay the round trip once instead of once per step.  Same products in the same order: results are bit-identical.
-template <int BN, bool OUT_F32, int EPI = 0, int NS = 2>    // EPI: 0 training (statistics), 2 inference (bias, act, residual)
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
+// (Round 3 built this loop as a ring of 3 / 4 LDS stages with counted vmcnt waits and a raw barrier as well - bit-identical results -
+// and measured it on every layer shape the kernel runs: 30 - 40 % SLOWER almost everywhere, because three 32 KB stages leave room for
+// one workgroup per CU instead of two and the second workgroup hides more latency than the deeper prefetch does;
+// profiles/r03_ring_ab.txt.  Removed again.)
+// A second variant kept two tiles in flight WITHOUT a third stage (both stages requested up front, tile it+2 requested as soon as
+// tile `it` had been read, a second barrier per step): within +-4 % of this loop on the 1x1 layers, 613 against 627 us over all of
+// them, nothing in the step (22.68 against 22.78 ms) - profiles/r03_ring_ab.txt.  Removed as well.
+template <int BN, bool OUT_F32, int EPI>
+__device__ __forceinline__ void igemm_dma_body(const IgemmArgs& p, const int bid, const int nwg) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM * 8 / 64 / 4;             // DMA instructions per wave for the A tile (4)
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run
     // of tiles (N fastest): the N tiles of one M tile and neighbouring M tiles share their operands in one L2
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tile_m = tile_id / tiles_n;
     const long m0 = (long)tile_m * BM;
@@ -95,8 +97,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         const int t = is_t, kc = is_kc;
         if (++is_t == p.T) { is_t = 0; ++is_kc; }
         const bool tail = kc >= ktail;                       // wave-uniform, false for every layer of the YOLOX-l path
-        int ktm = tail ? -(int)(kc < kmax) : -1;
-        if (NS > 2 && kc >= KC) ktm = 0;                     // ring filler beyond the last tile: every offset out of range
+        const int ktm = tail ? -(int)(kc < kmax) : -1;
         const int a_s = p.toff[t] + kc * (BK * 2);
         const unsigned b_s = (unsigned)((p.wslot[t] * p.K + kc * BK) * 2);
         char* stage = smem + buf * STAGE;
@@ -122,29 +123,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
 
-    if constexpr (NS == 2) issue(0);
-    else {
-#pragma unroll
-        for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);       // NS - 1 tiles in flight (fillers if the loop is shorter)
-    }
-    int st = 0;                                              // ring stage of tile `it`
-#pragma unroll 1
-    for (int it = 0; it < n_iter; ++it) {
-        const char* la;
-        if constexpr (NS == 2) {
-            __syncthreads();                   // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
-            if (it + 1 < n_iter) issue((it + 1) & 1);
-            la = smem + (it & 1) * STAGE;
-        } else {
-            // this wave's DMAs of tile `it` have landed when at most the (NS - 2) younger tiles' are outstanding; after the
-            // barrier every wave's have, and everybody is done reading stage (it - 1) % NS, which the next issue refills
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (A_INSTR + B_INSTR)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(st == 0 ? NS - 1 : st - 1);
-            __builtin_amdgcn_sched_barrier(0);     // without it the register allocator rotates the accumulators through copies (96 v_accvgpr moves per step)
-            la = smem + st * STAGE;
-            st = st + 1 == NS ? 0 : st + 1;
-        }
+    auto compute = [&](const char* la) {
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -161,9 +140,39 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
                 for (int q = 0; q < NT; ++q)
                     acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
         }
+    };
+    issue(0);
+    for (int it = 0; it < n_iter; ++it) {
+        __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
+        if (it + 1 < n_iter) issue((it + 1) & 1);
+        compute(smem + (it & 1) * STAGE);
     }
 
     igemm_epilogue<BN, OUT_F32, MT, EPI>(p, acc, m0, n0, tile_m, smem);
+}
+
+template <int BN, bool OUT_F32, int EPI = 0>                // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
+    igemm_dma_body<BN, OUT_F32, EPI>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to four gather-GEMMs in ONE launch: the parity classes of a stride-2 input gradient (same M, N and K; 1, 2, 2 and 4 taps) used
+// to be four dependent launches of one-round grids.  A workgroup finds its class from the tile prefix; inside a class the tile
+// order is the single launch's (the XCD label of a workgroup is its index mod 8 up to a constant shift per class).
+struct IgemmMulti {
+    IgemmArgs a[4];
+    int prefix[5];
+    int n;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q) {
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+        if (c < q.n && (int)blockIdx.x >= q.prefix[c]) cls = c;
+    cls = __builtin_amdgcn_readfirstlane(cls);
+    igemm_dma_body<BN, false, 0>(q.a[cls], (int)blockIdx.x - q.prefix[cls], q.prefix[cls + 1] - q.prefix[cls]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -172,13 +181,16 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
 // prologue / DMA round trip / epilogue.  Here the weight tile [BN][K] is loaded into LDS ONCE per workgroup and
 // every wave streams its own 32-row blocks of the activation matrix straight from global memory into MFMA
 // A-fragments (16 B per lane, rows are contiguous for a 1x1 conv): no staging, no barrier in the loop, the next
-// block's 16 loads per lane are in flight while the current one is multiplied and stored, BN statistics stay in
-// registers until the end.
-// A wave multiplies its rows with ALL BN columns of the tile (BN / 64 spans of 64): in round 1 the waves of a workgroup
-// split the columns and each fetched the same rows, so a row went through the vector-memory path once per 64 columns
-// and per N tile - the kernel ran at 5 TB/s for N = 64 but 3.1 for 128 x 128 and 2.5 for 256 x 256, the HBM share of a
-// saturated load path.
-template <int BN, int H, int EPI = 0>                          // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+// block's loads are in flight while the current one is multiplied and stored, BN statistics stay in registers
+// until the end.  A wave multiplies its rows with ALL BN columns of the tile (BN / 64 spans of 64).
+//
+// Round 3: the loop body is STRAIGHT-LINE code.  The round-2 form guarded every load with `if (k step < nks)`, every store with
+// `if (row < M)` and the second block of an iteration with `if (u + 1 < units)`; hipcc branched round each of them and put an
+// s_waitcnt vmcnt(0) in front of every load and before the first MFMA (it cannot count outstanding loads across those merges), so
+// the "next block in flight" never was: a block cost 4 - 5 serial round trips.  Now rows / columns / K steps that do not exist
+// are out-of-range buffer offsets (loads return zeros, stores are dropped, zeros add nothing to the statistics), the K-step count
+// and the accumulate form are template parameters, and the waits the compiler emits are counted.
+template <int BN, int H, int EPI, int NKS, bool ACC>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     constexpr int SP = BN / 64, NTW = SP * 4, MT = 2, RG = 4 * MT * 16;       // 4 waves x 32 rows per unit
     constexpr int OOB = 0x7FFFFFF0;
@@ -190,10 +202,147 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int nt = rest % n_tiles, rb = (rest / n_tiles) * 8 + xcd;
     const int n0 = nt * BN;
-    const int npan = (p.K + 63) >> 6;
-    const int nks = (p.K + 31) >> 5;
 
-    for (int u = tid; u < BN * npan * 8; u += 256) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
+    const auto drsrc = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const long n_groups = (p.M + RG - 1) / RG;
+    const long my_groups = rb < n_groups ? (n_groups - rb + bpn - 1) / bpn : 0;
+    const long units = my_groups * H;                                      // (row group, K half) pairs
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    // every load is issued: a row past M (also every row of a unit past the last one) and a K step past K read zeros
+    auto load = [&](bf16x8 (&A)[MT][NKS], long u) {
+        const long g = rb + (u / H) * bpn;
+        const int h = (int)(u % H);
+        const long r0 = g * RG + wave * (MT * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const long row = r0 + i * 16 + frow;
+            const int base = row < p.M ? (int)((row * p.ld_src + fq * 8 + h * 128) * 2) : OOB;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int vo = (h * 128 + ks * 32 + fq * 8 < p.K) ? base + ks * 64 : OOB;       // a select, not a branch
+                v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+                A[i][ks] = __builtin_bit_cast(bf16x8, t);
+            }
+        }
+    };
+
+    f32x4 acc[MT][NTW];
+    float s1[NTW], s2[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+    constexpr bool infer = EPI == 2;                        // eval mode: y = act(acc + bias) + residual
+    float ibias[infer ? NTW : 1];
+    if constexpr (infer) {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const int c = n0 + (q >> 2) * 64 + 4 * frow + (q & 3);
+            ibias[q] = c < p.N ? p.bias[c] : 0.f;
+        }
+    }
+    // HH: which K half this block is (compile time: in the two-block loop body block 0 is half 0 and block 1 half H - 1)
+    auto compute = [&](bf16x8 (&A)[MT][NKS], long u, auto hh) {
+        constexpr int h = decltype(hh)::value;
+        if constexpr (h == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the weight fragments are re-read from LDS for every block: the laundered base keeps the compiler from hoisting all
+        // 8 * BN / 16 of them out of the row loop into registers (128 VGPRs at BN = 128: it spilled to scratch)
+        int wbase = 0;
+        asm volatile("" : "+v"(wbase));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int kk = h * 4 + ks;
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp) {
+                bf16x8 fb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    fb[q] = *reinterpret_cast<const bf16x8*>(smem + wbase + (kk >> 1) * (BN * 128) + swz(sp * 64 + q * 16 + frow, (kk & 1) * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[i][sp * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], fb[q], acc[i][sp * 4 + q], 0, 0, 0);
+            }
+        }
+        if constexpr (h != H - 1) return;
+        const long g = rb + (u / H) * bpn;
+        const long r0 = g * RG + wave * (MT * 16);
+        if constexpr (infer) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long m = r0 + i * 16 + 4 * fq + r;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int sp = 0; sp < SP; ++sp) {
+                        const int c0 = n0 + sp * 64 + 4 * frow;
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = act_fwd(acc[i][sp * 4 + q][r] + ibias[sp * 4 + q], p.epi_act);
+                            if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
+                        }
+                        bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c0 + q < p.N) d[q] = (bf16)v[q];
+                    }
+                }
+            }
+        } else {
+            // 8-byte buffer stores, every one issued: the offset of a row >= M or a column group >= N is out of range (dropped).
+            // N is a multiple of 4 here (the launcher checks), so a column group is all in or all out.
+            auto voff = [&](int i, int r, int sp) {
+                const long m = r0 + i * 16 + 4 * fq + r;
+                const int c0 = n0 + sp * 64 + 4 * frow;
+                return (m < p.M && c0 < p.N) ? (int)((m * p.ld_dst + c0) * 2) : OOB;
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                v2u old[4][SP];
+                if constexpr (ACC) {                         // the old values of this 16-row block are requested before the first is needed
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int sp = 0; sp < SP; ++sp) old[r][sp] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff(i, r, sp), 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int sp = 0; sp < SP; ++sp) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = acc[i][sp * 4 + q][r];
+                            s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q];
+                        }
+                        if constexpr (ACC) {
+                            const bf16x4 o = __builtin_bit_cast(bf16x4, old[r][sp]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
+                        }
+                        bf16x4 w;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, w), drsrc, voff(i, r, sp), 0, 0);
+                    }
+            }
+        }
+    };
+
+    // The first block of rows is requested BEFORE the weight tile is fetched into LDS: the two round trips overlap.
+    bf16x8 A0[MT][NKS], A1[MT][NKS];
+    load(A0, 0);
+    constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;       // every 64-channel panel the K steps of the loop read (zeros past K)
+    for (int u = tid; u < BN * NPAN * 8; u += 256) {
         const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
         const int l = L & 63;
         const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
@@ -204,118 +353,15 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     }
     __syncthreads();
 
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
-    const long n_groups = (p.M + RG - 1) / RG;
-    const long my_groups = rb < n_groups ? (n_groups - rb + bpn - 1) / bpn : 0;
-    const long units = my_groups * H;                                      // (row group, K half) pairs
-
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    auto load = [&](bf16x8 (&A)[MT][4], long u) {
-        const long g = rb + (u / H) * bpn;
-        const int h = (int)(u % H);
-        const long r0 = g * RG + wave * (MT * 16);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const long row = r0 + i * 16 + frow;
-            const int base = row < p.M ? (int)((row * p.ld_src + fq * 8 + h * 128) * 2) : OOB;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int vo = (h * 128 + ks * 32 + fq * 8 < p.K) ? base + ks * 64 : OOB;
-                if (h * 4 + ks < nks) {
-                    v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
-                    A[i][ks] = __builtin_bit_cast(bf16x8, t);
-                }
-            }
-        }
-    };
-
-    f32x4 acc[MT][NTW];
-    float s1[NTW], s2[NTW];
-#pragma unroll
-    for (int q = 0; q < NTW; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-    constexpr bool infer = EPI == 2;                        // eval mode: y = act(acc + bias) + residual
-    float ibias[NTW];
-#pragma unroll
-    for (int q = 0; q < NTW; ++q) {
-        const int c = n0 + (q >> 2) * 64 + 4 * frow + (q & 3);
-        ibias[q] = (infer && c < p.N) ? p.bias[c] : 0.f;
-    }
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int q = 0; q < NTW; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-    auto compute = [&](bf16x8 (&A)[MT][4], long u) {
-        const int h = (int)(u % H);
-        if (h == 0) zero_acc();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = h * 4 + ks;
-            if (kk < nks) {
-#pragma unroll
-                for (int sp = 0; sp < SP; ++sp) {
-                    bf16x8 fb[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        fb[q] = *reinterpret_cast<const bf16x8*>(smem + (kk >> 1) * (BN * 128) + swz(sp * 64 + q * 16 + frow, (kk & 1) * 4 + fq));
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[i][sp * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], fb[q], acc[i][sp * 4 + q], 0, 0, 0);
-                }
-            }
-        }
-        if (h != H - 1) return;
-        const long g = rb + (u / H) * bpn;
-        const long r0 = g * RG + wave * (MT * 16);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = r0 + i * 16 + 4 * fq + r;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int sp = 0; sp < SP; ++sp) {
-                    const int c0 = n0 + sp * 64 + 4 * frow;
-                    float v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[q] = acc[i][sp * 4 + q][r];
-                        if (infer) {
-                            v[q] = act_fwd(v[q] + ibias[sp * 4 + q], p.epi_act);
-                            if (p.epi_res && c0 + q < p.N) v[q] += (float)p.epi_res[m * p.epi_ldres + c0 + q];
-                        } else { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }
-                    }
-                    bf16* d = reinterpret_cast<bf16*>(p.dst) + m * p.ld_dst + c0;
-                    if (c0 + 3 < p.N) {
-                        if (p.accumulate) {
-                            bf16x4 o = *reinterpret_cast<const bf16x4*>(d);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] += (float)o[q];
-                        }
-                        bf16x4 w;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
-                        *reinterpret_cast<bf16x4*>(d) = w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (c0 + q < p.N) d[q] = (bf16)(p.accumulate ? (float)d[q] + v[q] : v[q]);
-                    }
-                }
-            }
-        }
-    };
-
-    bf16x8 A0[MT][4], A1[MT][4];
-    if (units > 0) load(A0, 0);
+    // Two blocks per iteration, nothing conditional inside: with H = 2 block 0 is the first K half and block 1 the second of the
+    // same rows; with H = 1 both are whole row blocks, and when `units` is odd the last block 1 is a unit past the end - its rows
+    // are >= M, so it loads zeros, stores nothing and adds zeros to the statistics.
+#pragma unroll 1
     for (long u = 0; u < units; u += 2) {
-        if (u + 1 < units) load(A1, u + 1);
-        compute(A0, u);
-        if (u + 2 < units) load(A0, u + 2);
-        if (u + 1 < units) compute(A1, u + 1);
+        load(A1, u + 1);
+        compute(A0, u, std::integral_constant<int, 0>{});
+        load(A0, u + 2);
+        compute(A1, u + 1, std::integral_constant<int, H - 1>{});
     }
 
     if (p.stats) {
@@ -344,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     }
 }
 
-template <int BN, int H>
+template <int BN, int H, int NKS>
 void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     constexpr int RG = 128;
     const int n_tiles = ep24_cdiv(a.N, BN);
@@ -352,44 +398,20 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
     long bpn = (512 / n_tiles + 7) / 8 * 8;
     if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
-    const int npan = (a.K + 63) / 64;
-    size_t lds = (size_t)npan * BN * 128;
+    constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;          // as in the kernel: all panels its K steps touch
+    size_t lds = (size_t)NPAN * BN * 128;
     if (lds < 4096) lds = 4096;                                // the statistics fold: [4 waves][2][BN] floats
-    if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
-    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0>), dim3((unsigned)(bpn * n_tiles)), dim3(256), lds, stream, a, (int)bpn);
+    const dim3 grid((unsigned)(bpn * n_tiles));
+    if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
+    else if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
 }
 
-template <typename K>
-int big_lds(K kfn, size_t lds) {                 // more than 64 KB of dynamic LDS: the attribute, once per device and instantiation
-    if (lds <= 64 * 1024) return EP24_OK;
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv: hipGetDevice failed");
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", dev, hipGetErrorString(e));
-        done.fetch_or(bit, std::memory_order_release);
-    }
-    return EP24_OK;
-}
-
-template <int BN, bool F32, int NS = 2>
-int launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
-    constexpr size_t lds = NS * (BM * 128 + BN * 128);
-    if (a.epi_infer && !F32) {
-        hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), 2 * (BM * 128 + BN * 128), stream, a);
-        return EP24_OK;
-    }
-    if (int rc = big_lds(igemm_dma_kernel<BN, F32, 0, NS>, lds)) return rc;
-    hipLaunchKernelGGL((igemm_dma_kernel<BN, F32, 0, NS>), dim3(tiles), dim3(256), lds, stream, a);
-    return EP24_OK;
-}
-
-// Ring depth of the tiled kernel for a shape (2 = the two-stage loop).  Set from tools/ring_ab.py measurements.
-int ring_stages(const IgemmArgs& a, bool wide) {
-    (void)a; (void)wide;
-    return 2;
+template <int BN, bool F32>
+void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
+    constexpr size_t lds = 2 * (BM * 128 + BN * 128);
+    if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(tiles), dim3(256), lds, stream, a);
 }
 
 // The kernels address their operands with 32-bit byte offsets through buffer descriptors (out-of-range = zero fill is how
@@ -404,20 +426,49 @@ int check_extents(const IgemmArgs& a) {
 }
 
 // dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming)
-int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, bool dry = false, int* kernel_id = nullptr) {
-    if (!dry) { if (int rc = check_extents(a)) return rc; }
+void prepare(IgemmArgs& a, int kernel_opts) {
     a.narrow_epi = (kernel_opts & KOPT_NARROW_EPI) ? 1 : 0;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
+    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
+}
+
+// the classes of a stride-2 input gradient as one launch of the tiled kernel (bf16 output, no bias / statistics)
+int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
+    IgemmMulti q{};
+    q.n = n;
+    bool wide = true;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = check_extents(cls[i])) return rc;
+        prepare(cls[i], kernel_opts);
+        wide = wide && cls[i].N > 64 && (long)ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, 128) > 256;
+    }
+    for (int i = 0; i < n; ++i) {
+        q.a[i] = cls[i];
+        q.prefix[i + 1] = q.prefix[i] + ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, wide ? 128 : 64);
+    }
+    const dim3 grid((unsigned)q.prefix[n]);
+    if (wide) hipLaunchKernelGGL((igemm_dma_multi_kernel<128>), grid, dim3(256), 2 * (BM * 128 + 128 * 128), stream, q);
+    else hipLaunchKernelGGL((igemm_dma_multi_kernel<64>), grid, dim3(256), 2 * (BM * 128 + 64 * 128), stream, q);
+    EP24_LAUNCH_CHECK("ep24_conv_igemm_multi");
+    return EP24_OK;
+}
+
+int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, bool dry = false, int* kernel_id = nullptr) {
+    if (!dry) { if (int rc = check_extents(a)) return rc; }
+    prepare(a, kernel_opts);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
+    const long dst_b = ((a.M - 1) * a.ld_dst + a.N) * 2;     // the streaming kernel stores through a buffer descriptor (32-bit offsets)
     if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
-        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0) {
+        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L) {
         if (dry) { *kernel_id = 2; return EP24_OK; }
+        a.dst_bytes = (unsigned)dst_b;
         // 128-wide tiles where N fills them (a 256-wide tile - one pass of the rows for N = 256 - needs 400 registers and a whole CU
         // per workgroup: 68 against 50 us on 80x80x256->256 with cold operands, tools/stream_ab.py)
-        if (a.N > 64) { if (a.K > 128) launch_stream<128, 2>(a, stream); else launch_stream<128, 1>(a, stream); }
-        else          { if (a.K > 128) launch_stream<64, 2>(a, stream); else launch_stream<64, 1>(a, stream); }
+        // K steps of 32 per K half: 2 for K <= 64, else 4 (a K tail is zero-filled on both operands)
+        if (a.N > 64) { if (a.K > 128) launch_stream<128, 2, 4>(a, stream); else if (a.K > 64) launch_stream<128, 1, 4>(a, stream); else launch_stream<128, 1, 2>(a, stream); }
+        else          { if (a.K > 128) launch_stream<64, 2, 4>(a, stream); else if (a.K > 64) launch_stream<64, 1, 4>(a, stream); else launch_stream<64, 1, 2>(a, stream); }
         EP24_LAUNCH_CHECK("ep24_conv_igemm_stream");
         return EP24_OK;
     }
@@ -437,16 +488,13 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     // double the workgroups (+3 .. +27 % on those layers)
     const bool wide = a.N > 64 && (long)ep24_cdiv(a.M, BM) * ep24_cdiv(a.N, 128) > 256;
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, wide ? 128 : 64);
-    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
-    // ring depth: kernel_opts bits 2-3 choose it for A/B runs (1: three stages, 2: four); 0 = the dispatch rule
-    int ns = ring_stages(a, wide);
-    if ((kernel_opts >> 2) & 3) ns = 2 + ((kernel_opts >> 2) & 3);
-    if (kernel_opts & KOPT_TWO_STAGE) ns = 2;
-    int rc = EP24_OK;
-    if (out_f32) rc = wide ? launch_variant<128, true>(a, tiles, stream) : launch_variant<64, true>(a, tiles, stream);
-    else if (wide) rc = ns == 4 ? launch_variant<128, false, 4>(a, tiles, stream) : ns == 3 ? launch_variant<128, false, 3>(a, tiles, stream) : launch_variant<128, false>(a, tiles, stream);
-    else rc = ns == 4 ? launch_variant<64, false, 4>(a, tiles, stream) : ns == 3 ? launch_variant<64, false, 3>(a, tiles, stream) : launch_variant<64, false>(a, tiles, stream);
-    if (rc) return rc;
+    if (wide) {
+        if (out_f32) launch_variant<128, true>(a, tiles, stream);
+        else launch_variant<128, false>(a, tiles, stream);
+    } else {
+        if (out_f32) launch_variant<64, true>(a, tiles, stream);
+        else launch_variant<64, false>(a, tiles, stream);
+    }
     EP24_LAUNCH_CHECK("ep24_conv_igemm");
     return EP24_OK;
 }
@@ -547,6 +595,8 @@ static int conv_dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* 
     EP24_REQUIRE(H % 2 == 0 && W % 2 == 0, EP24_E_UNSUPPORTED, "conv_dgrad s2: odd spatial size %dx%d", H, W);
     // a 1x1 stride-2 conv reaches only the even pixels: as first writer it would leave the other three quarters of dx stale
     EP24_REQUIRE(ksize != 1 || accumulate, EP24_E_UNSUPPORTED, "conv_dgrad k=1 s=2 only accumulates (run it after another producer of dx)");
+    IgemmArgs cls[4];
+    int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             IgemmArgs c = a;
@@ -561,11 +611,15 @@ static int conv_dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* 
                     ++c.T;
                 }
             c.M = (long)B * c.GH * c.GW;
-            if (c.T == 0) continue;   // (k=1, odd parity): nothing reaches these pixels; caller zero-fills via accumulate=0 path below
-            int rc = launch(c, false, (hipStream_t)stream, kernel_opts);
-            if (rc) return rc;
+            if (c.T == 0) continue;   // (k=1, odd parity): nothing reaches these pixels (the entry point only accumulates then)
+            cls[ncls++] = c;
         }
-    return EP24_OK;
+    if (kernel_opts & KOPT_PER_CLASS) {                       // A/B: one launch per class, as before round 3
+        for (int i = 0; i < ncls; ++i)
+            if (int rc = launch(cls[i], false, (hipStream_t)stream, kernel_opts)) return rc;
+        return EP24_OK;
+    }
+    return launch_multi(cls, ncls, (hipStream_t)stream, kernel_opts);
 }
 
 extern "C" int ep24_conv_dgrad_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,

@@ -12,7 +12,6 @@
 // Workgroup = 128 co x 128 ci of one tap, 4 waves (2x2 of 64x64), 64 pixels per K-step; pixels are split
 // over blockIdx.y and combined with fp32 atomics (device scope, one 64-B segment per 16 lanes).
 #include <stdlib.h>
-#include <atomic>
 #include "common.h"
 
 namespace {
@@ -25,7 +24,6 @@ struct WgradArgs {
     long M;          // B*OH*OW
     long chunk;      // pixels per split (multiple of 64)
     int tiles_ci, tiles_co, T, tiles, xcd_remap;
-    int ring;        // LDS ring depth of the kernel (2 = the two-stage loop)
     FastDiv d_plane, d_ow;      // pixel -> (n, oh, ow)
     unsigned x_bytes, dy_bytes; // extents for the buffer descriptors
     int c_n, c_oh, c_ow, c_pix; // byte strides of X per image / output row / output column / input pixel
@@ -71,10 +69,7 @@ template <int OFF_LO, int OFF_HI> __device__ __forceinline__ bf16x8 tr_pair(unsi
 // the 32-B-block permutation is applied to the per-lane SOURCE channel; rows past the pixel range, padding taps
 // and channel tails use an out-of-range buffer offset (the DMA then writes zeros).  Two stages, one barrier per
 // 64-pixel step.
-// NS = 2: two stages, one __syncthreads() (vmcnt(0) + barrier) per 64-pixel step.  NS > 2: a ring with NS - 1 steps in flight,
-// retired by a counted vmcnt and a raw s_barrier (every step issues the same number of DMA instructions; past the last step they
-// are zero fills into a stage nobody reads).  Same products in the same order: bit-identical slabs.
-template <int TCO, int TCI, int NS = 2>
+template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2, STAGE = Y_BYTES + X_BYTES;
     constexpr int FM = TCO / 32, FN = TCI / 32;          // 16x16 fragments per wave along co / ci
@@ -124,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // per lane, carried from step to step by constant deltas plus at most one wrap of ow and of oh - into a small LDS
     // table two steps ahead; a DMA instruction then costs one ds_read_b32 and one add.  (Decoding per DMA instruction,
     // two divisions and 64-bit multiplies each, kept the VALU busier than the MFMAs: 90 -> 62 us per 3x3 256-ch layer.)
-    int* xtab = reinterpret_cast<int*>(smem + NS * STAGE);         // [NS][64] byte offsets, XOOB = padding / past the end
+    int* xtab = reinterpret_cast<int*>(smem + 2 * STAGE);          // [2][64] byte offsets, XOOB = padding / past the end
     constexpr int XOOB = 0x7FFF0000;
     int x_row[XI], x_colb[XI];
 #pragma unroll
@@ -160,7 +155,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     auto issue = [&](int it, int buf) {
         char* stage = smem + buf * STAGE;
         const int rows_left = p_end_i - (int)p_begin - it * 64;
-        const int* tab = xtab + (NS == 2 ? (it & 1) : buf) * 64;
+        const int* tab = xtab + (it & 1) * 64;
         int xo[XI];
 #pragma unroll
         for (int j = 0; j < XI; ++j) xo[j] = tab[x_row[j]];
@@ -195,41 +190,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) xa[j] = lds0 + Y_BYTES + tr_off<TCI>(fq * 8 + q, wn * FN + j, pp4);
 
-    if constexpr (NS == 2) {
-        produce(0);
-        produce(1);
-        __syncthreads();
-        if (n_iter > 0) issue(0, 0);
-    } else {
-#pragma unroll
-        for (int s0 = 0; s0 < NS; ++s0) produce(s0);          // offsets of steps 0 .. NS-1 (slot = step % NS = ring stage)
-        __syncthreads();
-#pragma unroll
-        for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0, s0);    // NS - 1 steps in flight (zero fills past the end)
-    }
-    int st = 0;                                                // ring stage of step `it`
-#pragma unroll 1
+    produce(0);
+    produce(1);
+    __syncthreads();
+    if (n_iter > 0) issue(0, 0);
     for (int it = 0; it < n_iter; ++it) {
-        if constexpr (NS == 2) {
-            __syncthreads();                 // vmcnt(0) + barrier: step `it` landed, the other stage is free
-            produce(it & 1);                 // offsets of step it+2; slot it&1 was last read when step `it` was issued
-            if (it + 1 < n_iter) issue(it + 1, (it + 1) & 1);
-        } else {
-            // this wave's DMAs of step `it` have landed when at most the NS - 2 younger steps' are outstanding; after the barrier
-            // every wave's have, and nobody still reads stage (it - 1) % NS or the table slot of step `it`
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (YI + XI)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            const int prev = st == 0 ? NS - 1 : st - 1;
-            issue(it + NS - 1, prev);        // reads table slot `prev` (step it+NS-1, produced one iteration ago)
-            produce(st);                     // offsets of step it+NS into the slot step `it` was issued from
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        __syncthreads();                 // vmcnt(0) + barrier: step `it` landed, the other stage is free
+        produce(it & 1);                 // offsets of step it+2; slot it&1 was last read when step `it` was issued
+        if (it + 1 < n_iter) issue(it + 1, (it + 1) & 1);
         // Fragment reads are inline asm: the compiler puts an s_waitcnt vmcnt(0) in front of the
         // ds_read_tr16_b64 BUILTIN (it treats it as a possible LDS store that must order behind the LDS-DMA just
         // issued), which serialised every step's DMA round trip with its MFMAs.  LDS returns in order and lgkmcnt
         // saturates at 15, so once all 32 reads are issued the 16 of the first 32-pixel half have landed.
-        const unsigned sb = (unsigned)((NS == 2 ? (it & 1) : st) * STAGE);
-        if constexpr (NS > 2) st = st + 1 == NS ? 0 : st + 1;
+        const unsigned sb = (unsigned)((it & 1) * STAGE);
         bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) fa0[i] = tr_pair<0, 4 * TCO * 2>(ya[i] + sb);
@@ -275,6 +248,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             for (int r = 0; r < 4; ++r)
                 tile[(wm * (TCO / 2) + i * 16 + 4 * fq + r) * TCI + wn * (TCI / 2) + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
+    // slab form with whole 4-channel groups: 16-byte stores, a wave covers 8 rows x 128 B (64 x 64 tile) or 4 rows x 256 B per
+    // instruction - a quarter of the store instructions of the 4-byte form below (the store tail is issue bound)
+    if (p.slab && (p.cin_valid & 3) == 0 && (p.ld_dw & 3) == 0 && ((long)tap * p.cin_valid & 3) == 0 &&
+        (((unsigned long long)p.slab | (unsigned long long)(p.slab_stride * 4)) & 15) == 0) {
+        constexpr int C4 = TCI / 4;                                // float4 groups per tile row
+        float* base = p.slab + (long)by * p.slab_stride + (long)tap * p.cin_valid + ci0;
+        for (int u = tid; u < TCO * C4; u += 256) {
+            const int row = u / C4, c4 = u - row * C4;
+            const int co = co0 + row;
+            if (co < p.cout_valid && ci0 + c4 * 4 < p.cin_valid)
+                *reinterpret_cast<f32x4*>(base + (long)co * p.ld_dw + c4 * 4) = *reinterpret_cast<const f32x4*>(tile + row * TCI + c4 * 4);
+        }
+        return;
+    }
     for (int row = wave; row < TCO; row += 4) {
         const int co = co0 + row;
         if (co >= p.cout_valid) break;
@@ -305,9 +292,7 @@ template <int TCO, int TCI>
 long wgrad_splits(const WgradArgs& a) {
     const int tiles = ep24_cdiv(a.Cin, TCI) * ep24_cdiv(a.Cout, TCO) * a.T;
     const bool small = TCO == 64 && TCI == 64, big = TCO == 128 && TCI == 128;
-    const int ns = a.ring > 2 ? a.ring : 2;
-    const long per_cu = (160L * 1024) / ((long)ns * 64 * (TCO + TCI) * 2 + 256 * ns);
-    const long slots = 256L * (ns == 2 ? (small ? 4 : (big ? 2 : 3)) : (per_cu > 4 ? 4 : per_cu));
+    const long slots = 256L * (small ? 4 : (big ? 2 : 3));
     const long min_steps = small ? 16 : 8;
     const long steps = (a.M + 63) / 64;
     long splits = slots / tiles;
@@ -316,26 +301,8 @@ long wgrad_splits(const WgradArgs& a) {
     return splits;                                          // trailing splits may be empty (they contribute zeros)
 }
 
-template <int TCO, int TCI, int NS>
-int launch_ring(const WgradArgs& a, dim3 grid, hipStream_t stream) {
-    constexpr size_t lds = (size_t)NS * 64 * (TCO + TCI) * 2 + 256 * NS;
-    if (lds > 64 * 1024) {                                  // the attribute, once per device and instantiation
-        static std::atomic<unsigned long long> done{0};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done.load(std::memory_order_acquire) & bit)) {
-            EP24_REQUIRE(hipFuncSetAttribute((const void*)wgrad_kernel<TCO, TCI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
-                         EP24_E_LAUNCH, "conv_wgrad: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d", dev);
-            done.fetch_or(bit, std::memory_order_release);
-        }
-    }
-    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI, NS>), grid, dim3(256), lds, stream, a);
-    return EP24_OK;
-}
-
 template <int TCO, int TCI>
-int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
     const int tiles = a.tiles_ci * a.tiles_co * a.T;
     long steps = (a.M + 63) / 64;
@@ -344,10 +311,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles = tiles;
     a.xcd_remap = 1;
     dim3 grid((unsigned)(tiles * splits));
-    if (a.ring == 3) return launch_ring<TCO, TCI, 3>(a, grid, stream);
-    if (a.ring == 4) return launch_ring<TCO, TCI, 4>(a, grid, stream);
     hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
-    return EP24_OK;
 }
 
 int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw, int cout_valid,
@@ -381,14 +345,6 @@ int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t
     return EP24_OK;
 }
 
-// Ring depth for a shape (2 = the two-stage loop); kernel_opts bits 2-3 of the _ex entry points override it (1: 3 stages, 2: 4).
-// Set from tools/ring_ab.py measurements.
-void ring_choice(WgradArgs& a, int kernel_opts) {
-    a.ring = 2;
-    if ((kernel_opts >> 2) & 3) a.ring = 2 + ((kernel_opts >> 2) & 3);
-    if (kernel_opts & 16) a.ring = 2;
-}
-
 // tile shape: 1x1 layers are tall-skinny (huge pixel count, small dW): 64x64 tiles quarter the epilogue bytes per workgroup
 void tile_choice(const WgradArgs& a, bool& co64, bool& ci64) {
     co64 = a.Cout <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
@@ -404,13 +360,13 @@ long splits_of(const WgradArgs& a) {
     return wgrad_splits<128, 128>(a);
 }
 
-int dispatch(WgradArgs& a, hipStream_t stream) {
+void dispatch(WgradArgs& a, hipStream_t stream) {
     bool co64, ci64;
     tile_choice(a, co64, ci64);
-    if (co64 && ci64) return launch_wgrad<64, 64>(a, stream);
-    if (co64) return launch_wgrad<64, 128>(a, stream);
-    if (ci64) return launch_wgrad<128, 64>(a, stream);
-    return launch_wgrad<128, 128>(a, stream);
+    if (co64 && ci64) launch_wgrad<64, 64>(a, stream);
+    else if (co64) launch_wgrad<64, 128>(a, stream);
+    else if (ci64) launch_wgrad<128, 64>(a, stream);
+    else launch_wgrad<128, 128>(a, stream);
 }
 
 // gflat[off + i] += sum_s slab[slab_off + s * numel + i] for a list of layers: desc rows (off, numel, splits, slab_off)
@@ -460,43 +416,30 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     EP24_REQUIRE(x && dy && dw, EP24_E_ARG, "conv_wgrad: null pointer");
     WgradArgs a{};
     if (int rc = fill_args(a, x, ld_x, dy, ld_dy, dw, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
-    ring_choice(a, 0);
-    if (int rc = dispatch(a, (hipStream_t)stream)) return rc;
+    dispatch(a, (hipStream_t)stream);
     EP24_LAUNCH_CHECK("ep24_conv_wgrad");
     return EP24_OK;
 }
 
-extern "C" int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts) {
+extern "C" int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
     WgradArgs a{};
     if (int rc = fill_args(a, nullptr, 8, nullptr, 8, nullptr, 0, Cout, Cin, B, H, W, Cin, Cout, ksize, stride)) return rc;
-    ring_choice(a, kernel_opts);
     return (int)splits_of(a);
-}
-
-extern "C" int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
-    return ep24_conv_wgrad_splits_ex(B, H, W, Cin, Cout, ksize, stride, 0);
-}
-
-extern "C" int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
-                                            int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
-                                            int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream) {
-    EP24_REQUIRE(x && dy && slab, EP24_E_ARG, "conv_wgrad_slab: null pointer");
-    WgradArgs a{};
-    if (int rc = fill_args(a, x, ld_x, dy, ld_dy, nullptr, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
-    ring_choice(a, kernel_opts);
-    a.slab = slab;
-    a.slab_stride = (long)cout_valid * ld_dw;
-    EP24_REQUIRE(splits_of(a) * a.slab_stride <= slab_floats, EP24_E_ARG, "conv_wgrad_slab: slab holds %ld floats, %ld needed",
-                 (long)slab_floats, splits_of(a) * a.slab_stride);
-    if (int rc = dispatch(a, (hipStream_t)stream)) return rc;
-    EP24_LAUNCH_CHECK("ep24_conv_wgrad_slab");
-    return EP24_OK;
 }
 
 extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
                                          int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
                                          int W, int Cin, int Cout, int ksize, int stride, void* stream) {
-    return ep24_conv_wgrad_slab_bf16_ex(x, ld_x, dy, ld_dy, slab, slab_floats, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride, 0, stream);
+    EP24_REQUIRE(x && dy && slab, EP24_E_ARG, "conv_wgrad_slab: null pointer");
+    WgradArgs a{};
+    if (int rc = fill_args(a, x, ld_x, dy, ld_dy, nullptr, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
+    a.slab = slab;
+    a.slab_stride = (long)cout_valid * ld_dw;
+    EP24_REQUIRE(splits_of(a) * a.slab_stride <= slab_floats, EP24_E_ARG, "conv_wgrad_slab: slab holds %ld floats, %ld needed",
+                 (long)slab_floats, splits_of(a) * a.slab_stride);
+    dispatch(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_conv_wgrad_slab");
+    return EP24_OK;
 }
 
 extern "C" int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream) {

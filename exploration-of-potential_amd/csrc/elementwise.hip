@@ -46,18 +46,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
     float* sh = lds + CP;
     auto pad = [](int c) { return c + (c >> 3); };
     for (int c = threadIdx.x; c < C; c += 256) {
+        // All replica loads of a channel are issued TOGETHER (8 per batch, index clamped instead of a conditional load): written
+        // as `for (r < reps) sum += stats[...]` the compiler waited for every pair before it issued the next one - eight serial
+        // L2 round trips in front of every block of every BatchNorm forward launch (most of its ~6 us fixed cost).
         long long i1 = 0, i2 = 0;
-        for (int r = 0; r < reps; ++r) {
-            i1 += stats[(long)r * 2 * C + c];
-            i2 += stats[(long)r * 2 * C + C + c];
+        const float gmm = gamma[c], bta = beta[c];          // requested with the statistics, not behind them
+        for (int rb = 0; rb < reps; rb += 8) {
+            long long a[8], b[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = rb + r < reps ? rb + r : rb;
+                a[r] = stats[(long)rr * 2 * C + c];
+                b[r] = stats[(long)rr * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                i1 += rb + r < reps ? a[r] : 0ll;
+                i2 += rb + r < reps ? b[r] : 0ll;
+            }
         }
         const float mean = from_fix(i1) / (float)M;
         float var = from_fix(i2) / (float)M - mean * mean;
         var = var < 0.f ? 0.f : var;
         const float invstd = rsqrtf(var + eps);
-        const float s_ = gamma[c] * invstd;
+        const float s_ = gmm * invstd;
         sc[pad(c)] = s_;
-        sh[pad(c)] = beta[c] - mean * s_;
+        sh[pad(c)] = bta - mean * s_;
         if (blockIdx.x == 0) {
             save[c] = mean;
             save[C + c] = invstd;
@@ -136,7 +150,7 @@ template <int UNROLL, int NT, int ACT>
 __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma,
                                                                const float* beta, long long* dgamma, long long* dbeta,
-                                                               long M, int C) {
+                                                               long M, int C, int reps) {
     constexpr int act = ACT;
     // Wide blocks (NT threads) so that one batch of UNROLL rows per thread covers the tensor with few blocks: the
     // per-block cost is 2*C memory-side int64 atomics, and all of a thread's loads are in flight at once.
@@ -154,11 +168,11 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
             bf16x8 vdy[UNROLL], vz[UNROLL];
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {                  // first batch issued before the constants are needed
-                const long mm = m_first + k * step;
-                if (mm < M) {
-                    vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
-                    vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
-                }
+                // every load is issued (a row past M re-reads row m_first and is never used): guarded by `if (mm < M)` the
+                // compiler put an s_waitcnt vmcnt(0) in front of each pair - four serial round trips, the whole kernel on a 20x20 layer
+                const long mm = m_first + k * step < M ? m_first + k * step : (m_first < M ? m_first : 0);
+                vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
+                vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
             }
             float sc[8], sh[8], iv[8], mi[8];
 #pragma unroll
@@ -179,10 +193,11 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
                         sg[j] = fmaf(du, fmaf(zz, iv[j], -mi[j]), sg[j]);
                     }
                 }
+                if (m + UNROLL * step < M) {                      // another batch follows (uniform per thread): all of it is issued
 #pragma unroll
-                for (int k = 0; k < UNROLL; ++k) {
-                    const long mm = m + (UNROLL + k) * step;
-                    if (mm < M) {
+                    for (int k = 0; k < UNROLL; ++k) {
+                        const long mn = m + (UNROLL + k) * step;
+                        const long mm = mn < M ? mn : m;
                         vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
                         vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
                     }
@@ -198,7 +213,9 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
             const int g = t >> 4, v = t & 15;
             float a = 0.f;
             for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
-            long long* dst = (v < 8 ? dgamma : dbeta) + (cg0 + g) * 8 + (v & 7);
+            // replica blockIdx % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
+            // addresses at about the same time - 256 serial adds per address at the memory-side atomic units, ~5 us of tail
+            long long* dst = (v < 8 ? dgamma : dbeta) + (long)(blockIdx.x % reps) * 2 * C + (cg0 + g) * 8 + (v & 7);
             atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(a));
         }
         __syncthreads();
@@ -209,28 +226,71 @@ template <int UNROLL, int ACT, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
                                                                const float* save, const float* gamma, const float* beta,
                                                                const long long* dgamma, const long long* dbeta, float* ggrad,
-                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C) {
+                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C, int reps) {
     constexpr int act = ACT;
     const RowMap rm(C);
     const int tid = threadIdx.x;
     const float invM = 1.f / (float)M;
+    // fold the replicas of the two sums ([reps][2][C] fixed point) once per block: thread t takes entries t, t + 256, ... of the
+    // 2 C, all replica loads of an entry issued together (index clamped, never a conditional load); exact integer sums, so the
+    // result does not depend on which block added to which replica
+    extern __shared__ float folded[];                           // [2][C]: sum of du * zhat, sum of du
+    for (int i = tid; i < 2 * C; i += 256) {
+        const long long* src = i < C ? dgamma + i : dbeta + (i - C);
+        long long acc = 0;
+        for (int rb = 0; rb < reps; rb += 8) {
+            long long a[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] = src[(long)(rb + r < reps ? rb + r : rb) * 2 * C];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc += rb + r < reps ? a[r] : 0ll;
+        }
+        folded[i] = from_fix(acc);
+    }
+    __syncthreads();
     for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048
         const int slot = rm.tpr >= 256 ? 0 : tid / rm.tpr;
         if (slot >= rm.rpb) break;
         float sc[8], sh[8], k1[8], k2[8], k3[8];
+        // The 8 channels' constants come in as 16-byte vector loads, all issued before the first is used.  Channel by channel (with
+        // the conditional `ggrad[c] += ...` between them, which the loads of the next channel may not pass) the prologue was eight
+        // serial L2 round trips in every block: ~3 us of every launch.
+        float cm[8], ci[8], cg_[8], cb[8], csg[8], csb[8];
+        {
+            const f32x4* pm = reinterpret_cast<const f32x4*>(save + cg * 8);
+            const f32x4* pi = reinterpret_cast<const f32x4*>(save + C + cg * 8);
+            const f32x4* pg = reinterpret_cast<const f32x4*>(gamma + cg * 8);
+            const f32x4* pb = reinterpret_cast<const f32x4*>(beta + cg * 8);
+            const f32x4 m0 = pm[0], m1 = pm[1], i0 = pi[0], i1 = pi[1], g0 = pg[0], g1 = pg[1], b0 = pb[0], b1 = pb[1];
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(folded + cg * 8), s1 = *reinterpret_cast<const f32x4*>(folded + cg * 8 + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(folded + C + cg * 8), t1 = *reinterpret_cast<const f32x4*>(folded + C + cg * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cm[j] = m0[j]; cm[4 + j] = m1[j]; ci[j] = i0[j]; ci[4 + j] = i1[j]; cg_[j] = g0[j]; cg_[4 + j] = g1[j]; cb[j] = b0[j]; cb[4 + j] = b1[j];
+                csg[j] = s0[j]; csg[4 + j] = s1[j]; csb[j] = t0[j]; csb[4 + j] = t1[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            const float mean = save[c], inv = save[C + c], g = gamma[c];
-            const float sg_ = from_fix(dgamma[c]), sb_ = from_fix(dbeta[c]);
-            sc[j] = g * inv; sh[j] = beta[c] - mean * sc[j];
+            const float mean = cm[j], inv = ci[j], g = cg_[j];
+            const float sg_ = csg[j], sb_ = csb[j];
+            sc[j] = g * inv; sh[j] = cb[j] - mean * sc[j];
             k1[j] = g * inv;
             k3[j] = k1[j] * inv * (sg_ * invM);
             k2[j] = k1[j] * (sb_ * invM) - k3[j] * mean;
-            if (blockIdx.x == 0 && slot == 0 && ggrad) {      // publish this call's sums into the parameter gradients
-                ggrad[c] += sg_;
-                bgrad[c] += sb_;
+        }
+        if (blockIdx.x == 0 && slot == 0 && ggrad) {          // publish this call's sums into the parameter gradients
+            // as four 16-byte read-modify-writes issued together: element by element this was 16 serial round trips in block 0,
+            // which every launch then waited for
+            f32x4* pgg = reinterpret_cast<f32x4*>(ggrad + cg * 8);
+            f32x4* pbg = reinterpret_cast<f32x4*>(bgrad + cg * 8);
+            f32x4 a0 = pgg[0], a1 = pgg[1], c0 = pbg[0], c1 = pbg[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] += csg[j]; a1[j] += csg[4 + j];
+                c0[j] += csb[j]; c1[j] += csb[4 + j];
             }
+            pgg[0] = a0; pgg[1] = a1; pbg[0] = c0; pbg[1] = c1;
         }
         const long step = (long)gridDim.x * rm.rpb;
         for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += UNROLL * step) {
@@ -819,20 +879,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, long 
 // All conv segments in ONE launch: desc[s] = {master offset, fwd offset, dgrad offset (-1: none), Cout, T, Cin,
 // Cin_pad, Cout_pad}; prefix[s] = first flat element index of segment s in the packed enumeration.
 __global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, const long* desc, const long* prefix, int n_seg,
-                                                          bf16* wf, bf16* wd) {
+                                                          bf16* wf, bf16* wd, const int* chunk_seg) {
     __shared__ int s_first;
     const long total = prefix[n_seg];
     for (long base = (long)blockIdx.x * 4096; base < total; base += (long)gridDim.x * 4096) {
-        if (threadIdx.x == 0) {
-            int lo = 0, hi = n_seg - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (prefix[mid] <= base) lo = mid; else hi = mid - 1;
+        // chunk_seg[c] = segment of element 4096 c (built once by the host): one load.  Without it thread 0 bisects the prefix table
+        // - eight dependent loads while 255 threads wait, three quarters of this kernel's time.
+        int seg;
+        if (chunk_seg) {
+            seg = chunk_seg[base >> 12];
+        } else {
+            if (threadIdx.x == 0) {
+                int lo = 0, hi = n_seg - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (prefix[mid] <= base) lo = mid; else hi = mid - 1;
+                }
+                s_first = lo;
             }
-            s_first = lo;
+            __syncthreads();
+            seg = s_first;
         }
-        __syncthreads();
-        int seg = s_first;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const long i = base + 4 * (threadIdx.x + 256 * k);       // four consecutive elements per thread
@@ -860,31 +927,37 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const float* flat, co
                 }
             }
         }
-        __syncthreads();
+        if (!chunk_seg) __syncthreads();
     }
 }
 
 // dgrad copy [Cin][T][Cout_pad] = transpose of the master [Cout][T][Cin] per tap: 64x64 tiles through LDS so that both
 // the fp32 reads (along ci) and the bf16 writes (along co) are coalesced.  tprefix[s] = first tile of segment s.
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* flat, const long* desc, const long* tprefix, int n_seg,
-                                                            bf16* wd) {
+                                                            bf16* wd, const int* tile_seg) {
     __shared__ float tile[64][65];
     __shared__ int s_seg;
     const long total = tprefix[n_seg];
     for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
-        if (threadIdx.x == 0) {
-            int lo = 0, hi = n_seg - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (tprefix[mid] <= tl) lo = mid; else hi = mid - 1;
+        int sg;
+        if (tile_seg) {
+            sg = tile_seg[tl];                                  // segment of tile tl, built once by the host
+        } else {
+            if (threadIdx.x == 0) {
+                int lo = 0, hi = n_seg - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (tprefix[mid] <= tl) lo = mid; else hi = mid - 1;
+                }
+                s_seg = lo;
             }
-            s_seg = lo;
+            __syncthreads();
+            sg = s_seg;
         }
-        __syncthreads();
-        const long* d = desc + (long)s_seg * 8;
+        const long* d = desc + (long)sg * 8;
         const int Cout = (int)d[3], T = (int)d[4], Cin = (int)d[5];
         const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
-        long r = tl - tprefix[s_seg];
+        long r = tl - tprefix[sg];
         const int ci0 = (int)(r % tci) * 64; r /= tci;
         const int co0 = (int)(r % tco) * 64;
         const int t = (int)(r / tco);
@@ -974,7 +1047,11 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     EP24_REQUIRE(C % 8 == 0 && ld_z % 8 == 0 && ld_y % 8 == 0 && (!residual || ld_res % 8 == 0), EP24_E_ARG,
                  "bn_act_fwd: C=%d / strides must be multiples of 8", C);
     EP24_REQUIRE(M > 0 && reps > 0, EP24_E_ARG, "bn_act_fwd: empty");
-    const int fw_per = 2;                                   // chunks per lane and launch: tools/bn_probe.py sweeps of round 1
+    // chunks per lane and launch.  Every block folds the statistics of ALL channels in its prologue (2 * reps * C 8-byte loads out of
+    // L2), so thin blocks multiply that traffic: at 2 chunks per lane a 20x20x1024 layer ran 2 000 blocks that read 262 MB of
+    // statistics for a 16 MB tensor.  4 = one batch of the body's unrolled loop.
+    // (swept again in round 3 with the batched prologue, tools/bn_probe.py: 8 wins where C >= 1024 or the tensor is large and narrow)
+    const int fw_per = (C >= 1024 || (C <= 128 && M * C >= (12L << 20))) ? 8 : 4;
     auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : act == 3 ? bn_act_fwd_kernel<3> : bn_act_fwd_kernel<0>;
     hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * (C + C / 8) * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, (long*)num_batches2, save, (bf16*)y, ld_y, (const bf16*)residual,
@@ -985,14 +1062,14 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
 
 extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                                       const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, int64_t M, int C,
-                                      int act, void* stream) {
-    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta, EP24_E_ARG, "bn_act_bwd_reduce: null pointer");
+                                      int act, int reps, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && reps > 0, EP24_E_ARG, "bn_act_bwd_reduce: null pointer / reps");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
     int red_cap = 256;                                      // one 512-thread block per CU: tools/bn_probe.py sweep
     int red_rows = 4;
     auto kfn = act == 1 ? bn_act_bwd_reduce_kernel<4, 512, 1> : act == 2 ? bn_act_bwd_reduce_kernel<4, 512, 2> : act == 3 ? bn_act_bwd_reduce_kernel<4, 512, 3> : bn_act_bwd_reduce_kernel<4, 512, 0>;
     hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
-                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C);
+                       save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, reps);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
 }
@@ -1000,14 +1077,18 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
 extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                                      const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                                      float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
-                                     void* stream) {
-    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply: null pointer");
+                                     int reps, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz && reps > 0, EP24_E_ARG, "bn_act_bwd_apply: null pointer / reps");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply: alignment");
-    int ap_rows = 16, ap_cap = 2048;
+    EP24_REQUIRE((((uintptr_t)save | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, EP24_E_ARG,
+                 "bn_act_bwd_apply: save / gamma / beta must be 16-byte aligned (they are read as vectors)");
+    EP24_REQUIRE((((uintptr_t)gamma_grad | (uintptr_t)beta_grad) & 15) == 0, EP24_E_ARG, "bn_act_bwd_apply: gamma_grad / beta_grad must be 16-byte aligned");
+    // rows per lane: 8 on the small tensors (more, thinner blocks: -1.5 ... -2.7 us on the 20x20 / 40x40 layers), 16 on the large
+    const int ap_rows = M * C <= (16L << 20) ? 8 : 16, ap_cap = 2048;
     auto kfn = act == 1 ? bn_act_bwd_apply_kernel<4, 1> : act == 2 ? bn_act_bwd_apply_kernel<4, 2> : act == 3 ? bn_act_bwd_apply_kernel<4, 3> : bn_act_bwd_apply_kernel<4, 0>;
-    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 0, S_, (const bf16*)dy, ld_dy,
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, ap_rows, ap_cap)), dim3(256), 2 * (size_t)C * sizeof(float), S_, (const bf16*)dy, ld_dy,
                        (const bf16*)z, ld_z, save, gamma, beta, (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad,
-                       (bf16*)dz, ld_dz, M, C);
+                       (bf16*)dz, ld_dz, M, C, reps);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
     return EP24_OK;
 }
@@ -1015,12 +1096,15 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
 extern "C" int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                                          const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                                          float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
-                                         void* stream) {
-    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz, EP24_E_ARG, "bn_act_bwd_apply_acc: null pointer");
+                                         int reps, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz && reps > 0, EP24_E_ARG, "bn_act_bwd_apply_acc: null pointer / reps");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_apply_acc: alignment");
+    EP24_REQUIRE((((uintptr_t)save | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, EP24_E_ARG,
+                 "bn_act_bwd_apply_acc: save / gamma / beta must be 16-byte aligned (they are read as vectors)");
+    EP24_REQUIRE((((uintptr_t)gamma_grad | (uintptr_t)beta_grad) & 15) == 0, EP24_E_ARG, "bn_act_bwd_apply_acc: gamma_grad / beta_grad must be 16-byte aligned");
     auto kfn = act == 1 ? bn_act_bwd_apply_kernel<4, 1, true> : act == 2 ? bn_act_bwd_apply_kernel<4, 2, true> : bn_act_bwd_apply_kernel<4, 0, true>;
-    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, 16, 2048)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z, save, gamma, beta,
-                       (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad, (bf16*)dz, ld_dz, M, C);
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, 16, 2048)), dim3(256), 2 * (size_t)C * sizeof(float), S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z, save, gamma, beta,
+                       (const long long*)dgamma, (const long long*)dbeta, gamma_grad, beta_grad, (bf16*)dz, ld_dz, M, C, reps);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply_acc");
     return EP24_OK;
 }
@@ -1178,6 +1262,20 @@ extern "C" int ep24_sgd_nesterov_hp(float* p, const float* g, float* buf, int64_
     return EP24_OK;
 }
 
+// The same update on elements [first, first + n) of the flat buffers: the update of the parameters whose gradients are complete
+// can run while the tail of backward still produces the others (ep24.train).  `last` != 0 on the call that finishes the step: only
+// that one clears the first-step flag.
+extern "C" int ep24_sgd_nesterov_hp_range(float* p, const float* g, float* buf, int64_t first, int64_t n, const float* hp,
+                                          int32_t* first_flag, float* ema, int last, void* stream) {
+    EP24_REQUIRE(p && g && buf && hp && first_flag && n > 0 && first >= 0 && first % 4 == 0, EP24_E_ARG, "sgd_nesterov_hp_range: bad arguments");
+    EP24_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf | (uintptr_t)ema) % 16 == 0, EP24_E_ARG, "sgd_nesterov_hp_range: 16-byte alignment");
+    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p + first, g + first, buf + first, n, 0.f, 0.f, 0.f, first_flag, hp,
+                       ema ? ema + first : nullptr);
+    if (last) hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
+    EP24_LAUNCH_CHECK("ep24_sgd_nesterov_hp_range");
+    return EP24_OK;
+}
+
 extern "C" int ep24_ema_update(float* ema, const float* src, int64_t n, float decay, float one_minus_decay, const float* hp,
                                void* stream) {
     EP24_REQUIRE(ema && src && n > 0, EP24_E_ARG, "ema_update: bad arguments");
@@ -1226,14 +1324,15 @@ extern "C" int ep24_memset_zero(void* p, int64_t bytes, void* stream) {
 }
 
 extern "C" int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int64_t* prefix, const int64_t* tile_prefix,
-                                         int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles, void* stream) {
+                                         int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles,
+                                         const int32_t* chunk_seg, const int32_t* tile_seg, void* stream) {
     EP24_REQUIRE(flat && desc && prefix && tile_prefix && w_fwd && w_dgrad && n_seg > 0 && total > 0, EP24_E_ARG,
                  "pack_weights_batched: bad arguments");
     long blocks = (total + 4095) / 4096;
     hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, S_, flat, (const long*)desc,
-                       (const long*)prefix, n_seg, (bf16*)w_fwd, (bf16*)w_dgrad);
+                       (const long*)prefix, n_seg, (bf16*)w_fwd, (bf16*)w_dgrad, (const int*)chunk_seg);
     hipLaunchKernelGGL(pack_transpose_kernel, dim3((unsigned)(total_tiles > 8192 ? 8192 : total_tiles)), dim3(256), 0, S_, flat,
-                       (const long*)desc, (const long*)tile_prefix, n_seg, (bf16*)w_dgrad);
+                       (const long*)desc, (const long*)tile_prefix, n_seg, (bf16*)w_dgrad, (const int*)tile_seg);
     EP24_LAUNCH_CHECK("ep24_pack_weights_batched");
     return EP24_OK;
 }

@@ -24,6 +24,7 @@ struct IgemmArgs {
     int epi_act; const bf16* epi_res; long epi_ldres; int epi_infer;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernels
+    unsigned dst_bytes;             // extent of the destination (streaming kernel: buffer stores)
     FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
     long M;
     int narrow_epi;                 // A/B option (kernel_opts bit 1 of the _ex entry points): the 8-byte-per-lane epilogue stores

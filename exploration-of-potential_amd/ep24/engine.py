@@ -260,6 +260,14 @@ class ParamHome:
             tpref.append(tpref[-1] + seg.taps * ((seg.cout + 63) // 64) * ((seg.cin + 63) // 64))
         self.pack_tprefix = torch.tensor(tpref, dtype=torch.int64, device=dev)
         self.pack_tiles = tpref[-1]
+        # lookup tables of the packing kernels: segment of every 4096-element chunk / of every transpose tile (built once)
+        import bisect
+        self.pack_chunk_seg = torch.tensor([bisect.bisect_right(pref, c * 4096) - 1 for c in range((pref[-1] + 4095) // 4096)] or [0],
+                                           dtype=torch.int32, device=dev)
+        tseg = []
+        for si in range(len(self.convs)):
+            tseg += [si] * (tpref[si + 1] - tpref[si])
+        self.pack_tile_seg = torch.tensor(tseg or [0], dtype=torch.int32, device=dev)
         self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.pack_prefix = torch.tensor(pref, dtype=torch.int64, device=dev)
         self.pack_total = pref[-1]
@@ -303,7 +311,8 @@ class ParamHome:
     def pack(self):
         """fp32 masters -> bf16 [Cout][T][Cin] (forward) and [Cin][T][Cout_pad] (dgrad) copies."""
         call("pack_weights_batched", ptr(self.flat), ptr(self.pack_desc), ptr(self.pack_prefix), ptr(self.pack_tprefix),
-             len(self.convs), ptr(self.wf), ptr(self.wd), self.pack_total, self.pack_tiles, stream_ptr())
+             len(self.convs), ptr(self.wf), ptr(self.wd), self.pack_total, self.pack_tiles, ptr(self.pack_chunk_seg),
+             ptr(self.pack_tile_seg), stream_ptr())
 
     def zero_grad(self):
         call("memset_zero", ptr(self.gflat), self.numel * 4, stream_ptr())
@@ -312,14 +321,18 @@ class ParamHome:
         call("sgd_nesterov", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), self.numel, float(lr), float(momentum),
              float(grad_scale), ptr(self.first_flag), stream_ptr())
 
-    def sgd_hp(self, hp, ema_home=None):
+    def sgd_hp(self, hp, ema_home=None, lo=0, hi=None, last=True):
         """The same update with lr / momentum / grad_scale (and the EMA decay) read from the device block ``hp``; with
-        ``ema_home`` the EMA copy of the parameters and of the BatchNorm running statistics is advanced as well."""
+        ``ema_home`` the EMA copy of the parameters and of the BatchNorm running statistics is advanced as well.
+        ``lo`` / ``hi``: only elements [lo, hi) of the flat buffers (ep24.train updates the parameters whose gradients are
+        complete while backward still runs); ``last``: this call finishes the step."""
         if ema_home is not None and (ema_home.numel, ema_home.bnumel) != (self.numel, self.bnumel):
             raise _lib.Ep24Error("ep24: the EMA model's parameter layout differs from the trained model's")
-        call("sgd_nesterov_hp", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), self.numel, ptr(hp), ptr(self.first_flag),
-             ptr(ema_home.flat) if ema_home is not None else None, stream_ptr())
-        if ema_home is not None and self.bnumel:
+        hi = self.numel if hi is None else hi
+        if hi > lo:
+            call("sgd_nesterov_hp_range", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), lo, hi - lo, ptr(hp), ptr(self.first_flag),
+                 ptr(ema_home.flat) if ema_home is not None else None, 1 if last else 0, stream_ptr())
+        if last and ema_home is not None and self.bnumel:
             call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
 
 
@@ -356,6 +369,54 @@ def exec_order(model, opts=None):
     if isinstance(model, enn.YOLOXHead):              # a head run on its own (YOLOXHead.forward)
         yield from head_order(model)
         return
+    def swapped(bb):
+        """(conv, bn) units / pre-activation pieces of a swapped backbone in execution order (darknet.py:179-674)."""
+        if isinstance(bb, enn.ResNet):
+            first = True
+            for conv, bn in bb.used_units():
+                yield ("unit", conv, bn, first)
+                first = False
+        elif isinstance(bb, enn.VGG):
+            first = True
+            for stage in bb.stages():
+                for m in stage:
+                    if isinstance(m, enn.ConvBNReLU):
+                        yield ("unit", m.conv, m.bn, first)
+                        first = False
+            yield ("unit", bb.conv_add.conv, bb.conv_add.bn, False)
+        elif isinstance(bb, enn.DenseNet):
+            yield ("unit", bb.stem[0].conv, bb.stem[0].bn, True)
+
+            def block(blk):
+                for lay in blk.denseblock:
+                    for cb in lay.conv_block:
+                        yield ("bn", cb.bn)
+                        yield ("conv", cb.conv, False)
+
+            def trans(t):
+                yield ("bn", t.trans[0].bn)
+                yield ("conv", t.trans[0].conv, False)
+            yield from block(bb.D1)
+            yield from trans(bb.T1)
+            yield from block(bb.D2)
+            yield ("unit", bb.baseconv1.conv, bb.baseconv1.bn, False)
+            yield from trans(bb.T2)
+            yield from block(bb.D3)
+            yield ("unit", bb.baseconv2.conv, bb.baseconv2.bn, False)
+            yield from trans(bb.T3)
+            yield from block(bb.D4)
+
+    def resnet_unused(bb):                                 # fc / baseconv1..3: parameters the reference never runs (darknet.py:311-330)
+        used = {id(p) for conv, bn in bb.used_units() for p in (conv.weight, bn.weight, bn.bias)}
+        for p in bb.parameters():
+            if id(p) not in used:
+                yield ("unused", p)
+
+    if isinstance(model, (enn.ResNet, enn.VGG, enn.DenseNet)):     # a swapped backbone run on its own (its forward)
+        yield from swapped(model)
+        if isinstance(model, enn.ResNet):
+            yield from resnet_unused(model)
+        return
     if not isinstance(model, enn.YOLOX):
         skip = set()
         for m in model.modules():
@@ -369,7 +430,7 @@ def exec_order(model, opts=None):
                 yield ("bn", m.bn)
                 yield ("conv", m.conv, False)
             elif isinstance(m, (enn.BaseConv_DN, enn.ConvBNReLU)):
-                yield ("unit", m.conv, m.bn, False)
+                yield ("unit", m.conv, m.bn, m.conv.in_channels == 3)     # 3 input channels: an image stem (im2col rows x GEMM)
             elif isinstance(m, enn.ResBottleneck):
                 if m.downsample is not None:
                     yield ("unit", m.downsample[0], m.downsample[1], False)
@@ -392,40 +453,8 @@ def exec_order(model, opts=None):
 
     neck, head = model.backbone, model.head
     bb = neck.backbone
-    if isinstance(bb, enn.ResNet):
-        first = True
-        for conv, bn in bb.used_units():
-            yield ("unit", conv, bn, first)
-            first = False
-    elif isinstance(bb, enn.VGG):
-        first = True
-        for stage in bb.stages():
-            for m in stage:
-                if isinstance(m, enn.ConvBNReLU):
-                    yield ("unit", m.conv, m.bn, first)
-                    first = False
-        yield ("unit", bb.conv_add.conv, bb.conv_add.bn, False)
-    elif isinstance(bb, enn.DenseNet):
-        yield ("unit", bb.stem[0].conv, bb.stem[0].bn, True)
-
-        def block(blk):
-            for lay in blk.denseblock:
-                for cb in lay.conv_block:
-                    yield ("bn", cb.bn)
-                    yield ("conv", cb.conv, False)
-
-        def trans(t):
-            yield ("bn", t.trans[0].bn)
-            yield ("conv", t.trans[0].conv, False)
-        yield from block(bb.D1)
-        yield from trans(bb.T1)
-        yield from block(bb.D2)
-        yield ("unit", bb.baseconv1.conv, bb.baseconv1.bn, False)
-        yield from trans(bb.T2)
-        yield from block(bb.D3)
-        yield ("unit", bb.baseconv2.conv, bb.baseconv2.bn, False)
-        yield from trans(bb.T3)
-        yield from block(bb.D4)
+    if isinstance(bb, (enn.ResNet, enn.VGG, enn.DenseNet)):
+        yield from swapped(bb)
     else:
         yield bb.stem.conv
         for name in ("dark2", "dark3", "dark4"):
@@ -445,11 +474,8 @@ def exec_order(model, opts=None):
     yield neck.bu_conv1
     yield from csp(neck.C3_n4)
     yield from head_order(head)
-    if isinstance(bb, enn.ResNet):                     # fc / baseconv1..3: parameters the reference never runs (darknet.py:311-330)
-        used = {id(p) for conv, bn in bb.used_units() for p in (conv.weight, bn.weight, bn.bias)}
-        for p in bb.parameters():
-            if id(p) not in used:
-                yield ("unused", p)
+    if isinstance(bb, enn.ResNet):
+        yield from resnet_unused(bb)
 
 
 def param_home(model):
@@ -665,6 +691,10 @@ class Engine:
                     self._deferred = []
                 self._force_side = want
             in_head = is_head
+            if b is self._bwd_builders[0] and len(self._bwd_builders) > 1:
+                # the last unit of backward (the stem): fold the pending weight-gradient slabs now, so that the final reduce launch
+                # covers this unit only and everything else is complete before it (ep24.train updates those parameters meanwhile)
+                self._flush_reduce()
             b()
         self._force_side = False
         for f in self._deferred:
@@ -717,8 +747,9 @@ class Engine:
         return lambda: self.stats.data_ptr() + 8 * off
 
     def _sums_slot(self, C):
+        """[STATS_REPLICAS][2][C] fixed-point sums of one BatchNorm backward (replica 0's two pointers; replica r is 2 C r further)."""
         off = sum(self._sum_specs)
-        self._sum_specs.append(2 * C)
+        self._sum_specs.append(STATS_REPLICAS * 2 * C)
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
@@ -787,10 +818,10 @@ class Engine:
             self._dz_elems += M * cout
             dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
             self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, act), reads=out)
+                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
             self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                          ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                         dz, cout, M, cout, act), writes=(gam, bet))
+                                         dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet))
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
@@ -1025,10 +1056,10 @@ class Engine:
             assert a.gready(), "activation without a gradient producer"
             acc = x.gwrite()
             self._b("bn_act_bwd_reduce", (a.gptr(), a.gld, x.ptr(), x.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
-                                          sum_g, sum_b, M, C, 2), reads=a)
+                                          sum_g, sum_b, M, C, 2, STATS_REPLICAS), reads=a)
             self._b("bn_act_bwd_apply_acc" if acc else "bn_act_bwd_apply",
                     (a.gptr(), a.gld, x.ptr(), x.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sum_g, sum_b,
-                     ptr(gflat, gam.off), ptr(gflat, bet.off), x.gptr(), x.gld, M, C, 2), writes=(gam, bet))
+                     ptr(gflat, gam.off), ptr(gflat, bet.off), x.gptr(), x.gld, M, C, 2, STATS_REPLICAS), writes=(gam, bet))
 
         self._add_builder(build_bwd)
         return a
@@ -1446,7 +1477,7 @@ class SubEngine(Engine):
     (network_blocks.py:50-51,179-185,139-144, darknet.py:165-177, yolo_pafpn.py:83-124, yolo_head_24p.py:143-210).
     Same building blocks, buffers and kernels as the whole-network plan; inputs / outputs cross as NCHW fp32 tensors."""
 
-    IMAGE_KINDS = ("focus", "darknet", "pafpn")
+    IMAGE_KINDS = ("focus", "darknet", "pafpn", "backbone", "stem_unit")
 
     def __init__(self, mod, kind, shapes, batch, dtype=BF16):
         self.kind, self.shapes = kind, shapes                 # shapes: (C, H, W) of every input tensor
@@ -1485,11 +1516,59 @@ class SubEngine(Engine):
             self.outs = list(self.build_neck(mod, *self.build_neck_inputs(mod)))
         elif kind == "head":
             self.build_head(mod, self.inputs)
+        elif kind == "backbone":                              # resnet50() / densenet121() / vgg19() on their own (darknet.py:389-674)
+            self.outs = list(self.build_backbone(mod))
+        elif kind == "stem_unit":                             # a conv-BN-ReLU unit over images: im2col rows x GEMM, as in the full plans
+            kk, st, pd = mod.conv.kernel_size[0], mod.conv.stride[0], mod.conv.padding[0]
+            cols = _r8(kk * kk * 3)
+            OH, OW = (self.IH + 2 * pd - kk) // st + 1, (self.IW + 2 * pd - kk) // st + 1
+            rows = self.new_act(cols, OH, OW)
+            rows.needs_grad = False
+            self._f("im2col_bf16", ptr(self.images), rows.ptr(), cols, B, 3, self.IH, self.IW, kk, st, pd)
+            self.outs = [self.unit(None, rows, stem=True, conv=mod.conv, bn=mod.bn, act=2)]
+        elif kind == "unit_relu":                             # BaseConv_DN / ConvBNReLU (darknet.py:432-445,518-529)
+            self.outs = [self.unit(None, x, conv=mod.conv, bn=mod.bn, act=2)]
+        elif kind == "resblock":                              # ResBottleneck (darknet.py:247-271)
+            self.outs = [self.res_block(mod, x)]
+        elif kind in ("convblock", "transition", "denselayer", "denseblock"):
+            self.outs = [self._dense_piece(mod, kind)]
         else:
             raise NotImplementedError(kind)
         for o in self.outs:
             o.gwrite()                                    # the caller is the consumer: it provides d(out)
         self._finalize()
+
+    def _dense_piece(self, mod, kind):
+        """ConvBlock / Transition / DenseLayer / DenseBlock of the DenseNet backbone on their own (darknet.py:532-597).  The input sits
+        in the head of a concatenation buffer, its batch statistics come from one ``colstats`` launch, and the pieces are the ones
+        the full plan uses (pre-activation BatchNorm over a prefix of the concatenation, raw convs into their channel slots)."""
+        C0, H, W = self.shapes[0]
+        nl = len(mod.denseblock) if kind == "denseblock" else (1 if kind == "denselayer" else 0)
+        cat = self.new_act(C0 + 32 * nl, H, W)
+        head = cat.slice(0, C0)
+        self.inputs = [head]                                  # replaces the stand-alone input buffer: the input IS the head slot
+        bstats = self._stats_slot(cat.C)
+        self.drop_keep = torch.ones(max(nl, 1), self.B, 32, dtype=torch.float32, device=self.dev)
+        self.drop_p = 0.3
+        self._f("colstats", head.ptr(), head.ld, bstats, cat.C, head.M, C0, ev=False)
+        if kind == "denseblock":                              # x -> cat(x, layer_0(x), layer_1(cat), ...)
+            if not any(l.drop_rate > 0 for l in mod.denseblock):
+                self.drop_keep = None
+            return self.dense_block(mod, cat, C0, bstats, 0)
+        if kind == "denselayer":                              # x -> the 32 new channels (after Dropout2d in training mode)
+            blk = torch.nn.Module()
+            blk.denseblock = [mod]
+            if mod.drop_rate <= 0:
+                self.drop_keep = None
+            self.dense_block(blk, cat, C0, bstats, 0)
+            return cat.slice(C0, 32)
+        cb = mod.trans[0] if kind == "transition" else mod
+        t = self.new_act(cb.conv.out_channels, H, W)
+        self.conv_raw(cb.conv, self.pre_bn(cb.bn, head, bstats, cat.C), t)
+        if kind == "convblock":
+            return t
+        out = self.new_act(t.C, H // 2, W // 2)
+        return self.avgpool2(t, out)
 
     def load_inputs(self, tensors):
         if self.kind in self.IMAGE_KINDS:

@@ -17,9 +17,12 @@ from . import _lib
 ACT_CODES = {"silu": 1, "relu": 2, "lrelu": 3}          # activation codes of the BN + act kernels (csrc/common.h act_fwd)
 
 
-def _no_eager(mod):
-    raise NotImplementedError(
-        "%s holds parameters only; run the network through YOLOX.forward (the HIP plan)" % type(mod).__name__)
+
+def _unit_relu_forward(mod, x):
+    """conv -> BatchNorm -> ReLU units of the swapped backbones; a unit over 3-channel images runs as im2col rows x GEMM."""
+    if mod.conv.in_channels == 3:
+        return _sub(mod, "stem_unit", x)[0]
+    return _sub(mod, "unit_relu", x)[0]
 
 
 def _sub(mod, kind, *tensors, train=True):
@@ -136,7 +139,8 @@ class ResBottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        _no_eager(self)
+        """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity) (darknet.py:252-271) as a sub-plan."""
+        return _sub(self, "resblock", x)[0]
 
 
 class ResNet(nn.Module):
@@ -179,6 +183,11 @@ class ResNet(nn.Module):
         layers += [ResBottleneck(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    def forward(self, x):
+        """images -> {"dark3", "dark4", "dark5"} = the outputs of layer2 / layer3 / layer4 (darknet.py:405-429)."""
+        d3, d4, d5 = _sub(self, "backbone", x)
+        return {"dark3": d3, "dark4": d4, "dark5": d5}
+
     def used_units(self):
         """(conv, bn) pairs in execution order - what the plan runs and the flat parameter buffers are ordered by."""
         yield self.conv1, self.bn1
@@ -189,9 +198,6 @@ class ResNet(nn.Module):
                 if blk.downsample is not None:
                     yield blk.downsample[0], blk.downsample[1]
                 yield blk.conv3, blk.bn3
-
-    def forward(self, x):
-        _no_eager(self)
 
 
 def resnet50():
@@ -208,7 +214,7 @@ class BaseConv_DN(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        _no_eager(self)
+        return _unit_relu_forward(self, x)                     # darknet.py:525-529
 
 
 class ConvBlock(nn.Module):
@@ -221,7 +227,7 @@ class ConvBlock(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, **kwargs)
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "convblock", x)[0]                   # conv(relu(bn(x))), darknet.py:539-543
 
 
 class Transition(nn.Module):
@@ -230,7 +236,7 @@ class Transition(nn.Module):
         self.trans = nn.Sequential(ConvBlock(in_channels, out_channels, kernel_size=1, stride=1, bias=False), nn.AvgPool2d(2, 2))
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "transition", x)[0]                  # darknet.py:555-556
 
 
 class DenseLayer(nn.Module):
@@ -245,7 +251,8 @@ class DenseLayer(nn.Module):
         self.dropout = nn.Dropout2d(self.drop_rate)
 
     def forward(self, x):
-        _no_eager(self)
+        """The 32 new channels; Dropout2d draws on the device in training mode (darknet.py:573-577)."""
+        return _sub(self, "denselayer", x)[0]
 
 
 class DenseBlock(nn.Module):
@@ -255,7 +262,7 @@ class DenseBlock(nn.Module):
         self.denseblock = nn.Sequential(*[DenseLayer(in_channels + i * 32, drop_rate=drop_rate) for i in range(num_layers)])
 
     def forward(self, x):
-        _no_eager(self)
+        return _sub(self, "denseblock", x)[0]                  # cat(x, layer_0(x), layer_1(...), ...), darknet.py:593-597
 
 
 class DenseNet(nn.Module):
@@ -281,7 +288,9 @@ class DenseNet(nn.Module):
         self.baseconv2 = BaseConv_DN(t3, t3 // 2, kernel_size=1, bias=False)
 
     def forward(self, x):
-        _no_eager(self)
+        """images -> {"dark3", "dark4", "dark5"} (darknet.py:640-674)."""
+        d3, d4, d5 = _sub(self, "backbone", x)
+        return {"dark3": d3, "dark4": d4, "dark5": d5}
 
 
 def densenet121():
@@ -298,7 +307,7 @@ class ConvBNReLU(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        _no_eager(self)
+        return _unit_relu_forward(self, x)                     # darknet.py:441-445
 
 
 class VGG(nn.Module):
@@ -328,7 +337,9 @@ class VGG(nn.Module):
         return (self.conv_pool1, self.conv_pool2, self.conv_pool3, self.conv_pool4, self.conv_pool5)
 
     def forward(self, x):
-        _no_eager(self)
+        """images -> {"dark3", "dark4", "dark5"} (darknet.py:483-513)."""
+        d3, d4, d5 = _sub(self, "backbone", x)
+        return {"dark3": d3, "dark4": d4, "dark5": d5}
 
 
 def vgg19():

@@ -177,8 +177,27 @@ class TrainStep:
         eng = self.eng
         eng._run(eng.bwd[lo:hi])
 
-    def _phase_update(self):
-        self.home.sgd_hp(self.hp, self.ema_home)
+    def _phase_update(self, lo=0, hi=None, last=True):
+        self.home.sgd_hp(self.hp, self.ema_home, lo, hi, last)
+
+    def _early_update_cut(self, segs):
+        """Where the flat parameter buffer is cut for the two-part update.  The buffer is in execution order, so backward completes it
+        from the tail; when the main lane has finished its last segment, everything except what the weight-gradient lane's LAST
+        segment still writes (the stem's weight gradient and the final reduce launch: the head of the buffer) is complete once that
+        lane has finished the segment before.  Returns (element offset, index of that segment) or None."""
+        eng = self.eng
+        if self.reducer is not None or len(segs) < 3:
+            return None                                       # with a reducer the update follows the last all-reduce
+        k = len(segs) - 2
+        lo_late = segs[k + 1][0]
+        late = [w for i in range(lo_late, len(eng.bwd)) if eng.bwd[i][0].startswith("side:") for w in eng.bwd_writes[i]]
+        if not late:
+            return None
+        cut = max(off + cnt for off, cnt in late)
+        cut = (cut + 3) // 4 * 4
+        if cut <= 0 or cut >= self.home.numel:
+            return None
+        return cut, k
 
     def _segments(self):
         """Cut points of the backward list.  The weight-gradient lane runs one segment behind the main lane, so the last
@@ -240,6 +259,7 @@ class TrainStep:
             if len(split) == 5 and getattr(self, "_side2", None) is None:
                 self._side2 = torch.cuda.Stream(device=eng.dev)
         self.g_upd = capture(self._phase_update)
+        self.g_upd_early = None
         self._cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
         self.g_bwd = None
         if self.graph_backward:
@@ -255,6 +275,13 @@ class TrainStep:
                 self.g_bwd.append((gm, gs, ready.get(hi), lo == eng.bwd_join, par))
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
+            # Two-part update: when the main lane is through, the weight-gradient lane still has its last segment to run (the
+            # stem's 2 M-pixel weight gradient and the final reduce, ~0.25 ms during which the main lane used to wait, then 0.18 ms
+            # of SGD).  The parameters above the cut are updated in that window, the few below it afterwards.
+            early = self._early_update_cut(segs)
+            if early is not None:
+                cut, k = early
+                self.g_upd_early = (capture(lambda: self._phase_update(cut, None, False)), capture(lambda: self._phase_update(0, cut, True)), k)
         self.graphs = True
 
     def step(self, images=None, labels=None):
@@ -309,6 +336,7 @@ class TrainStep:
             g_loss.replay()
         else:
             self.g_fwd.replay()
+        did_early = False
         if self.g_bwd is not None:
             main, side = torch.cuda.current_stream(), self._side
             # Host order matters: a graph launch into a stream that is still waiting on an event can hold the host, so
@@ -329,10 +357,21 @@ class TrainStep:
                     return e2
                 return None
 
+            seg_done = []                                    # per segment: event on the side lane behind its graph
+            early = self.g_upd_early
+
+            def launch_side_ev(p):
+                e = launch_side(p)
+                if early is not None:
+                    e3 = torch.cuda.Event()
+                    e3.record(side)
+                    seg_done.append(e3)
+                return e
+
             for gm, gs, ready, join, par in self.g_bwd:
                 if join:
                     if pending is not None:
-                        par_done = launch_side(pending) or par_done
+                        par_done = launch_side_ev(pending) or par_done
                         pending = None
                     if par_done is not None:
                         main.wait_event(par_done)          # the head levels that ran on the side lane (not its later work)
@@ -341,10 +380,16 @@ class TrainStep:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 if pending is not None:
-                    par_done = launch_side(pending) or par_done
+                    par_done = launch_side_ev(pending) or par_done
                 pending = (gs, ready, ev, par)
             if pending is not None:
-                launch_side(pending)
+                launch_side_ev(pending)
+                if early is not None and len(seg_done) > early[2] + 1:
+                    # the main lane is through and the weight-gradient lane has its last segment left: the early part of the
+                    # update runs on the main lane meanwhile (it needs that lane's segments up to the one before)
+                    main.wait_event(seg_done[early[2]])
+                    early[0].replay()
+                    did_early = True
             main.wait_stream(side)
         else:
             for i, (lo, hi) in enumerate(zip(self._cuts[:-1], self._cuts[1:])):
@@ -353,5 +398,8 @@ class TrainStep:
                     self.reducer.bucket_ready(i)
         if self.reducer is not None:
             self.reducer.wait()
-        self.g_upd.replay()
+        if did_early:
+            self.g_upd_early[1].replay()                     # the parameters below the cut; finishes the step
+        else:
+            self.g_upd.replay()
         return self.ws.result

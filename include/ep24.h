@@ -54,8 +54,8 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
 /* The same two entry points with an explicit kernel choice PER CALL (A/B timing, tests that compare two kernels on one shape;
  * there is no process-wide switch).  kernel_opts bit 0: the 3x3 stride-1 layers run in the generic tiled kernel instead of the
  * halo-patch kernel (csrc/conv_patch.hip); bit 1: the tiled kernels store their output 8 bytes per lane instead of staging
- * it for 16-byte stores; bits 2-3: LDS ring depth of the tiled kernel (1: three stages, 2: four) instead of the dispatch rule's;
- * bit 4: its two-stage loop.  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
+ * it for 16-byte stores; bit 2: a stride-2 input gradient runs as one launch per parity class (four) instead of one merged launch.
+ * kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                           int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream);
@@ -90,13 +90,6 @@ int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, in
 int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
                               int64_t ld_dw, int cout_valid, int cin_valid,
                               int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
-/* The weight-gradient entry points with an explicit kernel choice per call (A/B timing and bit-equality tests; kernel_opts bits 2-3:
- * LDS ring depth 3 / 4 instead of the dispatch rule's, bit 4: the two-stage loop).  The number of pixel splits - the slab size -
- * depends on the ring depth, so ep24_conv_wgrad_splits_ex takes the same kernel_opts. */
-int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
-                                 int64_t ld_dw, int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
-                                 int stride, int kernel_opts, void* stream);
-int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts);
 int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream);
 
 /* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad
@@ -108,9 +101,12 @@ int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, 
 /* The same for every conv segment of a model in one launch.  desc [n_seg][8] int64 = {master offset, w_fwd offset,
  * w_dgrad offset or -1, Cout, T, Cin, Cin_pad, Cout_pad} (element offsets into flat / w_fwd / w_dgrad); prefix
  * [n_seg+1] int64 = running sum of Cout*T*Cin (total = prefix[n_seg]); tile_prefix [n_seg+1] = running sum of
- * T*ceil(Cout/64)*ceil(Cin/64), the 64x64 tiles of the LDS transpose that writes w_dgrad coalesced. */
+ * T*ceil(Cout/64)*ceil(Cin/64), the 64x64 tiles of the LDS transpose that writes w_dgrad coalesced.
+ * chunk_seg [ceil(total/4096)] int32 = segment of element 4096*c and tile_seg [total_tiles] int32 = segment of tile t are
+ * optional lookup tables built once by the host (NULL: the kernels bisect the prefix tables, eight dependent loads per chunk). */
 int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int64_t* prefix, const int64_t* tile_prefix,
-                              int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles, void* stream);
+                              int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles,
+                              const int32_t* chunk_seg, const int32_t* tile_seg, void* stream);
 
 /* y = silu(bn(z)) (+ residual), training-mode BatchNorm with batch statistics taken from `stats`
  * ([replicas][2][C] fixed-point sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
@@ -123,17 +119,21 @@ int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats
                     second BatchNorm module when two units share the launch (merged CSP / head pairs), else NULL */
 
 /* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
- * 2^-20 fixed-point int64 like the forward statistics. */
+ * 2^-20 fixed-point int64 like the forward statistics, kept in `reps` replicas (replica r of either sum 2*C*r elements behind
+ * the pointer, i.e. [reps][2][C] when dbeta = dgamma + C; a workgroup adds to replica blockIdx % reps): the memory-side atomic
+ * units serialise the adds to one address, and with a single copy every workgroup of the launch hit the same 2 C addresses. */
 int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                            const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta,
-                           int64_t M, int C, int act, void* stream);
+                           int64_t M, int C, int act, int reps, void* stream);
 /* pass 2: dz = gamma*invstd*(du - dbeta/M - zhat*dgamma/M)  -> bf16 [M,C] (ld_dz).  dgamma/dbeta are this
  * call's sums (scratch, zeroed by the caller before pass 1); if gamma_grad/beta_grad are non-null they
- * receive += of those sums (the parameter .grad accumulators). */
+ * receive += of those sums (the parameter .grad accumulators).  The `reps` replicas of the sums (layout as in pass 1) are
+ * folded exactly (integers) by every workgroup.  save, gamma, beta, gamma_grad and beta_grad are read / updated 8 channels at
+ * a time as 16-byte vectors: they must be 16-byte aligned (C % 8 == 0 already). */
 int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                           const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
-                          void* stream);
+                          int reps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 PARITY MODE of the conv graph (csrc/f32path.hip).  The reference trains in fp32 (train_24p.py:86-104: no AMP,
@@ -297,6 +297,11 @@ int ep24_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr,
  * same pass: ema = ema*d + (1-d)*p, each product and the sum rounded to fp32 (utils/ema.py:47-60). */
 int ep24_sgd_nesterov_hp(float* p, const float* g, float* buf, int64_t n, const float* hp, int32_t* first_flag, float* ema,
                          void* stream);
+/* The same update restricted to elements [first, first + n) (first % 4 == 0): parameters whose gradients are complete are
+ * updated while the tail of backward still produces the rest.  last != 0 on the call that finishes the step (it clears
+ * first_flag); ema, if given, is the EMA copy's flat buffer (same layout). */
+int ep24_sgd_nesterov_hp_range(float* p, const float* g, float* buf, int64_t first, int64_t n, const float* hp,
+                               int32_t* first_flag, float* ema, int last, void* stream);
 /* ModelEMA.update over one flat buffer (parameters, or the BatchNorm running statistics); hp non-null overrides
  * decay / one_minus_decay with hp[3] / hp[4]. */
 int ep24_ema_update(float* ema, const float* src, int64_t n, float decay, float one_minus_decay, const float* hp,
@@ -428,7 +433,7 @@ int ep24_stats_gather(const int64_t* src, int64_t ld_src, int64_t* dst, int C, i
 /* ep24_bn_act_bwd_apply with dz += instead of dz = (same arguments). */
 int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                               const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
-                              float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
+                              float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act, int reps,
                               void* stream);
 /* nn.AvgPool2d(2, 2) of the Transition blocks, NHWC bf16. */
 int ep24_avgpool2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, void* stream);

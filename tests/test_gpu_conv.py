@@ -115,6 +115,10 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # them: 480 x 672 -> 60 x 84): rows m >= M of the last tile, the `live` guard of the statistics in the wide epilogue,
     # out-of-range patch pieces, with two patch buffers (K = 128, LDS exactly 160 KB) and with one (K = 64)
     (20, 60, 128, 128, 3, 1, 84), (12, 52, 64, 128, 3, 1, 100),
+    # the streaming 1x1 kernel's tails (its loads and stores are unconditional; what does not exist is an out-of-range buffer
+    # offset): rows past M in the last block and a whole block past the end (odd unit count), an N tail, K = 64 (two K steps),
+    # a K tail inside a step (K = 120), two K halves with a tail (K = 200, M large enough for the streaming form)
+    (3, 50, 64, 72, 1, 1, 50), (5, 36, 120, 200, 1, 1, 36), (17, 80, 200, 136, 1, 1, 79),
 ]
 
 
@@ -147,7 +151,8 @@ def test_conv_hot_shapes(shape):
     y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
     M = B * OH * OW
     if len(shape) > 6:
-        assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == 1, "meant to exercise the patch kernel's M tail"
+        want = 1 if k == 3 else 2
+        assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == want, "meant to exercise the patch / streaming kernel's tails"
 
     xd = nhwc(x).to(DEV)
     wf = w.permute(0, 2, 3, 1).contiguous().to(DEV)
@@ -266,12 +271,12 @@ def test_bn_silu_fwd_bwd(M, C, res):
     close(rvd, rv, rel=1e-4)
     assert int(nbt) == 1 and int(nbt2) == 6
     dyd = dy.to(DEV)
-    sums = torch.zeros(2, C, dtype=torch.int64, device=DEV)
+    sums = torch.zeros(3, 2, C, dtype=torch.int64, device=DEV)          # three replicas of the two sums: [reps][2][C]
     ggrad, bgrad = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
-    call("bn_act_bwd_reduce", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), M, C, 1, sp())
+    call("bn_act_bwd_reduce", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), M, C, 1, 3, sp())
     dz = torch.zeros(M, C, dtype=BF, device=DEV)
     call("bn_act_bwd_apply", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), ptr(ggrad),
-         ptr(bgrad), ptr(dz), C, M, C, 1, sp())
+         ptr(bgrad), ptr(dz), C, M, C, 1, 3, sp())
     close(dz, zr.grad, rel=2e-2)
     close(ggrad - 1, g_.grad, rel=5e-3)
     close(bgrad - 1, b_.grad, rel=5e-3)

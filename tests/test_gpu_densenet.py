@@ -62,13 +62,13 @@ def test_bn_apply_accumulating_form_is_apply_plus_add():
     save = torch.cat([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).to(DEV)
     gam, bet = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
     sg, sb = torch.zeros(C, dtype=torch.int64, device=DEV), torch.zeros(C, dtype=torch.int64, device=DEV)
-    call("bn_act_bwd_reduce", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), M, C, 2, sp())
+    call("bn_act_bwd_reduce", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), M, C, 2, 1, sp())
     old = torch.randn(M, 128, generator=g).to(BF).to(DEV)
     plain = torch.zeros(M, C, dtype=BF, device=DEV)
     gg, gb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    call("bn_act_bwd_apply", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), ptr(gg), ptr(gb), ptr(plain), C, M, C, 2, sp())
+    call("bn_act_bwd_apply", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), ptr(gg), ptr(gb), ptr(plain), C, M, C, 2, 1, sp())
     acc = old.clone()
-    call("bn_act_bwd_apply_acc", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), ptr(gg), ptr(gb), ptr(acc, 16), 128, M, C, 2, sp())
+    call("bn_act_bwd_apply_acc", ptr(dy), C, ptr(z), C, ptr(save), ptr(gam), ptr(bet), ptr(sg), ptr(sb), ptr(gg), ptr(gb), ptr(acc, 16), 128, M, C, 2, 1, sp())
     want = old.clone()
     want[:, 16:16 + C] = (old[:, 16:16 + C].float() + plain.float()).to(BF)
     assert torch.equal(acc, want) and float(plain.float().abs().sum()) > 0

@@ -23,7 +23,8 @@ def probe(M, C, kind, warm):
         dy = torch.randn(M, C, device=DEV).to(torch.bfloat16)
         out = torch.empty(M, C, device=DEV, dtype=torch.bfloat16)
         sets.append((z, dy, out))
-    stats = torch.zeros(1, 2, C, dtype=torch.int64, device=DEV)
+    R = 8                                                   # replicas of the statistics / backward sums, as the engine runs them
+    stats = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
     zf = sets[0][0].float()
     stats[0, 0] = (zf.sum(0) * (1 << 20)).long()
     stats[0, 1] = ((zf * zf).sum(0) * (1 << 20)).long()
@@ -31,20 +32,20 @@ def probe(M, C, kind, warm):
     beta = torch.zeros(C, device=DEV)
     save = torch.zeros(2, C, device=DEV)
     save[1] = 1.0
-    sums = torch.zeros(2, C, dtype=torch.int64, device=DEV)
+    sums = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
     iters = max(nset, 24)
 
     def run(i):
         z, dy, out = sets[i % nset]
         s = stream_ptr()
         if kind == "fwd":
-            call("bn_act_fwd", ptr(z), C, ptr(stats), 1, ptr(gamma), ptr(beta), None, None, None, None, ptr(save), ptr(out), C,
+            call("bn_act_fwd", ptr(z), C, ptr(stats), R, ptr(gamma), ptr(beta), None, None, None, None, ptr(save), ptr(out), C,
                  None, 0, M, C, 1e-3, 0.03, 1, s)
         elif kind == "reduce":
-            call("bn_act_bwd_reduce", ptr(dy), C, ptr(z), C, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums[1]), M, C, 1, s)
+            call("bn_act_bwd_reduce", ptr(dy), C, ptr(z), C, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums[0, 1]), M, C, 1, R, s)
         else:
-            call("bn_act_bwd_apply", ptr(dy), C, ptr(z), C, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums[1]),
-                 None, None, ptr(out), C, M, C, 1, s)
+            call("bn_act_bwd_apply", ptr(dy), C, ptr(z), C, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums[0, 1]),
+                 None, None, ptr(out), C, M, C, 1, R, s)
 
     run(0)
     torch.cuda.synchronize()

@@ -1,0 +1,58 @@
+"""Per-class bounds of one training step from a layer table (bench.py with EP24_LAYER_TABLE=...): launches, serial ms (HIP events
+round every launch of the instrumented serial pass), algorithmic bytes / 6.3 TB/s (the achievable HBM rate, MI355X_MICROARCH.md) and
+conv FLOPs / 900 TFLOP/s (what the best layers of this library reach; the dense bf16 MFMA peak is 2 500).
+usage: bound_table.py LAYER_TABLE.txt"""
+import collections
+import sys
+
+HBM, MFMA = 6.3e12, 900e12
+conv = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])      # class -> launches, ms, bytes, flops
+other = collections.defaultdict(lambda: [0, 0.0, 0.0])
+sec = 0
+for line in open(sys.argv[1]):
+    if line.startswith("other kernels"):
+        sec = 1
+        continue
+    if ":" not in line or line.startswith("kernel "):
+        continue
+    left, right = line.split(":")
+    f = left.split()
+    n, ms = int(right.split()[0]), float(right.split()[1])
+    if sec == 0 and f[0].startswith("conv_"):
+        B, H, W, Ci, Co, k, s = map(int, f[1:8])
+        OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+        flops = 2.0 * B * OH * OW * Ci * Co * k * k * n
+        byts = 2.0 * (B * H * W * Ci + B * OH * OW * Co + Co * k * k * Ci) * n
+        if f[0].startswith("conv_wgrad"):
+            byts += 0  # slab stores / reads are the split scheme's, not the algorithm's
+        c = conv[("1x1" if k == 1 else "3x3 s%d" % s)]
+        c[0] += n; c[1] += ms; c[2] += byts; c[3] += flops
+    elif sec == 1:
+        name, a = f[0], [int(v) for v in f[1:]]
+        o = other[name]
+        o[0] += n; o[1] += ms
+        if name == "bn_act_fwd":
+            o[2] += 4.0 * a[0] * a[1] * n
+        elif name == "bn_act_bwd_reduce":
+            o[2] += 4.0 * a[0] * a[1] * n
+        elif name in ("bn_act_bwd_apply", "bn_act_bwd_apply_acc"):
+            o[2] += 6.0 * a[1] * a[2] * n
+        elif name == "wgrad_reduce":
+            o[2] += 0.0
+print("| class | launches | serial ms | algorithmic GB | HBM bound ms (6.3 TB/s) | MFMA bound ms (900 TF) | serial / larger bound |")
+print("|---|---|---|---|---|---|---|")
+tot = [0, 0.0, 0.0]
+for k in ("1x1", "3x3 s1", "3x3 s2"):
+    n, ms, by, fl = conv[k]
+    hb, mb = by / HBM * 1e3, fl / MFMA * 1e3
+    print("| conv %s (fwd + dgrad + wgrad) | %d | %.2f | %.2f | %.2f | %.2f | %.2fx |" % (k, n, ms, by / 1e9, hb, mb, ms / max(hb, mb)))
+    tot[0] += n; tot[1] += ms; tot[2] += max(hb, mb)
+bn = [0, 0.0, 0.0]
+for k in ("bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"):
+    n, ms, by = other[k]
+    print("| %s | %d | %.2f | %.2f | %.2f | - | %.2fx |" % (k, n, ms, by / 1e9, by / HBM * 1e3, ms / (by / HBM * 1e3)))
+    tot[0] += n; tot[1] += ms; tot[2] += by / HBM * 1e3
+rest_n = sum(v[0] for k, v in other.items() if not k.startswith("bn_act"))
+rest_ms = sum(v[1] for k, v in other.items() if not k.startswith("bn_act"))
+print("| everything else in the table (wgrad_reduce, stem_pack, SPP, upsample, decode, copies) | %d | %.2f | - | - | - | - |" % (rest_n, rest_ms))
+print("| sum | %d | %.2f | | %.2f (sum of the larger bounds) | | %.2fx |" % (tot[0] + rest_n, tot[1] + rest_ms, tot[2], (tot[1]) / tot[2]))

@@ -20,6 +20,7 @@ ap.add_argument("--depth", type=float, default=1.0)
 ap.add_argument("--batch", type=int, default=20)
 ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--eager", action="store_true")
+ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet", "vgg"])
 ap.add_argument("--kernel-opts", type=int, default=0, help="PlanOptions.conv_kernel_opts: bit0 tiled kernel instead of the halo-patch kernel, bit1 narrow epilogue")
 a = ap.parse_args()
 DEV = torch.device("cuda", 0)
@@ -37,7 +38,7 @@ eengine.Buf.__init__ = _rec
 
 from ep24.options import PlanOptions, set_options
 torch.manual_seed(0)
-m = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width), enn.YOLOXHead(80, a.width))
+m = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width, backbone_type=a.backbone), enn.YOLOXHead(80, a.width))
 m.head.initialize_biases(1e-2)
 m.to(DEV)
 set_options(m, PlanOptions(conv_kernel_opts=a.kernel_opts))
@@ -46,6 +47,16 @@ ts = etrain.TrainStep(m, lf, lr=0.0, momentum=0.9, batch=a.batch, size=a.size, u
 ts.eng.images.copy_(synth.make_images(a.batch, a.size, seed=1).to(DEV))
 ts.labels.copy_(synth.make_labels(a.batch, 10, size=a.size, seed=1000).to(DEV))
 eng = ts.eng
+if getattr(eng, "drop_keep", None) is not None:
+    eng.fixed_dropout = True                                # DenseNet: the same Dropout2d draws in every step
+BUF_ID = {id(b): i for i, b in enumerate(BUFS)}
+UNIT_OF = {}                                                # buffer index -> "layer name (role)"
+_names = {id(mod): n for n, mod in m.named_modules()}
+for key, (xin, z, y) in eng.unit_acts.items():
+    nm = _names.get(id(key), type(key).__name__)
+    for role, act in (("x", xin), ("z", z), ("y", y)):
+        if act is not None:
+            UNIT_OF.setdefault(BUF_ID.get(id(act.buf), -1), "%s.%s" % (nm, role))
 
 
 def tensors():
@@ -76,7 +87,7 @@ def checksum(t):
 
 
 state0 = ts.state.clone()
-ref, names = None, None
+ref, names, prev = None, None, None
 bad = 0
 for step in range(a.steps):
     ts.state.copy_(state0)
@@ -84,14 +95,25 @@ for step in range(a.steps):
     tl = tensors()
     cs = torch.stack([checksum(t) for _, t in tl])
     if ref is None:
-        ref, names = cs.clone(), [n for n, _ in tl]
+        ref, names, prev = cs.clone(), [n for n, _ in tl], cs.clone()
         full = {n: t.clone() for n, t in tl if n.startswith("ws.")}
         print("tracking %d tensors, %.2f GB" % (len(tl), sum(t.numel() * t.element_size() for _, t in tl) / 1e9), flush=True)
         continue
     diff = (cs != ref).nonzero().flatten().tolist()
+    if diff and bad == 0:
+        same = [names[i] for i in range(len(names)) if i not in set(diff)]
+        print("unchanged tensors: %s" % ", ".join(same), flush=True)
+        prev_diff = (cs != prev).nonzero().flatten().tolist() if prev is not None else None
+    elif diff:
+        prev_diff = (cs != prev).nonzero().flatten().tolist()
+        print("step %d vs the step before it: %d tensors differ" % (step, len(prev_diff)), flush=True)
+    prev = cs.clone()
     if diff:
         bad += 1
         print("step %d: %d tensors differ; first: %s" % (step, len(diff), ", ".join(names[i] for i in diff[:12])), flush=True)
+        for i in diff[:6]:
+            if names[i].startswith("buf") and names[i][3:6].isdigit():
+                print("   %s = %s" % (names[i], UNIT_OF.get(int(names[i][3:6]), "?")), flush=True)
         for i in diff[:4]:
             n = names[i]
             if n in full:
