@@ -33,6 +33,8 @@ def conv_shape(name, args):
     """(B, H, W, Cin, Cout, k, s) of a conv launch entry (the _ex forms carry kernel_opts as one more trailing argument)."""
     if name.endswith("_ex"):
         args = args[:-1]
+    if name.startswith("conv_dgrad_bnr"):               # (dy, ld, wt, dx, ld, B, H, W, Cin, Cout_k, ksize, ...): stride 1
+        return tuple(args[5:11]) + (1,)
     return args[6:13] if name.startswith("conv_dgrad") else args[-7:]
 
 

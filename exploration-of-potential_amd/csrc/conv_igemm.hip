@@ -190,7 +190,15 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
 // the "next block in flight" never was: a block cost 4 - 5 serial round trips.  Now rows / columns / K steps that do not exist
 // are out-of-range buffer offsets (loads return zeros, stores are dropped, zeros add nothing to the statistics), the K-step count
 // and the accumulate form are template parameters, and the waits the compiler emits are counted.
-template <int BN, int H, int EPI, int NKS, bool ACC>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+//
+// GATHER (the Focus stem, round 3): the rows are not stored anywhere.  The source is the space-to-depth image [B][GH][GW][16] bf16
+// (12 real channels), row m of the GEMM is the 3x3 neighbourhood of pixel m: K index = tap * 16 + channel, 144 real columns in
+// 5 K steps of 32 (two taps each; the tenth tap is out of range and reads zeros).  A lane's 16-byte fragment of K step ks is half
+// a pixel of tap 2 ks + fq / 2 - one load, as for a 1x1 layer, with the address of a neighbour and the padding test folded into
+// the offset select.  The im2col form of rounds 1 - 2 wrote 224 bytes per pixel (459 MB at B = 20) and read them back twice
+// (forward and weight gradient): 0.33 + 0.14 ms at the head of every step.  The weight tile is re-indexed on its way into LDS
+// (HBM layout [Cout][tap * 12 + channel], row stride p.K).
+template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     constexpr int SP = BN / 64, NTW = SP * 4, MT = 2, RG = 4 * MT * 16;       // 4 waves x 32 rows per unit
     constexpr int OOB = 0x7FFFFFF0;
@@ -200,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     const int n_tiles = (p.N + BN - 1) / BN;
     // workgroup L runs on XCD L & 7: the n_tiles workgroups that walk the same rows get the same XCD (shared L2)
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int nt = rest % n_tiles, rb = (rest / n_tiles) * 8 + xcd;
+    // GATHER: an XCD takes a contiguous run of row groups per sweep, so the rows above and below (the other taps) are in its L2
+    const int nt = rest % n_tiles, rb = GATHER ? xcd * (bpn >> 3) + rest / n_tiles : (rest / n_tiles) * 8 + xcd;
     const int n0 = nt * BN;
 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
@@ -211,11 +220,42 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    // GATHER: per lane and K step the neighbour (dy, dx) of its tap and the byte offset of that neighbour's half pixel
+    int gdy[GATHER ? NKS : 1], gdx[GATHER ? NKS : 1], gof[GATHER ? NKS : 1];
+    if constexpr (GATHER) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int tap = 2 * ks + (fq >> 1);
+            const int ty = (tap * 11) >> 5;                                 // tap / 3 for tap < 10
+            gdy[ks] = tap < 9 ? ty - 1 : -(1 << 20);                        // the tenth tap fails the row test: zeros
+            gdx[ks] = tap - 3 * ty - 1;
+            gof[ks] = (((ty - 1) * p.GW + gdx[ks]) * 16 + (fq & 1) * 8) * 2;
+        }
+    }
     // every load is issued: a row past M (also every row of a unit past the last one) and a K step past K read zeros
     auto load = [&](bf16x8 (&A)[MT][NKS], long u) {
         const long g = rb + (u / H) * bpn;
         const int h = (int)(u % H);
         const long r0 = g * RG + wave * (MT * 16);
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const long row = r0 + i * 16 + frow;
+                const bool rv = row < p.M;
+                const int mm = rv ? (int)row : 0;
+                const int n = fdiv(mm, p.d_plane);
+                const int rem = mm - n * (p.GH * p.GW);
+                const int y = fdiv(rem, p.d_gw), x = rem - y * p.GW;
+                const int base = mm * 32;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bool ok = rv && (unsigned)(y + gdy[ks]) < (unsigned)p.GH && (unsigned)(x + gdx[ks]) < (unsigned)p.GW;
+                    v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? base + gof[ks] : OOB, 0, 0);
+                    A[i][ks] = __builtin_bit_cast(bf16x8, t);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const long row = r0 + i * 16 + frow;
@@ -348,7 +388,14 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
         const int k = pan * 64 + chunk * 8;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ch < p.N && k < p.K) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)ch * p.WT * p.K + k);
+        if constexpr (GATHER) {                     // K index tap * 16 + c of the tile <- column tap * 12 + c of the weight row
+            const int tap = k >> 4, c0 = k & 15;
+            if (ch < p.N && tap < 9) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < 12) v[e] = p.wt[(long)ch * p.K + tap * 12 + c0 + e];
+            }
+        } else if (ch < p.N && k < p.K) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)ch * p.WT * p.K + k);
         *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
     }
     __syncthreads();
@@ -390,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     }
 }
 
-template <int BN, int H, int NKS>
+template <int BN, int H, int NKS, bool GATHER = false>
 void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     constexpr int RG = 128;
     const int n_tiles = ep24_cdiv(a.N, BN);
@@ -402,9 +449,14 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     size_t lds = (size_t)NPAN * BN * 128;
     if (lds < 4096) lds = 4096;                                // the statistics fold: [4 waves][2][BN] floats
     const dim3 grid((unsigned)(bpn * n_tiles));
-    if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
-    else if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true>), grid, dim3(256), lds, stream, a, (int)bpn);
-    else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
+    if constexpr (GATHER) {
+        if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+    } else {
+        if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
+    }
 }
 
 template <int BN, bool F32>
@@ -460,7 +512,12 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     prepare(a, kernel_opts);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     const long dst_b = ((a.M - 1) * a.ld_dst + a.N) * 2;     // the streaming kernel stores through a buffer descriptor (32-bit offsets)
-    if (a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
+    if (a.bnr_z) {      // the fused BatchNorm-backward reduction lives in the 16-byte store path of the shared epilogue
+        EP24_REQUIRE(plain_dst && !out_f32 && !a.accumulate && !a.narrow_epi && !a.bias && !a.epi_infer && a.N % 8 == 0 && a.ld_dst % 8 == 0 &&
+                     a.bnr_ldz % 8 == 0 && ((reinterpret_cast<unsigned long long>(a.dst) | reinterpret_cast<unsigned long long>(a.bnr_z)) & 15) == 0 &&
+                     a.bnr_reps > 0, EP24_E_ARG, "conv_dgrad_bnr: needs a plain, first-writer bf16 destination with channel counts / strides in multiples of 8");
+    }
+    if (!a.bnr_z && a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
         (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L) {
         if (dry) { *kernel_id = 2; return EP24_OK; }
         a.dst_bytes = (unsigned)dst_b;
@@ -566,9 +623,47 @@ extern "C" int ep24_conv_fwd_infer_bf16(const void* x, int64_t ld_x, const void*
     return launch(a, false, (hipStream_t)stream);
 }
 
+// The Focus stem (network_blocks.py Focus: space-to-depth + BaseConv 3x3 over 12 channels) without an im2col buffer: the GATHER
+// form of the streaming kernel over the space-to-depth image f16 = [B][FH][FW][16] bf16 (ep24_focus_pack); w = [Cout][ld_w] with
+// column tap * 12 + channel (the packed forward copy of the [Cout][3][3][12] master, rows padded to ld_w).
+static int stem_fwd_impl(const void* f16, const void* w, int64_t ld_w, const float* bias, int act, int infer, void* y, int64_t ld_y,
+                         int64_t* stats, int stats_replicas, int B, int FH, int FW, int Cout, void* stream) {
+    EP24_REQUIRE(f16 && w && y, EP24_E_ARG, "stem_conv_fwd: null pointer");
+    EP24_REQUIRE(Cout > 0 && Cout % 4 == 0 && ld_y % 4 == 0 && ld_w >= 108, EP24_E_ARG, "stem_conv_fwd: Cout=%d ld_y=%ld ld_w=%ld", Cout, (long)ld_y, (long)ld_w);
+    EP24_REQUIRE(!stats || stats_replicas > 0, EP24_E_ARG, "stem_conv_fwd: stats_replicas");
+    IgemmArgs a{};
+    a.src = (const bf16*)f16; a.ld_src = 16; a.B = B; a.SH = FH; a.SW = FW;
+    a.GH = FH; a.GW = FW; a.sy = a.sx = 1; a.T = 1;
+    a.wt = (const bf16*)w; a.WT = 1; a.K = (int)ld_w; a.N = Cout;
+    a.dst = y; a.ld_dst = ld_y; a.DH = FH; a.DW = FW; a.dsy = a.dsx = 1; a.dbs = (long)FH * FW;
+    a.bias = bias; a.stats = (long long*)stats; a.stats_replicas = stats ? stats_replicas : 1;
+    a.epi_infer = infer; a.epi_act = act;
+    a.M = (long)B * FH * FW;
+    const long dst_b = ((a.M - 1) * ld_y + Cout) * 2;
+    EP24_REQUIRE(a.M * 32 < 0x7FFF0000L && dst_b < 0x7FFF0000L, EP24_E_UNSUPPORTED, "stem_conv_fwd: %ld pixels are beyond the 32-bit addressing: split the batch", (long)a.M);
+    prepare(a, 0);
+    a.src_bytes = (unsigned)(a.M * 32);
+    a.wt_bytes = (unsigned)((long)Cout * ld_w * 2);
+    a.dst_bytes = (unsigned)dst_b;
+    launch_stream<64, 1, 5, true>(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_stem_conv_fwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_stem_conv_fwd_bf16(const void* f16, const void* w, int64_t ld_w, void* y, int64_t ld_y, int64_t* stats,
+                                       int stats_replicas, int B, int FH, int FW, int Cout, void* stream) {
+    return stem_fwd_impl(f16, w, ld_w, nullptr, 0, 0, y, ld_y, stats, stats_replicas, B, FH, FW, Cout, stream);
+}
+
+extern "C" int ep24_stem_conv_fwd_infer_bf16(const void* f16, const void* w, int64_t ld_w, const float* bias, int act, void* y,
+                                             int64_t ld_y, int B, int FH, int FW, int Cout, void* stream) {
+    EP24_REQUIRE(bias, EP24_E_ARG, "stem_conv_fwd_infer: null bias");
+    return stem_fwd_impl(f16, w, ld_w, bias, act, 1, y, ld_y, nullptr, 1, B, FH, FW, Cout, stream);
+}
+
 static int conv_dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx,
                            int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
-                           int kernel_opts, void* stream, bool dry = false, int* kernel_id = nullptr) {
+                           int kernel_opts, void* stream, bool dry = false, int* kernel_id = nullptr, const IgemmArgs* bnr = nullptr) {
     EP24_REQUIRE(dry || (dy && wt && dx), EP24_E_ARG, "conv_dgrad: null pointer");
     EP24_REQUIRE(Cout_k % 8 == 0 && Cout_k > 0, EP24_E_ARG, "conv_dgrad: Cout_k=%d must be a multiple of 8", Cout_k);
     EP24_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), EP24_E_UNSUPPORTED,
@@ -581,6 +676,11 @@ static int conv_dgrad_impl(const void* dy, int64_t ld_dy, const void* wt, void* 
     a.wt = (const bf16*)wt; a.WT = ksize * ksize; a.K = Cout_k; a.N = Cin;
     a.dst = dx; a.ld_dst = ld_dx; a.DH = H; a.DW = W; a.dbs = (long)H * W; a.dp0 = 0;
     a.accumulate = accumulate; a.bias = nullptr; a.stats = nullptr; a.stats_replicas = 1;
+    if (bnr) {
+        a.bnr_z = bnr->bnr_z; a.bnr_ldz = bnr->bnr_ldz; a.bnr_mean = bnr->bnr_mean; a.bnr_invstd = bnr->bnr_invstd; a.bnr_gamma = bnr->bnr_gamma;
+        a.bnr_beta = bnr->bnr_beta; a.bnr_dgamma = bnr->bnr_dgamma; a.bnr_dbeta = bnr->bnr_dbeta; a.bnr_rep_stride = bnr->bnr_rep_stride;
+        a.bnr_reps = bnr->bnr_reps; a.bnr_act = bnr->bnr_act;
+    }
     if (stride == 1) {
         // dx[y,x] = sum_{kh,kw} dy[y + pad - kh, x + pad - kw] . w[:,kh,kw,:]
         a.GH = H; a.GW = W; a.sy = a.sx = 1;
@@ -632,6 +732,19 @@ extern "C" int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void
                                        int accumulate, int B, int H, int W, int Cin, int Cout_k, int ksize, int stride,
                                        int kernel_opts, void* stream) {
     return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, ksize, stride, kernel_opts, stream);
+}
+
+// Input gradient of a stride-1 conv that is the ONLY consumer of the unit below it: dx is that unit's dy, and the epilogue takes
+// the two BatchNorm-backward sums of that unit from the tile on its way out (see IgemmArgs::bnr_*).
+extern "C" int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int B, int H, int W,
+                                        int Cin, int Cout_k, int ksize, const void* z, int64_t ld_z, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta,
+                                        int64_t rep_stride, int reps, int act, void* stream) {
+    EP24_REQUIRE(z && mean && invstd && gamma && beta && dgamma && dbeta, EP24_E_ARG, "conv_dgrad_bnr: null pointer");
+    IgemmArgs b{};
+    b.bnr_z = (const bf16*)z; b.bnr_ldz = ld_z; b.bnr_mean = mean; b.bnr_invstd = invstd; b.bnr_gamma = gamma; b.bnr_beta = beta;
+    b.bnr_dgamma = (long long*)dgamma; b.bnr_dbeta = (long long*)dbeta; b.bnr_rep_stride = rep_stride; b.bnr_reps = reps; b.bnr_act = act;
+    return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, 0, B, H, W, Cin, Cout_k, ksize, 1, 0, stream, false, nullptr, &b);
 }
 
 extern "C" int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias) {

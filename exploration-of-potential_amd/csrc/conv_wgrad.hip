@@ -69,7 +69,13 @@ template <int OFF_LO, int OFF_HI> __device__ __forceinline__ bf16x8 tr_pair(unsi
 // the 32-B-block permutation is applied to the per-lane SOURCE channel; rows past the pixel range, padding taps
 // and channel tails use an out-of-range buffer offset (the DMA then writes zeros).  Two stages, one barrier per
 // 64-pixel step.
-template <int TCO, int TCI>
+//
+// VTAP (the Focus stem, round 3): X is the space-to-depth image [B][H][W][16] bf16 and the 64 "channels" of an X tile are four
+// taps x 16 channels of the 3x3 neighbourhood (tile g: taps 4 g .. 4 g + 3; the taps past the ninth and the channels past the
+// twelfth are zeros / dropped).  The offset table has one entry per (tile row, tap) - 256 per step, one per thread - and a DMA
+// lane picks the entry of its chunk's tap.  dW leaves as [Cout][tap * 12 + channel], the layout of the im2col form it replaces
+// (which re-read 224 bytes per pixel here: 0.40 ms at B = 20).
+template <int TCO, int TCI, bool VTAP = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2, STAGE = Y_BYTES + X_BYTES;
     constexpr int FM = TCO / 32, FN = TCI / 32;          // 16x16 fragments per wave along co / ci
@@ -119,20 +125,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // per lane, carried from step to step by constant deltas plus at most one wrap of ow and of oh - into a small LDS
     // table two steps ahead; a DMA instruction then costs one ds_read_b32 and one add.  (Decoding per DMA instruction,
     // two divisions and 64-bit multiplies each, kept the VALU busier than the MFMAs: 90 -> 62 us per 3x3 256-ch layer.)
-    int* xtab = reinterpret_cast<int*>(smem + 2 * STAGE);          // [2][64] byte offsets, XOOB = padding / past the end
+    int* xtab = reinterpret_cast<int*>(smem + 2 * STAGE);          // [2][64] byte offsets, XOOB = padding / past the end (VTAP: [2][64][4])
     constexpr int XOOB = 0x7FFF0000;
+    constexpr int XT = VTAP ? 256 : 64;                             // table entries per step
     int x_row[XI], x_colb[XI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int U = (wave * XI + j) * 64 + lane;
         const int r = U / XCH, pc = U % XCH;
         const int c = ((((pc >> 1) ^ rkey<TCI>(r)) << 1) | (pc & 1));
-        x_row[j] = r;
-        x_colb[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : XOOB;
+        if constexpr (VTAP) {                                       // chunk c = tap c / 2 of the tile, half c & 1 of the pixel
+            x_row[j] = r * 4 + (c >> 1);
+            x_colb[j] = (c & 1) * 16;
+        } else {
+            x_row[j] = r;
+            x_colb[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : XOOB;
+        }
     }
     const int p_end_i = (int)p_end;
-    // producer state of tile row wave*16 + (lane & 15)
-    const int t_row = wave * 16 + (lane & 15);
+    // producer state of tile row wave*16 + (lane & 15)   (VTAP: of (row tid / 4, tap tid % 4 of the tile))
+    const int t_row = VTAP ? tid >> 2 : wave * 16 + (lane & 15);
+    const int vt = (ci0 >> 6) * 4 + (tid & 3);                     // VTAP: this thread's tap; 9 .. 11 do not exist
+    const int pkh = VTAP ? (vt * 11) >> 5 : kh, pkw = VTAP ? vt - 3 * ((vt * 11) >> 5) : kw, ppad = VTAP ? 1 : p.pad;
     int t_p = (int)p_begin + t_row, t_ys, t_xs, t_off;
     {
         const int pd = t_p < p.M ? t_p : 0;
@@ -140,12 +154,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         const int rem = pd - n * (p.OH * p.OW);
         const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
         t_ys = oh * p.stride; t_xs = ow * p.stride;                 // input row / column of tap (pad, pad)
-        t_off = n * p.c_n + oh * p.c_oh + ow * p.c_ow + ((kh - p.pad) * p.W + (kw - p.pad)) * p.c_pix;
+        t_off = n * p.c_n + oh * p.c_oh + ow * p.c_ow + ((pkh - ppad) * p.W + (pkw - ppad)) * p.c_pix;
     }
-    const int lo_y = p.pad - kh, lo_x = p.pad - kw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
+    const int lo_y = ppad - pkh, lo_x = ppad - pkw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
     auto produce = [&](int slot) {
-        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W;
-        if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
+        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W && (!VTAP || vt < 9);
+        if constexpr (VTAP) xtab[slot * XT + tid] = ok ? t_off : XOOB;
+        else if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
         t_p += 64; t_ys += p.s_dys; t_xs += p.s_dxs; t_off += p.s_doff;
         if (t_xs >= wrap_x) { t_xs -= wrap_x; t_ys += p.stride; t_off += p.c_oh - p.OW * p.c_ow; }
         if (t_ys >= wrap_y) { t_ys -= wrap_y; t_off += p.c_n - p.OH * p.c_oh; }
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     auto issue = [&](int it, int buf) {
         char* stage = smem + buf * STAGE;
         const int rows_left = p_end_i - (int)p_begin - it * 64;
-        const int* tab = xtab + (it & 1) * 64;
+        const int* tab = xtab + (it & 1) * XT;
         int xo[XI];
 #pragma unroll
         for (int j = 0; j < XI; ++j) xo[j] = tab[x_row[j]];
@@ -250,6 +265,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     __syncthreads();
     // slab form with whole 4-channel groups: 16-byte stores, a wave covers 8 rows x 128 B (64 x 64 tile) or 4 rows x 256 B per
     // instruction - a quarter of the store instructions of the 4-byte form below (the store tail is issue bound)
+    if constexpr (VTAP) {                                    // column c of tile g = (tap 4 g + c / 16, channel c % 16) -> dW column tap * 12 + channel
+        const int c = lane, vtap = (ci0 >> 6) * 4 + (c >> 4), cc = c & 15;
+        for (int row = wave; row < TCO; row += 4) {
+            const int co = co0 + row;
+            if (co >= p.cout_valid) break;
+            if (vtap < 9 && cc < 12) p.slab[(long)by * p.slab_stride + (long)co * p.ld_dw + vtap * 12 + cc] = tile[row * TCI + c];
+        }
+        return;
+    }
     if (p.slab && (p.cin_valid & 3) == 0 && (p.ld_dw & 3) == 0 && ((long)tap * p.cin_valid & 3) == 0 &&
         (((unsigned long long)p.slab | (unsigned long long)(p.slab_stride * 4)) & 15) == 0) {
         constexpr int C4 = TCI / 4;                                // float4 groups per tile row
@@ -301,7 +325,7 @@ long wgrad_splits(const WgradArgs& a) {
     return splits;                                          // trailing splits may be empty (they contribute zeros)
 }
 
-template <int TCO, int TCI>
+template <int TCO, int TCI, bool VTAP = false>
 void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
     const int tiles = a.tiles_ci * a.tiles_co * a.T;
@@ -311,7 +335,7 @@ void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles = tiles;
     a.xcd_remap = 1;
     dim3 grid((unsigned)(tiles * splits));
-    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, a);
+    hipLaunchKernelGGL((wgrad_kernel<TCO, TCI, VTAP>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + (VTAP ? 2048 : 512), stream, a);
 }
 
 int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw, int cout_valid,
@@ -375,7 +399,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const long* desc, flo
     const long off = d[0], numel = d[1], splits = d[2], soff = d[3];
     float* g = grad + off;
     const float* sl = slab + soff;
-    if (((off | numel | soff) & 3) == 0) {
+    if (((off | numel | soff) & 3) == 0 && splits >= 128 && numel <= (1L << 16)) {
+        // Few elements, very many splits (the stem: 7 168 weights x 768 splits): the plain form below leaves the sum to a handful of
+        // blocks, each thread walking all splits (55 us on the step's critical tail).  Here 16 lanes share an element quad, each
+        // sums a contiguous sixteenth of the splits in order, and the sixteen partial sums are added in a fixed order: the same
+        // result every run.
+        __shared__ f32x4 part[16][16];
+        const long n4 = numel >> 2;
+        const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
+        const long per = (splits + 15) / 16;
+        for (long i0 = (long)blockIdx.x * 16; i0 < n4; i0 += (long)gridDim.x * 16) {
+            const long i = i0 + e;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (i < n4) {
+                const long lo = c * per, hi = lo + per < splits ? lo + per : splits;
+                for (long s2 = lo; s2 < hi; s2 += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const f32x4*>(sl + (s2 + k < hi ? s2 + k : lo) * numel)[i];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (s2 + k < hi) { acc[0] += v[k][0]; acc[1] += v[k][1]; acc[2] += v[k][2]; acc[3] += v[k][3]; }
+                }
+            }
+            part[c][e] = acc;
+            __syncthreads();
+            if (c == 0 && i < n4) {
+                f32x4 t = part[0][e];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) { t[0] += part[k][e][0]; t[1] += part[k][e][1]; t[2] += part[k][e][2]; t[3] += part[k][e][3]; }
+                float4 o = reinterpret_cast<float4*>(g)[i];
+                o.x += t[0]; o.y += t[1]; o.z += t[2]; o.w += t[3];
+                reinterpret_cast<float4*>(g)[i] = o;
+            }
+            __syncthreads();
+        }
+    } else if (((off | numel | soff) & 3) == 0) {
         const long n4 = numel >> 2;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
             float4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -442,10 +501,39 @@ extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void
     return EP24_OK;
 }
 
+// Weight gradient of the Focus stem straight from the space-to-depth image (VTAP above): slab[s][Cout][108], column tap * 12 + channel
+static int stem_wgrad_args(WgradArgs& a, const void* f16, const void* dy, int64_t ld_dy, int B, int FH, int FW, int Cout) {
+    EP24_REQUIRE(Cout % 8 == 0 && Cout > 0 && Cout <= 64, EP24_E_UNSUPPORTED, "stem_conv_wgrad: Cout=%d (a multiple of 8, at most 64)", Cout);
+    // three virtual channel tiles of 64 = 12 tap slots x 16 channels; 1x1 addressing over the 32-byte pixels
+    if (int rc = fill_args(a, f16, 16, dy, ld_dy, nullptr, 108, Cout, 108, B, FH, FW, 192, Cout, 1, 1)) return rc;
+    a.x_bytes = (unsigned)((long)B * FH * FW * 32);
+    return EP24_OK;
+}
+
+extern "C" int ep24_stem_conv_wgrad_splits(int B, int FH, int FW, int Cout) {
+    WgradArgs a{};
+    if (int rc = stem_wgrad_args(a, nullptr, nullptr, (Cout + 7) / 8 * 8, B, FH, FW, Cout)) return rc;
+    return (int)wgrad_splits<64, 64>(a);
+}
+
+extern "C" int ep24_stem_conv_wgrad_slab_bf16(const void* f16, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats, int B,
+                                              int FH, int FW, int Cout, void* stream) {
+    EP24_REQUIRE(f16 && dy && slab, EP24_E_ARG, "stem_conv_wgrad_slab: null pointer");
+    WgradArgs a{};
+    if (int rc = stem_wgrad_args(a, f16, dy, ld_dy, B, FH, FW, Cout)) return rc;
+    a.slab = slab;
+    a.slab_stride = (long)Cout * 108;
+    const long need = wgrad_splits<64, 64>(a) * a.slab_stride;
+    EP24_REQUIRE(need <= slab_floats, EP24_E_ARG, "stem_conv_wgrad_slab: slab holds %ld floats, %ld needed", (long)slab_floats, need);
+    launch_wgrad<64, 64, true>(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_stem_conv_wgrad_slab");
+    return EP24_OK;
+}
+
 extern "C" int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream) {
     EP24_REQUIRE(desc && grad && slab && n_layers > 0 && max_numel > 0, EP24_E_ARG, "wgrad_reduce: bad arguments");
     long bx = (max_numel / 4 + 255) / 256;
-    bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
+    bx = bx < 128 ? 128 : (bx > 512 ? 512 : bx);              // at least 128: the many-splits form of a small layer spreads over them
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
                        grad, slab);
     EP24_LAUNCH_CHECK("ep24_wgrad_reduce");

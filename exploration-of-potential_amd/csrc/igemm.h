@@ -28,6 +28,11 @@ struct IgemmArgs {
     FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
     long M;
     int narrow_epi;                 // A/B option (kernel_opts bit 1 of the _ex entry points): the 8-byte-per-lane epilogue stores
+    // Input gradient whose epilogue also does the BatchNorm-backward REDUCTION of the layer below (bnr_z != null): what it stores is
+    // that layer's dy, so sum(du) and sum(du * zhat) (du = dy * act'(bn(z))) are taken from the tile while it leaves - the reduce
+    // kernel read dy and z once more for them.  [reps][..] fixed-point sums, replica stride bnr_rep_stride, as bn_act_bwd_reduce.
+    const bf16* bnr_z; long bnr_ldz; const float* bnr_mean; const float* bnr_invstd; const float* bnr_gamma; const float* bnr_beta;
+    long long* bnr_dgamma; long long* bnr_dbeta; long bnr_rep_stride; int bnr_reps; int bnr_act;
 };
 
 constexpr int BM = 128;
@@ -91,6 +96,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
         // the same wave reads back what it wrote (LDS operations of a wave complete in order): no barrier
         const int ch = lane & 7;
         const int cc = n0 + wn * 64 + ch * 8;
+        const bool bnr = MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
+        float bsc[8], bsh[8], biv[8], bmi[8], bsg[8], bsb[8];
+        if (bnr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cc + j < p.N ? cc + j : 0;
+                const float mean = p.bnr_mean[c], inv = p.bnr_invstd[c];
+                bsc[j] = p.bnr_gamma[c] * inv; bsh[j] = p.bnr_beta[c] - mean * bsc[j]; biv[j] = inv; bmi[j] = mean * inv;
+                bsg[j] = 0.f; bsb[j] = 0.f;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < MT * 2; ++k) {
             const int row = k * 8 + (lane >> 3);
@@ -111,6 +127,42 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
                 for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
             }
             *reinterpret_cast<bf16x8*>(d) = v;
+            if (bnr) {                                       // the expressions of bn_act_bwd_reduce_kernel on the rounded dy it would read
+                const bf16x8 vz = *reinterpret_cast<const bf16x8*>(p.bnr_z + dpix * p.bnr_ldz + cc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float zz = (float)vz[j];
+                    const float du = (float)v[j] * act_grad(fmaf(zz, bsc[j], bsh[j]), p.bnr_act);
+                    bsb[j] += du;
+                    bsg[j] = fmaf(du, fmaf(zz, biv[j], -bmi[j]), bsg[j]);
+                }
+            }
+        }
+        if (bnr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { bsg[j] += __shfl_xor(bsg[j], o, 64); bsb[j] += __shfl_xor(bsb[j], o, 64); }
+            }
+            __syncthreads();                                   // every wave is through with its staging area
+            float* red = reinterpret_cast<float*>(smem);       // [NWV waves][2][64]
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[(wave * 2 + 0) * 64 + ch * 8 + j] = bsg[j];
+                    red[(wave * 2 + 1) * 64 + ch * 8 + j] = bsb[j];
+                }
+            }
+            __syncthreads();
+            const long rep = (long)(tile_m % p.bnr_reps) * p.bnr_rep_stride;
+            for (int i = tid; i < 2 * BN; i += NWV * 64) {
+                const int which = i / BN, c = i - which * BN;
+                const int wcol = c >> 6;
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < WM; ++r) t += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
+                if (n0 + c < p.N) atomicAdd((unsigned long long*)((which ? p.bnr_dbeta : p.bnr_dgamma) + rep + n0 + c), (unsigned long long)to_fix(t));
+            }
         }
     } else
 #pragma unroll

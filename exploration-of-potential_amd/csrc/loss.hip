@@ -27,51 +27,64 @@ __device__ __forceinline__ float l1_target(const float* lab, int c, float s, flo
     return logf(sqrtf(px * px + py * py) / s + 1e-8f);
 }
 
+// The matched anchors of a workgroup (about one in a hundred), as thread indices in anchor order: ballots and a prefix over the
+// four waves, so the list - and with it every sum below - is the same on every run.  Every thread of the workgroup calls it.
+__device__ __forceinline__ int compact_matched(bool m, int* s_list, int* s_wc) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(m);
+    if (lane == 0) s_wc[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += s_wc[i];
+    if (m) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = threadIdx.x;
+    const int n = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    __syncthreads();
+    return n;
+}
+
+// Every anchor has an objectness term; the 24 ray terms, the class row and the L1 row exist for matched anchors only.  One thread
+// per anchor left a wave waiting while one or two of its lanes walked 24 rays and 80 classes alone (75 us on the exposed path
+// between forward and backward).  Now the workgroup lists its matched anchors and a WAVE takes one at a time: lane k the k-th ray,
+// all lanes the classes.  The terms are the per-anchor form's, expression by expression; only the order of the sums differs.
 __global__ __launch_bounds__(256) void loss_terms_kernel(const float* outputs, int ncols, const float* labels,
                                                          const int* matched_gt, const float* matched_iou, float* partials,
                                                          int A, int C, const float* origin, const float* xs,
                                                          const float* ys, const float* strides) {
     __shared__ float red[4][NS];
+    __shared__ int s_list[256];
+    __shared__ int s_wc[4];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
-    float acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int g = -1;
+    float obj = 0.f;
     if (a < A) {
-        const float* o = outputs + ((long)b * A + a) * ncols;
-        const int g = matched_gt[(long)b * A + a];
-        acc[24] = bce_logits(o[26], g >= 0 ? 1.f : 0.f);
-        if (g >= 0) {
-            const float* lab = labels + ((long)b * G_MAX + g) * LCOLS;
-            const float gcx = lab[1], gcy = lab[2];
-            const float ddx = gcx - o[0], ddy = gcy - o[1];
-            const float d = sqrtf(ddx * ddx + ddy * ddy);
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                const float vx = lab[3 + 2 * k] - gcx, vy = lab[4 + 2 * k] - gcy;
-                acc[k] = 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), o[2 + k], d);
-            }
-            const int cls = (int)lab[0];
-            const float piou = matched_iou[(long)b * A + a];
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) s += bce_logits(o[27 + c], c == cls ? piou : 0.f);
-            acc[25] = s;
-            acc[26] = 1.f;
-            if (origin) {                                     // losses.py:304-307: |origin_preds - l1_target| over 26 columns
-                const float* og = origin + ((long)b * A + a) * 26;
-                const float st = strides[a], xsh = xs[a], ysh = ys[a];
-                float l1 = 0.f;
-                for (int c = 0; c < 26; ++c) l1 += fabsf(og[c] - l1_target(lab, c, st, xsh, ysh));
-                acc[27] = l1;
-            }
+        g = matched_gt[(long)b * A + a];
+        obj = bce_logits(outputs[((long)b * A + a) * ncols + 26], g >= 0 ? 1.f : 0.f);
+    }
+    const int n = compact_matched(g >= 0, s_list, s_wc);
+    float acc_r = 0.f, acc_c = 0.f, acc_l1 = 0.f, cnt = 0.f;
+    for (int m = w; m < n; m += 4) {
+        const int am = blockIdx.x * 256 + s_list[m];
+        const float* o = outputs + ((long)b * A + am) * ncols;
+        const float* lab = labels + ((long)b * G_MAX + matched_gt[(long)b * A + am]) * LCOLS;
+        const float gcx = lab[1], gcy = lab[2];
+        const float ddx = gcx - o[0], ddy = gcy - o[1];
+        const float d = sqrtf(ddx * ddx + ddy * ddy);
+        if (lane < 24) {
+            const float vx = lab[3 + 2 * lane] - gcx, vy = lab[4 + 2 * lane] - gcy;
+            acc_r += 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), o[2 + lane], d);
         }
+        const int cls = (int)lab[0];
+        const float piou = matched_iou[(long)b * A + am];
+        for (int c = lane; c < C; c += 64) acc_c += bce_logits(o[27 + c], c == cls ? piou : 0.f);
+        cnt += 1.f;
+        if (origin && lane < 26)                              // losses.py:304-307: |origin_preds - l1_target| over 26 columns
+            acc_l1 += fabsf(origin[((long)b * A + am) * 26 + lane] - l1_target(lab, lane, strides[am], xs[am], ys[am]));
     }
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const float v = wave_sum(acc[i]);
-        if ((threadIdx.x & 63) == 0) red[w][i] = v;
-    }
+    const float obj_w = wave_sum(obj), c_w = wave_sum(acc_c), l1_w = wave_sum(acc_l1);
+    if (lane < 24) red[w][lane] = acc_r;
+    if (lane == 0) { red[w][24] = obj_w; red[w][25] = c_w; red[w][26] = cnt; red[w][27] = l1_w; }
     __syncthreads();
     if (threadIdx.x < NS) {
         float v = 0.f;
@@ -149,52 +162,81 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* outputs, in
                                                         const float* grad_scale, float* dout, int A, int C,
                                                         const float* origin, const float* xs, const float* ys,
                                                         const float* strides, float* d_origin) {
+    // 99 % of the anchors are unmatched: their rows are zero but for the objectness column.  One thread per anchor writing its own
+    // 107-float row made every store instruction 64 scattered 4-byte writes (72 MB of them: 95 us on the exposed path between
+    // forward and backward).  Now the block writes the rows of its 256 anchors cooperatively, consecutive lanes on consecutive
+    // addresses; the few matched anchors are skipped there and written by their own threads below.  Same values as before.
+    __shared__ float s_obj[256];
+    __shared__ int s_g[256];
     const int b = blockIdx.y;
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= A) return;
+    const int a0 = blockIdx.x * 256;
+    const int a = a0 + threadIdx.x;
     const float gs = (grad_scale ? *grad_scale : 1.0f) / result[27];
-    const float* o = outputs + ((long)b * A + a) * ncols;
-    float* d_o = dout + ((long)b * A + a) * ncols;
-    const int g = matched_gt[(long)b * A + a];
-    const float so = 1.0f / (1.0f + expf(-o[26]));
-    d_o[26] = result[53] * gs * (so - (g >= 0 ? 1.f : 0.f));
-    if (g < 0) {
-        for (int c = 0; c < 26; ++c) d_o[c] = 0.f;
-        for (int c = 27; c < ncols; ++c) d_o[c] = 0.f;
-        if (d_origin)
-            for (int c = 0; c < 26; ++c) d_origin[((long)b * A + a) * 26 + c] = 0.f;
-        return;
+    int g = -2;                                                        // -2: no such anchor
+    if (a < A) {
+        g = matched_gt[(long)b * A + a];
+        const float so = 1.0f / (1.0f + expf(-outputs[((long)b * A + a) * ncols + 26]));
+        s_obj[threadIdx.x] = result[53] * gs * (so - (g >= 0 ? 1.f : 0.f));
     }
-    const float* lab = labels + ((long)b * G_MAX + g) * LCOLS;
-    if (d_origin) {                                                    // d |x - t| = sign(x - t), unweighted, / num_fg
-        const float* og = origin + ((long)b * A + a) * 26;
-        const float st = strides[a], xsh = xs[a], ysh = ys[a];
-        for (int c = 0; c < 26; ++c) {
-            const float e = og[c] - l1_target(lab, c, st, xsh, ysh);
-            d_origin[((long)b * A + a) * 26 + c] = e > 0.f ? gs : (e < 0.f ? -gs : 0.f);
+    s_g[threadIdx.x] = g;
+    __syncthreads();
+    {
+        const int nrows = min(256, A - a0);
+        float* base = dout + ((long)b * A + a0) * ncols;
+        int row = threadIdx.x / ncols, col = threadIdx.x - row * ncols;
+        const int drow = 256 / ncols, dcol = 256 - drow * ncols;
+        for (int f = threadIdx.x; f < nrows * ncols; f += 256) {
+            if (s_g[row] < 0) base[f] = col == 26 ? s_obj[row] : 0.f;
+            row += drow; col += dcol;
+            if (col >= ncols) { col -= ncols; ++row; }
+        }
+        if (d_origin) {
+            float* ob = d_origin + ((long)b * A + a0) * 26;
+            for (int f = threadIdx.x; f < nrows * 26; f += 256)
+                if (s_g[f / 26] < 0) ob[f] = 0.f;
         }
     }
-    const float gcx = lab[1], gcy = lab[2];
-    const float ddx = gcx - o[0], ddy = gcy - o[1];
-    const float d = sqrtf(ddx * ddx + ddy * ddy);
-    float gd = 0.f;
-    for (int k = 0; k < 24; ++k) {
-        const float vx = lab[3 + 2 * k] - gcx, vy = lab[4 + 2 * k] - gcy;
-        float g_r, g_d;
-        ray_loss_grad(sqrtf(vx * vx + vy * vy), o[2 + k], d, g_r, g_d);
-        const float w = result[29 + k] * gs;
-        d_o[2 + k] = w * g_r;
-        gd += w * g_d;
-    }
-    // d = sqrt((gx-cx)^2 + (gy-cy)^2): dd/dcx = -(gx-cx)/d.  d == 0 gives NaN, exactly as the reference's autograd
-    d_o[0] = gd * (-ddx / d);
-    d_o[1] = gd * (-ddy / d);
-    const int cls = (int)lab[0];
-    const float piou = matched_iou[(long)b * A + a];
-    const float cw = result[54] * gs;
-    for (int c = 0; c < C; ++c) {
-        const float sc = 1.0f / (1.0f + expf(-o[27 + c]));
-        d_o[27 + c] = cw * (sc - (c == cls ? piou : 0.f));
+    // the matched anchors, one per wave at a time: lane k the k-th ray, all lanes the classes (the per-anchor loop kept one lane
+    // of a wave busy for 24 rays and 80 classes); consecutive lanes write consecutive columns
+    __shared__ int s_list[256];
+    __shared__ int s_wc[4];
+    const int n = compact_matched(g >= 0, s_list, s_wc);
+    const int lane = threadIdx.x & 63;
+    for (int m = threadIdx.x >> 6; m < n; m += 4) {
+        const int t = s_list[m], am = a0 + t;
+        const float* o = outputs + ((long)b * A + am) * ncols;
+        float* d_o = dout + ((long)b * A + am) * ncols;
+        const float* lab = labels + ((long)b * G_MAX + s_g[t]) * LCOLS;
+        if (d_origin && lane < 26) {                                   // d |x - t| = sign(x - t), unweighted, / num_fg
+            const float e = origin[((long)b * A + am) * 26 + lane] - l1_target(lab, lane, strides[am], xs[am], ys[am]);
+            d_origin[((long)b * A + am) * 26 + lane] = e > 0.f ? gs : (e < 0.f ? -gs : 0.f);
+        }
+        const float gcx = lab[1], gcy = lab[2];
+        const float ddx = gcx - o[0], ddy = gcy - o[1];
+        const float d = sqrtf(ddx * ddx + ddy * ddy);
+        float gdl = 0.f;
+        if (lane < 24) {
+            const float vx = lab[3 + 2 * lane] - gcx, vy = lab[4 + 2 * lane] - gcy;
+            float g_r, g_d;
+            ray_loss_grad(sqrtf(vx * vx + vy * vy), o[2 + lane], d, g_r, g_d);
+            const float wk = result[29 + lane] * gs;
+            d_o[2 + lane] = wk * g_r;
+            gdl = wk * g_d;
+        }
+        const float gd = wave_sum(gdl);
+        // d = sqrt((gx-cx)^2 + (gy-cy)^2): dd/dcx = -(gx-cx)/d.  d == 0 gives NaN, exactly as the reference's autograd
+        if (lane == 0) {
+            d_o[0] = gd * (-ddx / d);
+            d_o[1] = gd * (-ddy / d);
+            d_o[26] = s_obj[t];
+        }
+        const int cls = (int)lab[0];
+        const float piou = matched_iou[(long)b * A + am];
+        const float cw = result[54] * gs;
+        for (int c = lane; c < C; c += 64) {
+            const float sc = 1.0f / (1.0f + expf(-o[27 + c]));
+            d_o[27 + c] = cw * (sc - (c == cls ? piou : 0.f));
+        }
     }
 }
 

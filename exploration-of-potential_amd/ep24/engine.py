@@ -99,7 +99,10 @@ class Act:
 
     def slice(self, c0, C):
         assert self._alias is None
-        return Act(self.buf, self.c0 + c0, C, self.B, self.H, self.W)
+        a = Act(self.buf, self.c0 + c0, C, self.B, self.H, self.W)
+        if getattr(self, "bn_info", None) is not None:       # a channel range of a unit's output: the range of its BatchNorm
+            a.bn_info, a.bn_c0 = self.bn_info, getattr(self, "bn_c0", 0) + c0
+        return a
 
     def alias_grad(self, other):
         """d(self) shares storage with d(other): used by y = f(x) + x, where dx = dy + f'(...)."""
@@ -308,11 +311,12 @@ class ParamHome:
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
 
-    def pack(self):
-        """fp32 masters -> bf16 [Cout][T][Cin] (forward) and [Cin][T][Cout_pad] (dgrad) copies."""
+    def pack(self, which=0):
+        """fp32 masters -> bf16 [Cout][T][Cin] (forward) and [Cin][T][Cout_pad] (dgrad) copies; ``which`` = 1 / 2: only the first /
+        only the second (a captured step packs the dgrad copy on the other stream beside the start of the forward pass)."""
         call("pack_weights_batched", ptr(self.flat), ptr(self.pack_desc), ptr(self.pack_prefix), ptr(self.pack_tprefix),
              len(self.convs), ptr(self.wf), ptr(self.wd), self.pack_total, self.pack_tiles, ptr(self.pack_chunk_seg),
-             ptr(self.pack_tile_seg), stream_ptr())
+             ptr(self.pack_tile_seg), which, stream_ptr())
 
     def zero_grad(self):
         call("memset_zero", ptr(self.gflat), self.numel * 4, stream_ptr())
@@ -519,6 +523,7 @@ class Engine:
         self._cur_tag = None
         self._force_side = False
         self._deferred = []
+        self.bwd_tail_cut = None                 # index behind the reduce launch that precedes the last unit of backward
         self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
         self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
         self.options = get_options(model)        # per-model plan options (ep24.options): no process-wide switches
@@ -589,17 +594,28 @@ class Engine:
             raise NotImplementedError("ep24: the fp32 parity mode covers the CSPDarknet network (the BASELINE configuration)")
         return (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels, bb.dark5[0].conv.out_channels)
 
+    def focus_stem(self, focus):
+        """Focus + its 3x3 BaseConv (network_blocks.py:188-210).  bf16: the space-to-depth image [B][H/2][W/2][16] and a conv that
+        gathers the nine taps itself (no im2col buffer: it was 459 MB written and read twice per step at B = 20).  The fp32 parity
+        mode keeps the im2col rows (K = 108 -> 112) x 1x1 GEMM form."""
+        B = self.B
+        if self.f32:
+            rows = self.new_act(112, self.IH // 2, self.IW // 2)
+            rows.needs_grad = False
+            self._f("f32_stem_pack", ptr(self.images), rows.ptr(), 112, B, self.IH, self.IW)
+            return self.unit(focus.conv, rows, stem=True)
+        f16 = self.new_act(16, self.IH // 2, self.IW // 2)
+        f16.needs_grad = False
+        self._f("focus_pack", ptr(self.images), f16.ptr(), B, self.IH, self.IW)
+        return self.unit(focus.conv, f16, stem="focus")
+
     def build_backbone(self, bb, out3=None, out4=None):
         """images -> (dark3, dark4, dark5) (darknet.py:165-177); ``out3`` / ``out4``: concat slots of the neck to write into."""
         B = self.B
         if isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG)):      # BASELINE config 4 (yolox/models/yolo_pafpn.py:31-38)
             build = self.resnet if isinstance(bb, enn.ResNet) else self.vgg if isinstance(bb, enn.VGG) else self.densenet
             return build(bb, out3, out4)
-        # stem: Focus + 3x3 conv as im2col rows (K = 108 -> 112) x 1x1 GEMM
-        rows = self.new_act(112, self.IH // 2, self.IW // 2)
-        rows.needs_grad = False
-        self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, self.IH, self.IW)
-        x = self.unit(bb.stem.conv, rows, stem=True)
+        x = self.focus_stem(bb.stem)
         x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
         x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=out3)
         x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=out4)
@@ -695,6 +711,7 @@ class Engine:
                 # the last unit of backward (the stem): fold the pending weight-gradient slabs now, so that the final reduce launch
                 # covers this unit only and everything else is complete before it (ep24.train updates those parameters meanwhile)
                 self._flush_reduce()
+                self.bwd_tail_cut = len(self.bwd)
             b()
         self._force_side = False
         for f in self._deferred:
@@ -753,9 +770,12 @@ class Engine:
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
-    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None):
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
-        name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none)."""
+        name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none).  ``x_single``: the
+        caller states that this unit is the only consumer of ``x`` (a Bottleneck's 3x3 over its 1x1): its input gradient IS the
+        dy of the unit that produced x, and a 3x3 stride-1 one then takes that unit's BatchNorm-backward sums in its epilogue
+        (ep24_conv_dgrad_bnr_bf16) instead of a reduce launch re-reading dy and z."""
         home = self.home
         if act is None:                            # a BaseConv carries its activation (silu / relu / lrelu); merged pairs: the first module's
             act = getattr(mod, "act_code", 1)
@@ -763,10 +783,11 @@ class Engine:
         bn = mod.bn if bn is None else bn
         seg = home.by_param[conv.weight]
         gam, bet = home.by_param[bn.weight], home.by_param[bn.bias]
+        focus = stem == "focus"                   # the Focus stem over the space-to-depth image (16 channels, 12 real): its own kernels
         k = k_ = 1 if stem else conv.kernel_size[0]
         s = 1 if stem else conv.stride[0]
         cin = x.C                                  # stem: im2col width 112 (108 real columns)
-        assert x.C == seg.cin_pad if stem else x.C == seg.cin, (x.C, seg.cin)
+        assert (x.C == 16 and (x.ld, seg.cin) == (16, 108)) if focus else x.C == seg.cin_pad if stem else x.C == seg.cin, (x.C, seg.cin)
         cout = seg.cout
         B, H, W = x.B, x.H, x.W
         OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
@@ -793,12 +814,20 @@ class Engine:
             self._fold_w += cout * seg.taps * seg.cin_pad
             self._fold_c += cout
             self._fold_units.append((seg, gam, bet, bn, woff, coff))
-            ev_conv = ("conv_fwd_infer_bf16", (x.ptr(), x.ld, (lambda woff=woff: self.fold_w.data_ptr() + 2 * woff),
-                                               (lambda coff=coff: self.fold_b.data_ptr() + 4 * coff), act, res_p, res_ld, out.ptr(), out.ld,
-                                               B, H, W, cin, cout, k, s))
+            fw, fb = (lambda woff=woff: self.fold_w.data_ptr() + 2 * woff), (lambda coff=coff: self.fold_b.data_ptr() + 4 * coff)
+            if focus:
+                assert residual is None
+                ev_conv = ("stem_conv_fwd_infer_bf16", (x.ptr(), fw, seg.cin_pad, fb, act, out.ptr(), out.ld, B, H, W, cout))
+            else:
+                ev_conv = ("conv_fwd_infer_bf16", (x.ptr(), x.ld, fw, fb, act, res_p, res_ld, out.ptr(), out.ld, B, H, W, cin, cout, k, s))
+        elif focus:
+            ev_conv = ("stem_conv_fwd_bf16", (x.ptr(), wf, seg.cin_pad, z.ptr(), z.ld, None, 1, B, H, W, cout))
         else:
             ev_conv = ("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s))
-        self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s, ev=ev_conv)
+        if focus:
+            self._f("stem_conv_fwd_bf16", x.ptr(), wf, seg.cin_pad, z.ptr(), z.ld, stats, STATS_REPLICAS, B, H, W, cout, ev=ev_conv)
+        else:
+            self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s, ev=ev_conv)
         self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
                 ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
                 ptr(bn2.num_batches_tracked) if bn2 is not None else None, ptr(save), out.ptr(), out.ld,
@@ -809,6 +838,9 @@ class Engine:
         if residual is not None:
             residual.alias_grad(out)
         self.unit_acts[mod if mod is not None else conv] = (x, z, out)
+        info = dict(z=z, save=save, gam=gam, bet=bet, sum_g=sum_g, sum_b=sum_b, act=act, cout=cout, fused=0)
+        if residual is None:                       # with a residual the incoming gradient is shared with the shortcut: not this unit's alone
+            out.bn_info, out.bn_c0 = info, 0
 
         def build_bwd():
             assert out.gready(), "activation without a gradient producer"
@@ -817,24 +849,31 @@ class Engine:
             dzoff = self._dz_elems
             self._dz_elems += M * cout
             dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
-            self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                          ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
+            assert info["fused"] in (0, cout), "BatchNorm-backward sums fused for a part of the channels only"
+            if not info["fused"]:                     # else: the consumer's input-gradient epilogue has produced the two sums
+                self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
             self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                          ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                         dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet))
+                                         dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet), reads=out if info["fused"] else None)
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
             # few layers folds them into the flat gradient in a fixed order (no atomics: bitwise reproducible)
-            splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k_, s)
+            splits = _lib.lib().fn["ep24_stem_conv_wgrad_splits"](B, H, W, cout) if focus else \
+                _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k_, s)
             assert splits >= 1, splits
             soff = self._slab_floats
             self._slab_floats += splits * seg.numel
 
             def emit_wgrad():
                 self._b("@side_wait_main", ())
-                self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, cout, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
-                                                      splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k_, s))
+                slab_p = (lambda soff=soff: self.slab.data_ptr() + 4 * soff)
+                if focus:
+                    self._b("side:stem_conv_wgrad_slab_bf16", (x.ptr(), dz, cout, slab_p, splits * seg.numel, B, H, W, cout))
+                else:
+                    self._b("side:conv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, cout, slab_p,
+                                                          splits * seg.numel, seg.taps * seg.cin, cout, seg.cin, B, H, W, cin, cout, k_, s))
                 self._b("@side_record", (k,))
                 self._pending_reduce.append((seg, splits, soff))
                 if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
@@ -848,8 +887,19 @@ class Engine:
                 emit_wgrad()
             if x.needs_grad:
                 acc = x.gwrite()
-                self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
-                                            seg.cout_pad, k_, s))
+                below = getattr(x, "bn_info", None) if x_single else None
+                if (below is not None and not acc and k_ == 3 and s == 1 and self.options.fuse_bn_reduce and x._alias is None and
+                        x.C % 8 == 0 and x.gld % 8 == 0 and below["z"].ld % 8 == 0):
+                    o, ct = x.bn_c0, below["cout"]
+                    zb, sv, gb, bb = below["z"], below["save"], below["gam"], below["bet"]
+                    self._b("conv_dgrad_bnr_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, B, H, W, cin, seg.cout_pad, k_,
+                                                    zb.ptr() + 2 * o, zb.ld, ptr(sv, o), ptr(sv, ct + o), ptr(flat, gb.off + o), ptr(flat, bb.off + o),
+                                                    (lambda f=below["sum_g"], o=o: f() + 8 * o), (lambda f=below["sum_b"], o=o: f() + 8 * o),
+                                                    2 * ct, STATS_REPLICAS, below["act"]))
+                    below["fused"] += x.C
+                else:
+                    self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
+                                                seg.cout_pad, k_, s))
 
         self._add_builder(build_bwd)
         return out
@@ -901,7 +951,7 @@ class Engine:
         for i, blk in enumerate(mod.m):
             last = i == n - 1
             u = self.unit(blk.conv1, t)
-            t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None)
+            t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, cat, out=out)
 
     def relu(self, y):
@@ -1168,7 +1218,7 @@ class Engine:
             self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
             u = self.unit(blk.conv1, t)
-            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None)
+            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 
     def spp(self, mod, x):
@@ -1216,15 +1266,15 @@ class Engine:
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
             _same_bn(c0.bn, r0.bn)
-            both = self.unit(None, x, conv=c0.conv, bn=c0.bn, act=c0.act_code, bn2=r0.bn)   # [class branch | regression branch], one GEMM (N = 2h)
+            both = self.unit(None, x, conv=c0.conv, bn=c0.bn, act=c0.act_code, bn2=r0.bn, x_single=True)   # [class branch | regression branch], one GEMM (N = 2h)
             xa, za, ya = self.unit_acts.pop(c0.conv)
             self.unit_acts[c0] = (xa, za.slice(0, hc), ya.slice(0, hc))
             self.unit_acts[r0] = (xa, za.slice(hc, hc), ya.slice(hc, hc))
-            cf = self.unit(head.cls_convs[k][1], both.slice(0, hc))
-            rf = self.unit(head.reg_convs[k][1], both.slice(hc, hc))
+            cf = self.unit(head.cls_convs[k][1], both.slice(0, hc), x_single=True)      # each branch owns its half of the merged unit's channels
+            rf = self.unit(head.reg_convs[k][1], both.slice(hc, hc), x_single=True)
         else:
-            cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x))
-            rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x))
+            cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x), x_single=True)
+            rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x), x_single=True)
         ro_seg = home.by_param[head.reg_preds[k].weight]
         ro_b = home.by_param[head.reg_preds[k].bias]
         cl_seg = home.by_param[head.cls_preds[k].weight]
@@ -1500,12 +1550,9 @@ class SubEngine(Engine):
                                           "first convs of the head branches): call the enclosing module, or build the model with PlanOptions(merge_csp=False, merge_head=False)")
             self.outs = [self.unit(mod, x)]
         elif kind == "focus":
-            rows = self.new_act(112, self.IH // 2, self.IW // 2)
-            rows.needs_grad = False
-            self._f("f32_stem_pack" if self.f32 else "stem_pack", ptr(self.images), rows.ptr(), 112, B, self.IH, self.IW)
-            self.outs = [self.unit(mod.conv, rows, stem=True)]
+            self.outs = [self.focus_stem(mod)]
         elif kind == "bottleneck":
-            self.outs = [self.unit(mod.conv2, self.unit(mod.conv1, x), residual=x if mod.use_add else None)]
+            self.outs = [self.unit(mod.conv2, self.unit(mod.conv1, x), residual=x if mod.use_add else None, x_single=True)]
         elif kind == "csp":
             self.outs = [self.csp(mod, x)]
         elif kind == "spp":

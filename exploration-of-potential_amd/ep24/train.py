@@ -140,19 +140,26 @@ class TrainStep:
             return eng.fwd[:fork], eng.fwd[fork:f1], eng.fwd[lo:hi], eng.fwd[f1:lo] + eng.fwd[hi1:], eng.fwd[lo1:hi1]
         return eng.fwd[:fork], eng.fwd[fork:lo] + eng.fwd[hi:], eng.fwd[lo:hi]
 
+    def _phase_pre_side(self):
+        """The label-only part of SimOTA (candidate masks) on the second lane beside the start of the forward pass: that lane is idle
+        until the level-0 head forks.  (The candidate kernel used to deviate next to MFMA kernels: a v_pk_mul_f32 with swapped
+        operand halves emitted by the SLP vectoriser, rooted in round 3 - tools/hazard_probe.hip; the library
+        is built without it, tests/test_gpu_hazard.py.)"""
+        eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
+
+    def _phase_pre_backward(self):
+        """What only backward needs, on the second lane while the main lane runs the loss (a chain of small kernels that leave most
+        of the chip idle): the gradient clear and the transposed weight copy of the input-gradient kernels.  At the start of the
+        step the same two kernels shared the memory system with the stem (profiles/r03_stream_gaps.txt)."""
+        self.home.zero_grad()
+        self.home.pack(2)
+
     def _phase_forward_head(self):
         eng = self.eng
-        # The label-only part of SimOTA (candidate masks) runs first: it depends on nothing but the labels.  (In round 2 it
-        # opened the second forward lane, and next to the MFMA kernels of the other lane its angle sums came back different
-        # in lanes 48..63 of a wave now and then.  Root cause, round 3: a v_pk_mul_f32 with swapped operand halves emitted by
-        # the SLP vectoriser - tools/hazard_probe.hip; the library is built without it and the kernel is
-        # correct on any stream, tests/test_gpu_hazard.py.  The placement stays: nothing needs the masks earlier.)
-        eloss.assign_candidates(self.ws, self.labels, self.xs, self.ys, self.st)
-        self.home.zero_grad()
         if not torch.cuda.is_current_stream_capturing():
             eng.draw_dropout()
         eng.zero_step_buffers()
-        self.home.pack()
+        self.home.pack(1)
         eng.run_lane(self._fwd_split()[0])
 
     def _phase_loss(self):
@@ -213,6 +220,8 @@ class TrainStep:
             rc = self.reducer.cuts(self.eng)
             cuts |= set(rc)
             ready = {c: i for i, c in enumerate(rc[1:])}          # cut index -> reducer segment that ends there
+        if getattr(self.eng, "bwd_tail_cut", None):            # the reduce launch in front of the last unit closes a segment:
+            cuts.add(self.eng.bwd_tail_cut)                    # the side lane runs it while the main lane does that unit's BatchNorm
         join = self.eng.bwd_join
         if join is not None:                                   # head levels 1, 2 run on the side lane up to here
             cuts.add(join)
@@ -253,6 +262,8 @@ class TrainStep:
             self.g_fwd = capture(self._phase_forward)
         else:
             lanes = [capture(lambda l=l: eng.run_lane(l)) for l in split[1:]]
+            self.g_pre = capture(self._phase_pre_side)
+            self.g_pre_bwd = capture(self._phase_pre_backward)
             self.g_fwd = (capture(self._phase_forward_head),) + tuple(lanes) + (capture(self._phase_loss),)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
@@ -301,6 +312,14 @@ class TrainStep:
                 self.reducer.reduce_all()
             self._phase_update()
             return self.ws.result
+        if isinstance(self.g_fwd, tuple):
+            # the second lane starts the step too: candidate masks (the loss waits for this lane's later work anyway)
+            main, side = torch.cuda.current_stream(), self._side
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                self.g_pre.replay()
         if isinstance(self.g_fwd, tuple) and len(self.g_fwd) == 6:
             g1, g_main_a, g_side, g_main_b, g_side2, g_loss = self.g_fwd
             main, side, side2 = torch.cuda.current_stream(), self._side, self._side2
@@ -320,6 +339,11 @@ class TrainStep:
             main.wait_stream(side)
             main.wait_stream(side2)
             g_loss.replay()
+            with torch.cuda.stream(side):
+                self.g_pre_bwd.replay()
+            ev_pb = torch.cuda.Event()
+            ev_pb.record(side)
+            main.wait_event(ev_pb)
         elif isinstance(self.g_fwd, tuple):
             g1, g_main, g_side, g_loss = self.g_fwd
             main, side = torch.cuda.current_stream(), self._side
@@ -334,6 +358,11 @@ class TrainStep:
             ev2.record(side)
             main.wait_event(ev2)
             g_loss.replay()
+            with torch.cuda.stream(side):
+                self.g_pre_bwd.replay()                # beside the loss; backward starts behind both
+            ev_pb = torch.cuda.Event()
+            ev_pb.record(side)
+            main.wait_event(ev_pb)
         else:
             self.g_fwd.replay()
         did_early = False
@@ -370,7 +399,11 @@ class TrainStep:
 
             for gm, gs, ready, join, par in self.g_bwd:
                 if join:
-                    if pending is not None:
+                    # Only a pending segment that IS one of the side-lane head chains has to be enqueued before the wait (its event is
+                    # what the main lane waits for).  Anything else (the weight gradients of the level-0 head) goes in behind the
+                    # main lane's next graph as always: enqueueing it first held the host until the main lane had reached that
+                    # segment's event, and the trunk's first graph arrived ~0.18 ms late (profiles/r03_stream_gaps.txt).
+                    if pending is not None and pending[3]:
                         par_done = launch_side_ev(pending) or par_done
                         pending = None
                     if par_done is not None:

@@ -62,6 +62,16 @@ int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, i
 int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
                             int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, int kernel_opts, void* stream);
 
+/* Input gradient of a stride-1 conv that is the ONLY consumer of the conv-BN-act unit below it (a Bottleneck's 3x3 over its 1x1,
+ * network_blocks.py:54-79): dx IS that unit's dy, so the epilogue also takes the unit's two BatchNorm-backward sums - what
+ * ep24_bn_act_bwd_reduce would compute from dx and z - from the tile on its way out.  z [B*H*W][ld_z]: the unit's conv output;
+ * mean / invstd / gamma / beta [Cin]; dgamma / dbeta: fixed-point sums, replica r at + r * rep_stride.  First writer only (dx is
+ * overwritten); Cin, ld_dx, ld_z multiples of 8. */
+int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int B, int H, int W, int Cin,
+                             int Cout_k, int ksize, const void* z, int64_t ld_z, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, int64_t rep_stride, int reps,
+                             int act, void* stream);
+
 /* Which device kernel ep24_conv_fwd_bf16 (dgrad = 0) / ep24_conv_dgrad_bf16 (dgrad = 1, stride 1) launches for a shape - the
  * library's own dispatch rule, for reports (bench.py attributes launch times to kernels with it).  Returns 0 =
  * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch), 2 = igemm_stream_kernel (1x1 streaming), < 0 on error.
@@ -103,10 +113,11 @@ int ep24_pack_weights(const float* w, int64_t ld_w, void* w_fwd, void* w_dgrad, 
  * [n_seg+1] int64 = running sum of Cout*T*Cin (total = prefix[n_seg]); tile_prefix [n_seg+1] = running sum of
  * T*ceil(Cout/64)*ceil(Cin/64), the 64x64 tiles of the LDS transpose that writes w_dgrad coalesced.
  * chunk_seg [ceil(total/4096)] int32 = segment of element 4096*c and tile_seg [total_tiles] int32 = segment of tile t are
- * optional lookup tables built once by the host (NULL: the kernels bisect the prefix tables, eight dependent loads per chunk). */
+ * optional lookup tables built once by the host (NULL: the kernels bisect the prefix tables, eight dependent loads per chunk).
+ * which: 0 both copies, 1 w_fwd only, 2 w_dgrad only (backward is the first to read it). */
 int ep24_pack_weights_batched(const float* flat, const int64_t* desc, const int64_t* prefix, const int64_t* tile_prefix,
                               int n_seg, void* w_fwd, void* w_dgrad, int64_t total, int64_t total_tiles,
-                              const int32_t* chunk_seg, const int32_t* tile_seg, void* stream);
+                              const int32_t* chunk_seg, const int32_t* tile_seg, int which, void* stream);
 
 /* y = silu(bn(z)) (+ residual), training-mode BatchNorm with batch statistics taken from `stats`
  * ([replicas][2][C] fixed-point sums over the M rows, as written by ep24_conv_fwd_bf16).  Also writes save[0][c]=mean,
@@ -179,6 +190,22 @@ int ep24_f32_colsum(const float* g, int64_t ld, float* db, int64_t M, int N, voi
 /* Focus + im2col for the 3x3 stem: images [B,3,S,S] fp32 NCHW -> rows [B*(S/2)^2][ld] bf16, columns
  * (kh,kw,c4) with c4 = TL,BL,TR,BR x 3 channels, 108 real + zero padding to ld (network_blocks.py:188-210). */
 int ep24_stem_pack(const float* images, void* rows, int64_t ld, int B, int H, int W, void* stream);
+
+/* The Focus stem without an im2col buffer (round 3; network_blocks.py:188-210, Focus.forward + its BaseConv 3x3 over 12 channels).
+ * ep24_focus_pack: images [B,3,S,S] fp32 NCHW -> f16 [B][S/2][S/2][16] bf16, channel (x parity * 2 + y parity) * 3 + c (the
+ * reference's cat(top-left, bottom-left, top-right, bottom-right)), channels 12..15 zero.
+ * ep24_stem_conv_fwd_bf16: y[B*FH*FW][ld_y] = conv3x3(f16, w), w = [Cout][ld_w] bf16 with column tap * 12 + channel (the packed
+ * forward copy of the [Cout][3][3][12] master); stats as ep24_conv_fwd_bf16.  _infer: y = act(acc + bias) (BatchNorm folded).
+ * ep24_stem_conv_wgrad_slab_bf16: slab[s][Cout][108] = partial dW of pixel split s (column tap * 12 + channel), folded by
+ * ep24_wgrad_reduce; ep24_stem_conv_wgrad_splits = the number of splits.  Cout <= 64 for the weight gradient. */
+int ep24_focus_pack(const float* images, void* f16, int B, int H, int W, void* stream);
+int ep24_stem_conv_fwd_bf16(const void* f16, const void* w, int64_t ld_w, void* y, int64_t ld_y, int64_t* stats, int stats_replicas,
+                            int B, int FH, int FW, int Cout, void* stream);
+int ep24_stem_conv_fwd_infer_bf16(const void* f16, const void* w, int64_t ld_w, const float* bias, int act, void* y, int64_t ld_y,
+                                  int B, int FH, int FW, int Cout, void* stream);
+int ep24_stem_conv_wgrad_slab_bf16(const void* f16, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats, int B, int FH,
+                                   int FW, int Cout, void* stream);
+int ep24_stem_conv_wgrad_splits(int B, int FH, int FW, int Cout);
 
 /* SPP max pools k = 5, 9, 13, stride 1, pad k/2 over x[B,H,W,C] (network_blocks.py:131-143).  Writes the
  * three pooled maps into y5/y9/y13 (row stride ld_y) and the winning window offset (dy*16+dx biased by 8)

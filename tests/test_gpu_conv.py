@@ -195,6 +195,90 @@ def test_conv_hot_shapes(shape):
     close(g.view(Cout, k, k, Cin).permute(0, 3, 1, 2), dw_ref, rel=5e-3)
 
 
+@pytest.mark.parametrize("B,IH,IW,Cout", [(2, 32, 32, 64), (3, 96, 80, 64), (1, 64, 132, 24), (2, 48, 40, 8), (5, 160, 160, 64)])
+def test_focus_stem_without_im2col(B, IH, IW, Cout):
+    """Focus + 3x3 conv over the space-to-depth image (network_blocks.py:188-210): pack bit-exact, forward / statistics / eval-mode
+    form / weight gradient against torch on the same bf16 operands; row, column and channel tails, several pixel splits."""
+    call, ptr, sp = _abi()
+    from ep24._lib import lib
+    img = torch.rand(B, 3, IH, IW, generator=torch.Generator().manual_seed(61)) * 255 - 100
+    FH, FW = IH // 2, IW // 2
+    f16 = torch.full((B, FH, FW, 16), 9.0, dtype=BF, device=DEV)
+    imgd = img.to(DEV)
+    call("focus_pack", ptr(imgd), ptr(f16), B, IH, IW, sp())
+    foc = torch.cat([img[..., 0::2, 0::2], img[..., 1::2, 0::2], img[..., 0::2, 1::2], img[..., 1::2, 1::2]], 1)   # Focus.forward
+    assert torch.equal(f16[..., :12].float().cpu(), nhwc(foc).to(BF).float())
+    assert float(f16[..., 12:].abs().sum()) == 0
+    w = rnd(Cout, 12, 3, 3, seed=62, scale=108 ** -0.5 / 50)
+    xr = foc.to(BF).float()
+    wr = w.float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, 1, 1)
+    wrow = torch.zeros(Cout, 112, dtype=BF)
+    wrow[:, :108] = w.permute(0, 2, 3, 1).reshape(Cout, 108)                # column tap * 12 + channel
+    wrow = wrow.to(DEV)
+    R = 3
+    y = torch.full((B, FH, FW, Cout), 5.0, dtype=BF, device=DEV)
+    stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
+    call("stem_conv_fwd_bf16", ptr(f16), ptr(wrow), 112, ptr(y), Cout, ptr(stats), R, B, FH, FW, Cout, sp())
+    close(y.permute(0, 3, 1, 2), y_ref.detach())
+    st = stats.sum(0).cpu().double().div(2 ** 20).float()
+    yr = y_ref.detach()
+    close(st[0], yr.sum((0, 2, 3)), rel=2e-3)
+    close(st[1], (yr * yr).sum((0, 2, 3)), rel=2e-3)
+    # eval mode: y = silu(acc + bias)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(63))
+    y2 = torch.zeros(B, FH, FW, Cout, dtype=BF, device=DEV)
+    bd = bias.to(DEV)
+    call("stem_conv_fwd_infer_bf16", ptr(f16), ptr(wrow), 112, ptr(bd), 1, ptr(y2), Cout, B, FH, FW, Cout, sp())
+    close(y2.permute(0, 3, 1, 2), F.silu(yr + bias.view(1, -1, 1, 1)))
+    # weight gradient: slabs of the pixel splits, folded by wgrad_reduce
+    gy = rnd(B, Cout, FH, FW, seed=64)
+    y_ref.backward(gy.float())
+    gyd = nhwc(gy).to(DEV)
+    splits = lib().fn["ep24_stem_conv_wgrad_splits"](B, FH, FW, Cout)
+    assert splits >= 1
+    slab = torch.full((splits, Cout, 108), float("nan"), device=DEV)
+    call("stem_conv_wgrad_slab_bf16", ptr(f16), ptr(gyd), Cout, ptr(slab), slab.numel(), B, FH, FW, Cout, sp())
+    dw = slab.sum(0).view(Cout, 3, 3, 12).permute(0, 3, 1, 2)
+    close(dw, wr.grad, rel=5e-3)
+    slab2 = torch.zeros_like(slab)
+    call("stem_conv_wgrad_slab_bf16", ptr(f16), ptr(gyd), Cout, ptr(slab2), slab.numel(), B, FH, FW, Cout, sp())
+    assert torch.equal(slab, slab2)                                         # plain stores, fixed order: the same bits every run
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [(2, 20, 20, 64, 64, 1), (3, 16, 24, 128, 128, 1), (5, 9, 9, 72, 200, 2), (2, 12, 12, 16, 24, 1),
+                                                  (2, 40, 40, 256, 256, 1), (1, 7, 13, 8, 40, 3)])
+def test_dgrad_with_fused_bn_reduce(B, H, W, Cin, Cout, act):
+    """ep24_conv_dgrad_bnr_bf16 = ep24_conv_dgrad_bf16 followed by ep24_bn_act_bwd_reduce on its result: the same dx bit for bit,
+    the same two sums up to the order of fp32 partial sums (halo-patch and tiled kernels, row / channel tails, three activations)."""
+    call, ptr, sp = _abi()
+    M = B * H * W
+    gy = nhwc(rnd(B, Cout, H, W, seed=71)).to(DEV)
+    wd = rnd(Cin, 3, 3, Cout, seed=72, scale=(Cout * 9) ** -0.5).to(DEV)
+    z = nhwc(rnd(B, Cin, H, W, seed=73)).to(DEV)
+    g = torch.Generator().manual_seed(74)
+    mean, inv = torch.randn(Cin, generator=g) * 0.3, torch.rand(Cin, generator=g) + 0.5
+    save = torch.cat([mean, inv]).to(DEV)
+    gamma, beta = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (torch.randn(Cin, generator=g) * 0.2).to(DEV)
+    R = 4
+    dx = torch.full((B, H, W, Cin), 3.0, dtype=BF, device=DEV)
+    call("conv_dgrad_bf16", ptr(gy), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, 3, 1, sp())
+    sums = torch.zeros(R, 2, Cin, dtype=torch.int64, device=DEV)
+    call("bn_act_bwd_reduce", ptr(dx), Cin, ptr(z), Cin, ptr(save), ptr(gamma), ptr(beta), ptr(sums), ptr(sums) + 8 * Cin, M, Cin, act, R, sp())
+    dx2 = torch.full((B, H, W, Cin), 5.0, dtype=BF, device=DEV)
+    sums2 = torch.zeros(R, 2, Cin, dtype=torch.int64, device=DEV)
+    call("conv_dgrad_bnr_bf16", ptr(gy), Cout, ptr(wd), ptr(dx2), Cin, B, H, W, Cin, Cout, 3, ptr(z), Cin, ptr(save), ptr(save) + 4 * Cin,
+         ptr(gamma), ptr(beta), ptr(sums2), ptr(sums2) + 8 * Cin, 2 * Cin, R, act, sp())
+    assert torch.equal(dx, dx2)
+    a, b = sums.sum(0).cpu().double() / 2 ** 20, sums2.sum(0).cpu().double() / 2 ** 20
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-3, ((a - b).abs().max().item(), scale)
+    sums3 = torch.zeros_like(sums2)
+    call("conv_dgrad_bnr_bf16", ptr(gy), Cout, ptr(wd), ptr(dx2), Cin, B, H, W, Cin, Cout, 3, ptr(z), Cin, ptr(save), ptr(save) + 4 * Cin,
+         ptr(gamma), ptr(beta), ptr(sums3), ptr(sums3) + 8 * Cin, 2 * Cin, R, act, sp())
+    assert torch.equal(sums2.sum(0), sums3.sum(0))                           # fixed-point sums: the same bits every run
+
+
 def test_conv_refuses_operands_beyond_2gib():
     """32-bit tile addressing: an activation of 2 GiB or more is refused, not wrapped (pointers are never dereferenced)."""
     call, ptr, sp = _abi()

@@ -41,10 +41,7 @@ def block_engine(mod, name, x):
             B, C, H, W = x.shape
             if name == "focus":
                 self.images = x.to(self.dev).float().contiguous()
-                rows = self.new_act(112, H // 2, W // 2)
-                rows.needs_grad = False
-                self._f("stem_pack", self.images.data_ptr(), rows.ptr(), 112, B, H, W)
-                self.xin, out = None, self.unit(mod.conv, rows, stem=True)
+                self.xin, out = None, self.focus_stem(mod)
             else:
                 xin = self.new_act(C, H, W)
                 xin.buf.t.copy_(x.permute(0, 2, 3, 1).reshape(-1).to(BF))

@@ -107,11 +107,13 @@ def test_config5_full_size_step_with_the_warp_in_the_loop():
 def test_bf16_product_forward_vs_bf16_emulating_oracle_end_to_end():
     """YOLOX-l, B = 2, 640 x 640.  Both paths store bf16 at the same points (conv inputs, packed weights, raw conv outputs,
     activated outputs) and accumulate in fp32, so what is left is accumulation order and the 1-ulp differences it causes, carried
-    through 131 BatchNorm layers.  Asserted: the decoded head outputs and the loss of the product against the chained oracle at
-    the tolerances below.  Measured on MI355X: rms relative error 1.0e-2 on the centres, 0.11 on the log-radii, 5.6e-2 on the
+    through 131 BatchNorm layers.  Asserted: the decoded head outputs of the product against the chained oracle at the tolerances
+    below, and the loss two ways.  Measured on MI355X: rms relative error 1.0e-2 on the centres, 0.11 on the log-radii, 5.4e-2 on the
     logits - 131 BatchNorm layers over a batch of 2 amplify one-ulp differences, though 3 - 6 times less than the ~30 % rms between
-    the fp32 reference and either bf16 path - while the LOSS, a sum over 16 800 anchors, agrees to 2e-4 (44.566 against 44.557).
-    The bounds are about twice the measured values."""
+    the fp32 reference and either bf16 path.  The loss: the product's loss kernels against the ORACLE's loss on the product's own
+    head outputs (same inputs: 1e-4), and against the oracle's loss on the oracle's outputs (different inputs, and SimOTA's
+    matching is discrete: 44.780 against 44.557 with the gathering stem of round 3, 44.566 with the im2col stem before it - both
+    inside the 2 % asserted; the output errors are the same in both).  The output bounds are about twice the measured values."""
     from ep24 import loss as eloss
     from oracle import model as om
     from oracle.loss import LossOracle
@@ -144,6 +146,7 @@ def test_bf16_product_forward_vs_bf16_emulating_oracle_end_to_end():
         om.EMULATE_BF16 = False
     want = want_tuple[3].float()
     loss_want = float(LossOracle(80)(want_tuple, labels)[0])
+    loss_same_inputs = float(LossOracle(80)(synth.outputs_train_tuple(got.clone(), size=S), labels)[0])
 
     def rel(a, b):
         return float((a - b).abs().max() / b.abs().max())
@@ -155,4 +158,5 @@ def test_bf16_product_forward_vs_bf16_emulating_oracle_end_to_end():
     print("bf16 bridge: rms rel err centres %.3e, log-radii %.3e, logits %.3e; max rel logits %.3e; loss %.5f vs %.5f" %
           (e_xy, e_r, e_lg, rel(got[..., 26:], want[..., 26:]), loss_got, loss_want))
     assert e_xy < 2.5e-2 and e_r < 0.25 and e_lg < 0.12, (e_xy, e_r, e_lg)
-    assert abs(loss_got - loss_want) < 1e-3 * abs(loss_want), (loss_got, loss_want)
+    assert abs(loss_got - loss_same_inputs) < 1e-4 * abs(loss_same_inputs), (loss_got, loss_same_inputs)
+    assert abs(loss_got - loss_want) < 2e-2 * abs(loss_want), (loss_got, loss_want)

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+sgd = [i for i, r in enumerate(rows) if "clear_flag_kernel" in r["Kernel_Name"]]     # once per step, behind the last part of the update
 k = int(sys.argv[3]) if len(sys.argv) > 3 else len(sgd) - 3
 step = rows[sgd[k] + 1:sgd[k + 1] + 1]
 t0 = step[0]["s"]
