@@ -72,6 +72,12 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 #define EP24_FIX_SCALE 1048576.0f
 __device__ __forceinline__ long long to_fix(float v) { return (long long)__float2ll_rn(v * EP24_FIX_SCALE); }
 __device__ __forceinline__ float from_fix(long long v) { return (float)((double)v * (1.0 / 1048576.0)); }
+// The two sums of BatchNorm BACKWARD (du and du * zhat over the pixels) are sums of GRADIENTS: in the class branch of the head a
+// workgroup's partial sum is 1e-5 .. 1e-4, i.e. 10 .. 100 units of 2^-20 - round 3 found channels whose gamma / beta gradient had
+// rounded to exactly 0 that way (0.8 % of the channels of the head's first class conv).  They use 2^-36: resolution 1.5e-11,
+// |sum| < 1.3e8 (gradient sums over 2 M pixels stay many orders below that).
+__device__ __forceinline__ long long to_fix_g(float v) { return (long long)__float2ll_rn(v * 68719476736.0f); }
+__device__ __forceinline__ float from_fix_g(long long v) { return (float)((double)v * (1.0 / 68719476736.0)); }
 
 // exact x / d for 0 <= x < 2^31 with one mulhi + shift (divisor known at launch time)
 struct FastDiv {

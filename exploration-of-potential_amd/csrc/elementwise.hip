@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
             // replica blockIdx % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
             // addresses at about the same time - 256 serial adds per address at the memory-side atomic units, ~5 us of tail
             long long* dst = (v < 8 ? dgamma : dbeta) + (long)(blockIdx.x % reps) * 2 * C + (cg0 + g) * 8 + (v & 7);
-            atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix(a));
+            atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix_g(a));
         }
         __syncthreads();
     }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc += rb + r < reps ? a[r] : 0ll;
         }
-        folded[i] = from_fix(acc);
+        folded[i] = from_fix_g(acc);
     }
     __syncthreads();
     for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048

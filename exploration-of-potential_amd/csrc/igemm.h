@@ -75,6 +75,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
     const bool wide = MODE == 0 && !OUT_F32 && !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 &&
                       (reinterpret_cast<unsigned long long>(p.dst) & 15) == 0;
     if (wide) {
+        // fused BatchNorm-backward sums: the z rows of this wave's part of the tile are requested NOW, all of them (clamped indices, no
+        // conditional load), so they arrive while the accumulators go through LDS - fetched inside the store loop they were eight
+        // serial round trips per workgroup (+24 us per launch: more than the reduce kernel they replace)
+        const bool bnr = MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
+        bf16x8 zr[MT * 2];
+        if (bnr) {
+            const int zc = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int k = 0; k < MT * 2; ++k) {
+                const long m = m0 + wm * (MT * 16) + k * 8 + (lane >> 3);
+                zr[k] = *reinterpret_cast<const bf16x8*>(p.bnr_z + (m < p.M ? m : 0) * p.bnr_ldz + (zc < p.N ? zc : 0));
+            }
+        }
         __syncthreads();                                   // every wave is out of the main loop: LDS is free
         char* stg = smem + wave * (MT * 16 * 128);         // [MT*16 rows][128 B], 16-byte chunk index XOR (row & 7)
 #pragma unroll
@@ -96,7 +109,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
         // the same wave reads back what it wrote (LDS operations of a wave complete in order): no barrier
         const int ch = lane & 7;
         const int cc = n0 + wn * 64 + ch * 8;
-        const bool bnr = MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
         float bsc[8], bsh[8], biv[8], bmi[8], bsg[8], bsb[8];
         if (bnr) {
 #pragma unroll
@@ -128,7 +140,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             }
             *reinterpret_cast<bf16x8*>(d) = v;
             if (bnr) {                                       // the expressions of bn_act_bwd_reduce_kernel on the rounded dy it would read
-                const bf16x8 vz = *reinterpret_cast<const bf16x8*>(p.bnr_z + dpix * p.bnr_ldz + cc);
+                const bf16x8 vz = zr[k];                     // row m of z: the destination is plain (dpix == m)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float zz = (float)vz[j];
@@ -161,7 +173,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
                 float t = 0.f;
 #pragma unroll
                 for (int r = 0; r < WM; ++r) t += red[((r * WN + wcol) * 2 + which) * 64 + (c & 63)];
-                if (n0 + c < p.N) atomicAdd((unsigned long long*)((which ? p.bnr_dbeta : p.bnr_dgamma) + rep + n0 + c), (unsigned long long)to_fix(t));
+                if (n0 + c < p.N) atomicAdd((unsigned long long*)((which ? p.bnr_dbeta : p.bnr_dgamma) + rep + n0 + c), (unsigned long long)to_fix_g(t));
             }
         }
     } else

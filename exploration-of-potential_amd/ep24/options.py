@@ -24,8 +24,9 @@ class PlanOptions:
     capture_side: bool = False         # cross-stream edges inside captured graphs (experimental; faulted on ROCm 7.2)
     fold_bn_eval: bool = True          # eval mode: BatchNorm folded into the conv (one launch per unit)
     conv_kernel_opts: int = 0          # bit 0: 3x3 stride-1 layers through the generic tiled kernel, bit 1: 8-byte epilogue stores
-    fuse_bn_reduce: bool = True        # a 3x3 stride-1 input gradient that is the only consumer of the unit below takes that unit's
-                                       # BatchNorm-backward sums in its epilogue (no reduce launch for it)
+    fuse_bn_reduce: bool = False       # a 3x3 stride-1 input gradient that is the only consumer of the unit below takes that unit's
+                                       # BatchNorm-backward sums in its epilogue (no reduce launch for it).  Measured slower in the step
+                                       # (899 against 912 images/s, same box): kept for A/B runs only
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane
     forward_lanes: int = 2

@@ -270,9 +270,9 @@ def test_dgrad_with_fused_bn_reduce(B, H, W, Cin, Cout, act):
     call("conv_dgrad_bnr_bf16", ptr(gy), Cout, ptr(wd), ptr(dx2), Cin, B, H, W, Cin, Cout, 3, ptr(z), Cin, ptr(save), ptr(save) + 4 * Cin,
          ptr(gamma), ptr(beta), ptr(sums2), ptr(sums2) + 8 * Cin, 2 * Cin, R, act, sp())
     assert torch.equal(dx, dx2)
-    a, b = sums.sum(0).cpu().double() / 2 ** 20, sums2.sum(0).cpu().double() / 2 ** 20
+    a, b = sums.sum(0).cpu().double() / 2 ** 36, sums2.sum(0).cpu().double() / 2 ** 36
     scale = a.abs().max().item()
-    assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-3, ((a - b).abs().max().item(), scale)
+    assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-6, ((a - b).abs().max().item(), scale)
     sums3 = torch.zeros_like(sums2)
     call("conv_dgrad_bnr_bf16", ptr(gy), Cout, ptr(wd), ptr(dx2), Cin, B, H, W, Cin, Cout, 3, ptr(z), Cin, ptr(save), ptr(save) + 4 * Cin,
          ptr(gamma), ptr(beta), ptr(sums3), ptr(sums3) + 8 * Cin, 2 * Cin, R, act, sp())

@@ -347,6 +347,39 @@ def test_replayed_steps_are_reproducible(graph_backward):
         assert err < 1e-4, (rep, err)
 
 
+def test_fused_bn_reduce_plan_matches_the_default_plan():
+    """PlanOptions(fuse_bn_reduce=True) (off by default: slower in the step) drops the BatchNorm-backward reduce
+    launch of every unit whose only consumer is a 3x3 stride-1 conv and takes the two sums in that conv's input-gradient epilogue:
+    same loss bit for bit, same gradients up to the order of fp32 partial sums."""
+    from ep24 import loss as eloss, train as etrain
+    from ep24.options import PlanOptions, set_options
+
+    def run(plan):
+        torch.manual_seed(0)
+        m = tiny_model()
+        m.head.initialize_biases(1e-2)
+        set_options(m, PlanOptions.parse(plan))
+        ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.0, momentum=0.9, batch=4, size=256)
+        ts.eng.images.copy_(synth.make_images(4, 256, seed=1).to(DEV))
+        ts.labels.copy_(synth.make_labels(4, 3, size=256, seed=1000).to(DEV))
+        loss = float(ts.step()[0])
+        torch.cuda.synchronize()
+        names = [n for n, _ in ts.eng.bwd]
+        return loss, ts.home.gflat.clone(), sum("dgrad_bnr" in n for n in names), sum("bwd_reduce" in n for n in names)
+
+    la, ga, fa, ra = run("fuse_bn_reduce=1")
+    lb, gb, fb, rb = run("")
+    assert fb == 0 and fa >= 10 and ra < rb                              # bottlenecks and the head chains really took the fused path
+    assert la == lb
+    # The head's sums agree to fp32 order (1e-7 relative, tools/bnr_debug.py --tiny --sums); every layer further down stores its
+    # dz in bf16, a last-bit difference flips a rounding here and there, and on this tiny model (256 values per channel at the
+    # coarsest level) that grows about threefold per layer to 1.7 % of the largest gradient at the stem - deterministic in either
+    # plan, bit-identical between two runs of the same plan
+    assert float((ga - gb).abs().max() / gb.abs().max()) < 5e-2 and cos(ga, gb) > 0.9995
+    la2, ga2, _, _ = run("fuse_bn_reduce=1")
+    assert la2 == la and torch.equal(ga2, ga)
+
+
 def test_full_size_step_properties():
     """BASELINE config 2 itself (YOLOX-l-24p, B = 20, 640x640) through size-independent properties: (1) two training
     runs from the same state are bitwise identical - loss AND every parameter after 3 steps (fixed-point BN sums,
@@ -371,8 +404,13 @@ def test_full_size_step_properties():
     lb, wb, gb, _ = run(0.001, 3)
     assert la == lb and torch.equal(wa, wb) and torch.equal(ga, gb), (la, lb)
     assert all(np.isfinite(la)) and la[0] != la[1]
-    assert bool(torch.isfinite(ga).all()) and float((ga != 0).float().mean()) > 0.99
-    l0, w0, _, m0 = run(0.0, 2)
+    assert bool(torch.isfinite(ga).all())
+    l0, w0, g0, m0 = run(0.0, 2)
+    # "reach every parameter" is a statement about the FIRST step's gradient (= the lr-0 run's): with these labels SimOTA matches six
+    # anchors of the stride-8 level at the initial weights and, two updates later, sometimes none - then that level's class and
+    # regression branches rightly get zero gradient (2.2 % of the parameters; which run of a pair of numerically different builds
+    # gets there first is chance, tools/bnr_debug.py)
+    assert bool(torch.isfinite(g0).all()) and float((g0 != 0).float().mean()) > 0.99
     torch.manual_seed(0)
     ref = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
     ref.head.initialize_biases(1e-2)
