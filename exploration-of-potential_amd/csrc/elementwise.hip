@@ -30,13 +30,16 @@ struct RowMap {        // thread -> (row slot, 8-channel group); rows strided by
 // Prologue: the block folds the fixed-point statistics into per-channel scale / shift in LDS (one channel per
 // thread, 2*reps loads).  Body: flat grid-stride over 16-byte chunks, consecutive lanes on consecutive
 // addresses whatever C is, 2 chunks in flight per lane.
-template <int ACT>
+template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_z, const long long* stats, int reps,
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, long* nbt, long* nbt2, float* save, bf16* y, long ld_y,
-                                                         const bf16* res, long ld_res, long M, int C, float eps,
+                                                         const bf16* res_, long ld_res, long M, int C, float eps,
                                                          float momentum) {
     constexpr int act = ACT;                     // compile-time: the SiLU instantiation carries no trace of the other modes
+    // ... nor of the residual: tested per element at run time, `res ? r : 0` was a scalar branch per output value (32 taken branches
+    // per loop iteration in the disassembly)
+    const bf16* res = RES ? res_ : nullptr;
     extern __shared__ float lds[];
     // rows of 8 constants padded to 9 floats: a thread reads the 8 of ITS channel group, and with a lane stride of 9 words the
     // 64 lanes of a wave fall on 64 different banks (an 8-word stride put lanes l and l + 8 on one bank: SQ_LDS_BANK_CONFLICT was
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
             }
             if (ok) {
                 v[k] = *reinterpret_cast<const bf16x8*>(z + mm[k] * ld_z + gg[k] * 8);
-                if (res) r[k] = *reinterpret_cast<const bf16x8*>(res + mm[k] * ld_res + gg[k] * 8);
+                if constexpr (RES) r[k] = *reinterpret_cast<const bf16x8*>(res + mm[k] * ld_res + gg[k] * 8);
             }
         }
 #pragma unroll
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
                 const float a_ = fixed_group ? rsc[j] : sc[gg[k] * 9 + j];
                 const float b_ = fixed_group ? rsh[j] : sh[gg[k] * 9 + j];
                 const float u = fmaf((float)v[k][j], a_, b_);
-                o[j] = (bf16)(act_fwd(u, act) + (res ? (float)r[k][j] : 0.f));
+                if constexpr (RES) o[j] = (bf16)(act_fwd(u, act) + (float)r[k][j]);
+                else o[j] = (bf16)act_fwd(u, act);
             }
             *reinterpret_cast<bf16x8*>(y + mm[k] * ld_y + gg[k] * 8) = o;
         }
@@ -1112,7 +1116,8 @@ extern "C" int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats
     // statistics for a 16 MB tensor.  4 = one batch of the body's unrolled loop.
     // (swept again in round 3 with the batched prologue, tools/bn_probe.py: 8 wins where C >= 1024 or the tensor is large and narrow)
     const int fw_per = (C >= 1024 || (C <= 128 && M * C >= (12L << 20))) ? 8 : 4;
-    auto kfn = act == 1 ? bn_act_fwd_kernel<1> : act == 2 ? bn_act_fwd_kernel<2> : act == 3 ? bn_act_fwd_kernel<3> : bn_act_fwd_kernel<0>;
+    auto kfn = residual ? (act == 1 ? bn_act_fwd_kernel<1, true> : act == 2 ? bn_act_fwd_kernel<2, true> : act == 3 ? bn_act_fwd_kernel<3, true> : bn_act_fwd_kernel<0, true>)
+                        : (act == 1 ? bn_act_fwd_kernel<1, false> : act == 2 ? bn_act_fwd_kernel<2, false> : act == 3 ? bn_act_fwd_kernel<3, false> : bn_act_fwd_kernel<0, false>);
     hipLaunchKernelGGL(kfn, dim3(flat_grid(M, C, fw_per)), dim3(256), 2 * (C + C / 8) * sizeof(float), S_, (const bf16*)z, ld_z, (const long long*)stats, reps, gamma,
                        beta, running_mean, running_var, (long*)num_batches, (long*)num_batches2, save, (bf16*)y, ld_y, (const bf16*)residual,
                        ld_res, M, C, eps, momentum);

@@ -9,6 +9,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
+python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_sustained.json 2> $OUT/bench_sustained.err
+echo "sustained bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
 echo "kernel trace done"
 EP24_LAYER_TABLE=$OUT/layer_table.txt python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/layer.log 2>&1
@@ -18,6 +20,7 @@ echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $OUT/pmc_w.log 2>&1
 echo "write pass done"
 python3 $R/tools/trace_gaps.py $OUT/kt/kt_kernel_trace.csv > $OUT/stream_gaps.txt 2>&1 || true
+python3 $R/tools/trace_step.py $OUT/kt/kt_kernel_trace.csv $OUT/step_timeline.csv > /dev/null 2>&1 || true
 # the trace CSVs are large: keep the stats and the counter files only
 rm -f $OUT/kt/kt_kernel_trace.csv $OUT/pmc_f/f_kernel_trace.csv $OUT/pmc_w/w_kernel_trace.csv
 ls -la $OUT $OUT/kt $OUT/pmc_f $OUT/pmc_w
