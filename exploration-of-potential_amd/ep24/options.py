@@ -31,6 +31,7 @@ class PlanOptions:
     parallel_forward: bool = True      # level-0 head chain on a second forward lane
     forward_lanes: int = 2
     bwd_cuts: Optional[Tuple[float, ...]] = None   # fractions of the backward list where its graph segments are cut (None: default)
+    chunked_update: bool = True        # the optimizer update in pieces on the weight-gradient lane, each as soon as its gradients are complete
 
     LAYOUT_FIELDS: ClassVar[tuple] = ("merge_csp", "merge_csp_shortcut", "merge_head")     # these decide the flat parameter layout
 

@@ -92,6 +92,7 @@ class TrainStep:
         opts = self.eng.options                          # per-model plan options (ep24.options.PlanOptions)
         self.parallel_forward = graph_backward and opts.parallel_forward
         self.forward_lanes = int(opts.forward_lanes)
+        self.chunked_update = bool(opts.chunked_update)
         self.world = 1 if reducer is None else reducer.world
         if reducer is not None:
             reducer.attach(self.home, eng)
@@ -206,6 +207,37 @@ class TrainStep:
             return None
         return cut, k
 
+    def _update_chunks(self, segs, k_early):
+        """The update in pieces on the weight-gradient lane (that lane idles behind the main one for half the backward pass, and the
+        update is pure HBM traffic - 1.5 GB per step with the EMA copy - that used to fall into the step's HBM-bound tail next to the
+        stem's weight gradient).  Returns ({segment index: (lo, hi)}, lo of the lowest piece): once the lane has run segment i, the
+        elements [lo, hi) of the flat buffers can be updated - every gradient in the range was written by an entry of a segment <= i
+        (both lanes: the lane starts a segment when the main lane has finished it) or is written by nobody (alignment padding).
+        Segments from ``k_early`` on stay with the two-part update at the end of the step."""
+        eng, n = self.eng, self.home.numel
+        min_chunk = max(n // 16, 4096)                            # at most 16 pieces: a launch per piece
+        wr = [[w for i in range(lo, hi) for w in eng.bwd_writes[i]] for lo, hi in segs]
+        done, pos = [], 0
+        for off, cnt in sorted(w for ws in wr for w in ws):       # regions nobody writes are complete from the start
+            if off > pos:
+                done.append((pos, off - pos))
+            pos = max(pos, off + cnt)
+        if pos < n:
+            done.append((pos, n - pos))
+        chunks, prev = {}, n
+        for k in range(k_early):
+            done += wr[k]
+            x = n
+            for off, cnt in sorted(done, key=lambda w: -(w[0] + w[1])):     # lowest x with [x, n) covered
+                if off + cnt < x:
+                    break
+                x = min(x, off)
+            x = (x + 3) // 4 * 4
+            if prev - x >= min_chunk:
+                chunks[k] = (x, prev)
+                prev = x
+        return chunks, prev
+
     def _segments(self):
         """Cut points of the backward list.  The weight-gradient lane runs one segment behind the main lane, so the last
         segments are short (what is left of the lane after the main lane has finished is exposed); with a reducer its
@@ -284,10 +316,20 @@ class TrainStep:
             # which starts a segment when the main lane has finished it - one event per segment, none inside a graph
             segs, ready = self._segments()
             self.g_bwd = []
-            for lo, hi in segs:
+            early = self._early_update_cut(segs)
+            chunks, upd_hi = self._update_chunks(segs, early[1]) if early is not None and self.chunked_update else ({}, None)
+            self.update_chunks = dict(chunks)
+            for si, (lo, hi) in enumerate(segs):
                 main, side = eng.lane_lists(lo, hi)
                 gm = capture(lambda: eng.run_lane(main)) if main else None
-                gs = capture(lambda: eng.run_lane(side)) if side else None
+                piece = chunks.get(si)
+
+                def side_work(side=side, piece=piece):
+                    eng.run_lane(side)
+                    if piece is not None:                     # the parameters whose gradients this segment has completed
+                        self._phase_update(piece[0], piece[1], False)
+
+                gs = capture(side_work) if side or piece is not None else None
                 par = eng.bwd_par_end is not None and hi <= eng.bwd_par_end      # a segment that runs on the side lane only
                 self.g_bwd.append((gm, gs, ready.get(hi), lo == eng.bwd_join, par))
             if self._side is None:
@@ -295,10 +337,11 @@ class TrainStep:
             # Two-part update: when the main lane is through, the weight-gradient lane still has its last segment to run (the
             # stem's 2 M-pixel weight gradient and the final reduce, ~0.25 ms during which the main lane used to wait, then 0.18 ms
             # of SGD).  The parameters above the cut are updated in that window, the few below it afterwards.
-            early = self._early_update_cut(segs)
             if early is not None:
                 cut, k = early
-                self.g_upd_early = (capture(lambda: self._phase_update(cut, None, False)), capture(lambda: self._phase_update(0, cut, True)), k)
+                self.g_upd_early = (capture(lambda: self._phase_update(cut, upd_hi, False)), capture(lambda: self._phase_update(0, cut, True)), k)
+                if chunks:                                    # what is left if the early part does not run
+                    self.g_upd = capture(lambda: self._phase_update(0, upd_hi, True))
         self.graphs = True
 
     def step(self, images=None, labels=None):

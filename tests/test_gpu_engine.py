@@ -347,6 +347,33 @@ def test_replayed_steps_are_reproducible(graph_backward):
         assert err < 1e-4, (rep, err)
 
 
+def test_chunked_update_equals_the_single_update():
+    """PlanOptions.chunked_update (default): the optimizer update runs in pieces on the weight-gradient lane, each as soon as the
+    gradients of its range are complete.  The update is elementwise, so three steps with lr > 0 must leave every parameter and
+    every momentum value bit-identical to the plan that updates at the end of the step."""
+    from ep24 import loss as eloss, train as etrain
+    from ep24.options import PlanOptions, set_options
+
+    def run(plan):
+        torch.manual_seed(0)
+        m = tiny_model()
+        m.head.initialize_biases(1e-2)
+        set_options(m, PlanOptions.parse(plan))
+        ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.01, momentum=0.9, batch=4, size=256)
+        ts.eng.images.copy_(synth.make_images(4, 256, seed=1).to(DEV))
+        ts.labels.copy_(synth.make_labels(4, 3, size=256, seed=1000).to(DEV))
+        losses = [float(ts.step()[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, ts.home.flat.clone(), ts.home.mflat.clone(), ts
+
+    la, wa, ma, tsa = run("")
+    lb, wb, mb, tsb = run("chunked_update=0")
+    assert len(tsa.update_chunks) >= 3 and not tsb.update_chunks            # the default plan really updated in pieces
+    pieces = sorted(tsa.update_chunks.values())
+    assert all(a[1] == b[0] for a, b in zip(pieces[:-1], pieces[1:])) and pieces[-1][1] == tsa.home.numel   # contiguous, up to the end
+    assert la == lb and torch.equal(wa, wb) and torch.equal(ma, mb)
+
+
 def test_fused_bn_reduce_plan_matches_the_default_plan():
     """PlanOptions(fuse_bn_reduce=True) (off by default: slower in the step) drops the BatchNorm-backward reduce
     launch of every unit whose only consumer is a 3x3 stride-1 conv and takes the two sums in that conv's input-gradient epilogue:
