@@ -52,7 +52,17 @@ for k in ("bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"):
     n, ms, by = other[k]
     print("| %s | %d | %.2f | %.2f | %.2f | - | %.2fx |" % (k, n, ms, by / 1e9, by / HBM * 1e3, ms / (by / HBM * 1e3)))
     tot[0] += n; tot[1] += ms; tot[2] += by / HBM * 1e3
-rest_n = sum(v[0] for k, v in other.items() if not k.startswith("bn_act"))
-rest_ms = sum(v[1] for k, v in other.items() if not k.startswith("bn_act"))
-print("| everything else in the table (wgrad_reduce, stem_pack, SPP, upsample, decode, copies) | %d | %.2f | - | - | - | - |" % (rest_n, rest_ms))
+STEM = ("focus_pack", "stem_conv_fwd_bf16", "stem_conv_wgrad_slab_bf16")
+st_n = sum(other[k][0] for k in STEM if k in other)
+st_ms = sum(other[k][1] for k in STEM if k in other)
+if st_n:
+    # per pixel of the space-to-depth grid: pack 48 B in + 32 B out, conv 32 B in + 128 B out, weight gradient 128 + 32 B in
+    Mst = [int(l.split()[1]) * int(l.split()[2]) * int(l.split()[3]) // 4 for l in open(sys.argv[1]) if l.startswith("focus_pack")][0]
+    by = 400.0 * Mst
+    print("| Focus stem (focus_pack + gathering conv + weight gradient; no im2col buffer) | %d | %.2f | %.2f | %.2f | 0.06 | %.2fx |" % (
+        st_n, st_ms, by / 1e9, by / HBM * 1e3, st_ms / (by / HBM * 1e3)))
+    tot[0] += st_n; tot[1] += st_ms; tot[2] += by / HBM * 1e3
+rest_n = sum(v[0] for k, v in other.items() if not k.startswith("bn_act") and k not in STEM)
+rest_ms = sum(v[1] for k, v in other.items() if not k.startswith("bn_act") and k not in STEM)
+print("| everything else in the table (wgrad_reduce, SPP, upsample, decode, copies) | %d | %.2f | - | - | - | - |" % (rest_n, rest_ms))
 print("| sum | %d | %.2f | | %.2f (sum of the larger bounds) | | %.2fx |" % (tot[0] + rest_n, tot[1] + rest_ms, tot[2], (tot[1]) / tot[2]))
