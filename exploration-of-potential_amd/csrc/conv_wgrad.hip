@@ -317,7 +317,10 @@ long wgrad_splits(const WgradArgs& a) {
     const int tiles = ep24_cdiv(a.Cin, TCI) * ep24_cdiv(a.Cout, TCO) * a.T;
     const bool small = TCO == 64 && TCI == 64, big = TCO == 128 && TCI == 128;
     const long slots = 256L * (small ? 4 : (big ? 2 : 3));
-    const long min_steps = small ? 16 : 8;
+    // small tile: 12 steps where the layer has several tiles (80x80x128 1x1: 33 -> 27 us with its reduce launch, a workgroup is one
+    // memory latency per step and more of them hide it), 16 where it has one (160x160x64: the extra slabs cost the reduce launch
+    // more than the lane gains) - tools/wgrad_splits_ab.py, round 3
+    const long min_steps = small ? (tiles >= 4 ? 12 : 16) : 8;
     const long steps = (a.M + 63) / 64;
     long splits = slots / tiles;
     if (splits > steps / min_steps) splits = steps / min_steps;

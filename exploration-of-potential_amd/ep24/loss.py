@@ -108,9 +108,10 @@ class Loss_Function(nn.Module):
     ``(loss, reg_w*loss_iou[24], loss_obj, loss_cls, loss_l1, num_fg/num_gts, draw_content)``; ``loss_l1`` is the python
     float 0.0 unless ``use_l1`` is set (then a 0-dim tensor, losses.py:304-309, and the head must have produced
     ``origin_preds``).
-    Differences, all about avoiding host syncs: position 5 is a 0-dim device tensor (float()-able) instead of
-    a python float, and draw_content[0:3] (matched cx / cy / radii, dynamic length) are only materialised when
-    ``self.draw`` is True.
+    With ``self.draw`` True (the default, as the reference runs) position 5 is a python float as in the reference
+    (losses.py:349-357) and draw_content[0:3] (matched cx / cy / radii, dynamic length) are materialised - both cost a host
+    sync.  With ``self.draw`` False (what ep24.train's captured step uses) nothing synchronises: position 5 is a 0-dim device
+    tensor (float()-able) and draw_content[0:3] are None.
     """
 
     def __init__(self, num_classes):
@@ -176,7 +177,10 @@ class Loss_Function(nn.Module):
             draw = [None, None, None]
         draw += [reg_w, obj_w, cls_w]
         loss_l1 = res[56] if self.use_l1 else 0.0
-        return res[0], res[1:25], res[25], res[26], loss_l1, res[55] / torch.clamp(res[28], min=1.0), draw
+        ratio = res[55] / torch.clamp(res[28], min=1.0)                       # num_fg / max(num_gts, 1)
+        if self.draw:
+            ratio = float(ratio)                                              # the reference's python float (the mask above has synchronised already)
+        return res[0], res[1:25], res[25], res[26], loss_l1, ratio, draw
 
     # --- reference helper kept for API parity (losses.py:360-442): assignment of one image of the last call
     def assignment_of(self, labels, b):
