@@ -257,12 +257,10 @@ class TrainStep:
         join = self.eng.bwd_join
         if join is not None:                                   # head levels 1, 2 run on the side lane up to here
             cuts.add(join)
-            # ... and the trunk's first graph is short: the host is held at the join until the side lane's chains are through (a graph
-            # launch into a waiting stream), and what it submits next starts only when its submission is complete - ~0.15 ms for a
-            # 60-kernel graph (profiles/r03_stream_gaps.txt), a few microseconds for this one; its ~0.15 ms of kernels cover the
-            # submission of the rest of the segment (with two launches the rest still arrived 0.09 ms late)
-            if self.eng.options.bwd_cuts is None and join + 8 < n:
-                cuts.add(join + 8)
+            # (Cutting the trunk's first graph short - 2 / 8 launches, or a chain of 2, 4, 8, 16 - so that its submission would not
+            # delay the first kernel behind the join was tried: the main lane's wait there stayed 0.12 - 0.17 ms in two of three
+            # traces and the step time did not move, 923 against 925 images/s same box.  The wait is the host waking up, not the
+            # size of what it submits.)
             if self.eng.bwd_par_end:
                 cuts.add(self.eng.bwd_par_end)
         cuts = sorted(cuts)
