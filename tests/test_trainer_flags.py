@@ -89,3 +89,51 @@ def test_plan_options_are_per_model_objects():
         open(os.path.join(ROOT, "exploration-of-potential_amd", "ep24", "train.py")).read() + \
         open(os.path.join(ROOT, "exploration-of-potential_amd", "ep24", "dp.py")).read()
     assert "os.environ" not in src                                     # no environment switches on the product path
+
+
+def test_update_chunks_only_cover_completed_gradients():
+    """ep24.train.TrainStep._update_chunks (pure host logic): a piece of the flat buffer may be updated after weight-gradient-lane
+    segment k only if every element in it was written by an entry of a segment <= k or is written by nobody (alignment padding),
+    and the pieces tile a suffix of the buffer without gaps or overlaps."""
+    import random
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
+    from ep24.train import TrainStep
+    rnd = random.Random(7)
+    for trial in range(20):
+        # parameters in execution order: backward writes them from the tail, a few entries late (the slab reduce of a later segment)
+        sizes = [rnd.choice([16, 64, 256, 1000, 4096, 30000]) for _ in range(rnd.randint(12, 60))]
+        offs, n = [], 0
+        for sz in sizes:
+            offs.append(n)
+            n += (sz + 3) // 4 * 4 + rnd.choice([0, 0, 4])            # some padding nobody writes
+        order = list(range(len(sizes)))[::-1]
+        for _ in range(len(order) // 4):                              # a few gradients complete later than their neighbours
+            i = rnd.randrange(len(order) - 1)
+            order[i], order[i + 1] = order[i + 1], order[i]
+        nseg = rnd.randint(4, 9)
+        per = (len(order) + nseg - 1) // nseg
+        bwd_writes, segs = [], []
+        for s in range(nseg):
+            lo = len(bwd_writes)
+            for j in order[s * per:(s + 1) * per]:
+                bwd_writes.append([(offs[j], sizes[j])])
+                bwd_writes.append([])                                 # entries that write no parameter gradient
+            segs.append((lo, len(bwd_writes)))
+        segs = [sg for sg in segs if sg[1] > sg[0]]
+        fake = types.SimpleNamespace(eng=types.SimpleNamespace(bwd_writes=bwd_writes), home=types.SimpleNamespace(numel=n))
+        k_early = len(segs) - 1
+        chunks, lo_all = TrainStep._update_chunks(fake, segs, k_early)
+        written_by = {}
+        for k, (lo, hi) in enumerate(segs):
+            for i in range(lo, hi):
+                for off, cnt in bwd_writes[i]:
+                    for e in range(off, off + cnt):
+                        written_by[e] = k
+        prev = n
+        for k in sorted(chunks):
+            lo, hi = chunks[k]
+            assert hi == prev and lo < hi and lo % 4 == 0, (trial, chunks)
+            assert all(written_by.get(e, -1) <= k for e in range(lo, hi)), (trial, k, chunks[k])
+            prev = lo
+        assert prev == lo_all
