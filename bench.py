@@ -67,6 +67,10 @@ def pmc_traffic(prefix):
     return (round(b / n) if n else None), "%s @ %s" % (os.path.basename(files[-1]), d.get("git_head", "unstamped"))
 
 
+# device-kernel name prefixes behind each member of the dominant family in a rocprofv3 kernel list
+REPLAY_PREFIX = {"conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_"}
+
+
 def replayed_ms_per_step(prefix):
     """ms per step the kernels starting with `prefix` take in the graph-replayed, two-lane run: from the committed rocprofv3
     --kernel-trace --stats summary (profiles/*_kernel_meta.json, stamped with the commit it was taken at)."""
@@ -253,7 +257,8 @@ def main():
     ap.add_argument("--depth", type=float, default=1.0, help="non-default: depth multiplier")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
     ap.add_argument("--plan", default="", help="non-default: per-model plan options for A/B runs, e.g. 'merge_csp=0,forward_lanes=3' (ep24.options.PlanOptions.parse)")
-    ap.add_argument("--dp-wire", default="bf16", choices=["bf16", "fp32"], help="wire format of the gradient all-reduce at --gpus > 1 (bf16: half the xGMI bytes)")
+    ap.add_argument("--dp-wire", default="fp32", choices=["bf16", "fp32"], help="wire format of the gradient all-reduce at --gpus > 1: fp32 as the reference's DDP and "
+                    "the trainer's default; bf16 (half the xGMI bytes) is the opt-in of train_24p.py --dp-wire bf16")
     ap.add_argument("--bucket-mb", type=int, default=32, help="all-reduce bucket size at --gpus > 1")
     a = ap.parse_args()
 
@@ -290,6 +295,17 @@ def main():
     solo = world == 1 and os.environ.get("EP24_NCCL_SOLO") == "1"
     if solo:
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=dev)
+
+    # Which device every rank drives, gathered over the process group itself: the record that the collective backend saw
+    # `world` DISTINCT GPUs (core/launch.py:118-124 of the reference pins one device per rank the same way).
+    pr = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local, "device_index": dev.index, "name": pr.name,
+          "uuid": str(getattr(pr, "uuid", "")), "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+          "pid": os.getpid()}
+    ranks_info = [me]
+    if dist.is_initialized():
+        ranks_info = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_info, me)
 
     torch.manual_seed(0)                                     # identical replicas on every rank
     model = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width, backbone_type=a.backbone), enn.YOLOXHead(80, a.width))
@@ -373,10 +389,12 @@ def main():
         dom = " + ".join(members)
         f = {key: sum(fam[k][key] for k in members) for key in ("flops", "ms", "launches", "bytes")}
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        tr = [(pmc_traffic(k), fam[k]["launches"]) for k in members]
+        tr = [(pmc_traffic(REPLAY_PREFIX[k]), fam[k]["launches"]) for k in members]
         traffic = round(sum(t[0] * n for (t, n) in tr if t[0]) / max(sum(n for (t, n) in tr if t[0]), 1)) if any(t[0] for t, _ in tr) else None
         traffic_src = tr[0][0][1]
-        reps = [replayed_ms_per_step(k) for k in members]
+        # the family's time in the replayed run: a member's launches may run as several device kernels (the six stride-2 input
+        # gradients of igemm_dma_kernel's share are igemm_dma_multi_kernel launches)
+        reps = [replayed_ms_per_step(REPLAY_PREFIX[k]) for k in members]
         default_cfg = (a.batch, a.size, a.gts, a.backbone, a.width, a.depth) == (20, 640, 10, "darknet", 1.0, 1.0) and not (a.fisheye or a.long_run or a.no_graph or a.plan)
         rep_ms = sum(r[0] for r in reps) if (default_cfg and all(r[0] for r in reps)) else None     # the committed profile is of the default workload
         rep_src = reps[0][1]
@@ -392,6 +410,11 @@ def main():
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
                        **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),
+            "ranks": ranks_info,
+            "distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                             "distinct_devices": len({(r["uuid"], r["pci_bus_id"]) for r in ranks_info}),
+                             "dp_wire": a.dp_wire, "bucket_mb": a.bucket_mb, "rehearsal_on_one_device": rehearse}
+                            if dist.is_initialized() else None),
             "step_mfma_frac": round(ips / world * {"darknet": TRAIN_GFLOP_PER_IMAGE, "resnet": 290.7, "densenet": 388.0, "vgg": 1196.0}[a.backbone] * (a.size / 640.0) ** 2 / 1e3
                                     / MFMA_BF16_PEAK_TFLOPS, 4),      # swaps: 3 x 2 x 48.45 / 64.67 GMAC
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,

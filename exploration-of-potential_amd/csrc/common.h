@@ -75,9 +75,21 @@ __device__ __forceinline__ float from_fix(long long v) { return (float)((double)
 // The two sums of BatchNorm BACKWARD (du and du * zhat over the pixels) are sums of GRADIENTS: in the class branch of the head a
 // workgroup's partial sum is 1e-5 .. 1e-4, i.e. 10 .. 100 units of 2^-20 - round 3 found channels whose gamma / beta gradient had
 // rounded to exactly 0 that way (0.8 % of the channels of the head's first class conv).  They use 2^-36: resolution 1.5e-11,
-// |sum| < 1.3e8 (gradient sums over 2 M pixels stay many orders below that).
-__device__ __forceinline__ long long to_fix_g(float v) { return (long long)__float2ll_rn(v * 68719476736.0f); }
-__device__ __forceinline__ float from_fix_g(long long v) { return (float)((double)v * (1.0 / 68719476736.0)); }
+// valid range |partial sum| < 2^17 (gradient sums over 2 M pixels stay many orders below that).
+// A diverged gradient must stay visible: __float2ll_rn turns NaN into 0 and 2^-36 wraps at |v| >= 2^27, so a partial
+// sum that is NaN or beyond 2^17 (no real workgroup sum comes within orders of magnitude of it) is clamped to the marker 2^53; up to
+// 511 such adds stay below 2^62, and from_fix_g answers NaN for any fold that reached the marker - gamma / beta gradients go NaN
+// instead of silently zero or wrapped.
+#define EP24_FIXG_MARK (1LL << 53)
+__device__ __forceinline__ long long to_fix_g(float v) {
+    const float a = fabsf(v);
+    if (!(a < 131072.0f)) return EP24_FIXG_MARK;                 // also NaN (the comparison is false)
+    return (long long)__float2ll_rn(v * 68719476736.0f);
+}
+__device__ __forceinline__ float from_fix_g(long long v) {
+    if (v >= EP24_FIXG_MARK || v <= -EP24_FIXG_MARK) return __builtin_nanf("");
+    return (float)((double)v * (1.0 / 68719476736.0));
+}
 
 // exact x / d for 0 <= x < 2^31 with one mulhi + shift (divisor known at launch time)
 struct FastDiv {

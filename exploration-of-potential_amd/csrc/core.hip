@@ -11,4 +11,4 @@ void ep24_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ep24_last_error(void) { return g_err; }
-extern "C" int ep24_abi_version(void) { return 1; }
+extern "C" int ep24_abi_version(void) { return EP24_ABI_VERSION; }

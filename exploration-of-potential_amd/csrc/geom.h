@@ -41,6 +41,27 @@ __device__ __forceinline__ float ray_giou(float r1 /*gt*/, float r2 /*pred*/, fl
     return iou - top / cs;
 }
 
+// The intersection area alone: what IOUloss.circle_inter (losses.py:23-78) and utils.boxes.circle_inter (boxes.py:102-163) return
+// next to the centre distance.  Same expressions and case order as ray_giou's first half.
+__device__ __forceinline__ float ray_inter(float r1 /*gt*/, float r2 /*pred*/, float d) {
+    const float pi = EP24_PI_F;
+    const float rmin = fminf(r1, r2), rmax = fmaxf(r1, r2);
+    const float rmin2 = rmin * rmin, rmax2 = rmax * rmax, d2 = d * d;
+    const bool contained = fabsf(r1 - r2) >= d;
+    const bool disjoint = d >= r1 + r2;
+    float inter = contained ? pi * rmin2 : 0.0f;
+    if (disjoint) inter = 0.0f;
+    if (!(contained || disjoint)) {
+        float c1 = (rmin2 + d2 - rmax2) / (2.0f * rmin * d + 1e-8f);
+        float c2 = (rmax2 + d2 - rmin2) / (2.0f * rmax * d + 1e-8f);
+        c1 = fminf(fmaxf(c1, -0.99f), 0.99f);
+        c2 = fminf(fmaxf(c2, -0.99f), 0.99f);
+        const float a1 = acosf(c1), a2 = acosf(c2);
+        inter = a1 * rmin2 + a2 * rmax2 - rmin * d * sinf(a1);
+    }
+    return inter;
+}
+
 // d(1 - giou)/d(r2), d(1 - giou)/d(d): analytic form of what autograd derives from the expressions above
 // (clip passes gradient on the closed interval, min/max ties route to the GT side, selects by mask).
 __device__ __forceinline__ void ray_loss_grad(float r1, float r2, float d, float& g_r2, float& g_d) {

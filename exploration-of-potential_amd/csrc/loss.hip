@@ -269,6 +269,24 @@ __global__ __launch_bounds__(256) void matched_fwd_kernel(const float* pred26, c
     loss24[i] = 1.0f - ray_giou(sqrtf(vx * vx + vy * vy), q[2 + k], d);
 }
 
+// circle_inter of the reference as it stands: intersection areas and centre distances of (gt row, pred row) pairs over the 24 rays.
+// pairwise = 0: row i of the one against row i of the other (IOUloss.circle_inter, losses.py:23-78); pairwise = 1: every gt row
+// against every pred row, pair index g * P + p (utils.boxes.circle_inter, boxes.py:102-163: repeat_interleave on gt, repeat on pred).
+// One thread per (pair, ray): consecutive lanes on consecutive addresses of both outputs.
+__global__ __launch_bounds__(256) void circle_lens_kernel(const float* gt_cx, const float* gt_cy, const float* gt_r, const float* pd_cx,
+                                                          const float* pd_cy, const float* pd_r, float* res, float* dist, long pairs,
+                                                          int P, int pairwise) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs * 24) return;
+    const long pr = i / 24;
+    const int k = (int)(i - pr * 24);
+    const long g = pairwise ? pr / P : pr, p = pairwise ? pr - g * P : pr;
+    const float ddx = gt_cx[g] - pd_cx[p], ddy = gt_cy[g] - pd_cy[p];
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    res[i] = ray_inter(gt_r[g * 24 + k], pd_r[p * 24 + k], d);
+    dist[i] = d;
+}
+
 __global__ __launch_bounds__(256) void matched_bwd_kernel(const float* pred26, const float* target50, const float* dloss24,
                                                           float* dpred26, int N) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -351,5 +369,18 @@ extern "C" int ep24_circle_matched_bwd(const float* pred26, const float* target5
     hipLaunchKernelGGL(matched_bwd_kernel, dim3(ep24_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred26, target50, dloss24,
                        dpred26, N);
     EP24_LAUNCH_CHECK("ep24_circle_matched_bwd");
+    return EP24_OK;
+}
+
+extern "C" int ep24_circle_lens(const float* gt_cx, const float* gt_cy, const float* gt_r, const float* pd_cx, const float* pd_cy,
+                                const float* pd_r, float* res_inter, float* dist, int G, int P, int pairwise, void* stream) {
+    EP24_REQUIRE(G >= 0 && P >= 0 && (pairwise || G == P), EP24_E_ARG, "circle_lens: the matched form needs as many gt rows as pred rows (%d, %d)", G, P);
+    const long pairs = pairwise ? (long)G * P : G;
+    if (pairs == 0) return EP24_OK;             // the reference's placeholder path: nothing to compute
+    EP24_REQUIRE(gt_cx && gt_cy && gt_r && pd_cx && pd_cy && pd_r && res_inter && dist, EP24_E_ARG, "circle_lens: null pointer");
+    EP24_REQUIRE(pairs * 24 < (1L << 31) * 256, EP24_E_UNSUPPORTED, "circle_lens: %ld pairs are beyond one launch", pairs);
+    hipLaunchKernelGGL(circle_lens_kernel, dim3((unsigned)ep24_cdiv(pairs * 24, 256)), dim3(256), 0, (hipStream_t)stream, gt_cx, gt_cy,
+                       gt_r, pd_cx, pd_cy, pd_r, res_inter, dist, pairs, P, pairwise);
+    EP24_LAUNCH_CHECK("ep24_circle_lens");
     return EP24_OK;
 }

@@ -61,6 +61,12 @@ class _Lib:
             f.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
             f.argtypes = [_to_ctype(t) for t, _ in params]
             self.fn[name] = f
+        # a library built from another header must not be called into (arguments would be mis-passed silently)
+        m = re.search(r"#define\s+EP24_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read())
+        want, got = (int(m.group(1)) if m else None), self.fn["ep24_abi_version"]()
+        if want is None or got != want:
+            raise Ep24Error("ep24: %s reports ABI version %s, include/ep24.h declares %s - rebuild the library "
+                            "(make -C exploration-of-potential_amd/csrc)" % (LIB_PATH, got, want))
 
     def last_error(self):
         return self.fn["ep24_last_error"]().decode()

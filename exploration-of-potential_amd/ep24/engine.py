@@ -482,6 +482,15 @@ def exec_order(model, opts=None):
         yield from resnet_unused(bb)
 
 
+def _drop_rate_of(layers):
+    """The Dropout2d probability of a run of DenseLayers (darknet.py:569-577: ``nn.Dropout2d(self.drop_rate)``).  One buffer of keep
+    factors is drawn per plan with one probability, so the layers that drop at all must agree; 0 when none does."""
+    rates = sorted({float(l.drop_rate) for l in layers if float(l.drop_rate) > 0})
+    if len(rates) > 1:
+        raise _lib.Ep24Error("ep24: the DenseLayers of one plan must share their drop_rate (got %s)" % rates)
+    return rates[0] if rates else 0.0
+
+
 def param_home(model):
     """The flat parameter buffers a module lives in.  A module of a tree that has already been moved into flat buffers
     (a YOLOPAFPN inside a YOLOX that has run) shares its owner's home; a module on its own gets one of its own."""
@@ -526,7 +535,9 @@ class Engine:
         self.bwd_tail_cut = None                 # index behind the reduce launch that precedes the last unit of backward
         self.bwd_join = None                     # index of the first backward entry that needs the parallel head levels joined
         self.bwd_par_end = None                  # entries [0, bwd_par_end) all run on the side lane
-        self.options = get_options(model)        # per-model plan options (ep24.options): no process-wide switches
+        # per-model plan options (ep24.options): no process-wide switches.  A submodule of a model that already lives in flat
+        # buffers (SubEngine on model.backbone, a CSPLayer ...) has no options of its own: it inherits the home's, i.e. the root's
+        self.options = model.__dict__.get("_ep24_options") or getattr(self.home, "options", None) or get_options(model)
         if self.options.layout() != self.home.options.layout():
             raise _lib.Ep24Error("ep24: this model's parameters are laid out for %r; the merge options cannot change afterwards" % (self.home.options,))
         self.parallel_head = self.options.parallel_head and not self.f32
@@ -1151,7 +1162,7 @@ class Engine:
         x = self.unit(None, rows, stem=True, conv=bb.stem[0].conv, bn=bb.stem[0].bn, act=2)
         n_layers = sum(len(b.denseblock) for b in (bb.D1, bb.D2, bb.D3, bb.D4))
         self.drop_keep = torch.ones(n_layers, B, 32, dtype=torch.float32, device=self.dev)
-        self.drop_p = 0.3
+        self.drop_p = _drop_rate_of([l for b in (bb.D1, bb.D2, bb.D3, bb.D4) for l in b.denseblock])
         H, W = IH // 4, IW // 4
         base, cat, feats = 0, None, []
         for bi, (blk, tr) in enumerate(((bb.D1, bb.T1), (bb.D2, bb.T2), (bb.D3, bb.T3), (bb.D4, None))):
@@ -1596,7 +1607,7 @@ class SubEngine(Engine):
         self.inputs = [head]                                  # replaces the stand-alone input buffer: the input IS the head slot
         bstats = self._stats_slot(cat.C)
         self.drop_keep = torch.ones(max(nl, 1), self.B, 32, dtype=torch.float32, device=self.dev)
-        self.drop_p = 0.3
+        self.drop_p = _drop_rate_of(list(mod.denseblock) if kind == "denseblock" else [mod] if kind == "denselayer" else [])
         self._f("colstats", head.ptr(), head.ld, bstats, cat.C, head.M, C0, ev=False)
         if kind == "denseblock":                              # x -> cat(x, layer_0(x), layer_1(cat), ...)
             if not any(l.drop_rate > 0 for l in mod.denseblock):

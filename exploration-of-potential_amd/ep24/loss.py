@@ -215,6 +215,10 @@ class IOUloss(nn.Module):
         super().__init__()
         self.reduction = reduction
 
+    def circle_inter(self, c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r):
+        """Method form of the reference (losses.py:23-78): row i against row i -> (res_inter [N,24], dist [N,24])."""
+        return _circle_lens(c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r, pairwise=False)
+
     def forward(self, pred, target):
         if pred.shape[1] != 26 or target.shape[1] != 50:
             raise IndexError
@@ -228,6 +232,33 @@ class IOUloss(nn.Module):
         predc = pred.contiguous()
         loss24 = _MatchedFn.apply(predc, target.contiguous())
         return loss24, [predc[:, 0], predc[:, 1], predc[:, 2:]]
+
+
+def _circle_lens(c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r, pairwise):
+    """One launch of ``ep24_circle_lens``.  Neither form of the reference carries gradient users (both callers wrap the
+    result in their own arithmetic on detached geometry only inside ``no_grad`` or re-derive it), so this is a plain forward."""
+    _lib.require_gpu()
+    _check_cuda(pd_r, "pd_r")
+    dev = pd_r.device
+    f = lambda t, *shape: t.detach().to(device=dev, dtype=torch.float32).reshape(*shape).contiguous()
+    G, P = gt_r.shape[0], pd_r.shape[0]
+    if gt_r.shape[1:] != (24,) or pd_r.shape[1:] != (24,):
+        raise IndexError
+    if not pairwise and G != P:
+        raise RuntimeError("circle_inter: the matched form pairs row i with row i (%d gt rows, %d pred rows)" % (G, P))
+    n = G * P if pairwise else G
+    res = torch.zeros(n, 24, dtype=torch.float32, device=dev)
+    dist = torch.zeros(n, 24, dtype=torch.float32, device=dev)
+    if n:
+        call("circle_lens", ptr(f(c_gtx, G)), ptr(f(c_gty, G)), ptr(f(gt_r, G, 24)), ptr(f(c_pdx, P)), ptr(f(c_pdy, P)),
+             ptr(f(pd_r, P, 24)), ptr(res), ptr(dist), G, P, int(pairwise), stream_ptr())
+    return res, dist
+
+
+def circle_inter(c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r):
+    """Drop-in for the module-level ``utils.boxes.circle_inter`` (yolox_24p/utils/boxes.py:102-163): every gt row against
+    every pred row -> (res_inter [G*P,24], dist [G*P,24]), pair index g*P + p."""
+    return _circle_lens(c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r, pairwise=True)
 
 
 def bboxes_iou(bboxes_a, bboxes_b, imgs=None):

@@ -59,15 +59,18 @@ class Exp(BaseExp):
         self.model.head.initialize_biases(1e-2)
         return self.model
 
-    def get_data_loader(self, batch_size):
-        from datasets import SyntheticDataset
+    def get_data_loader(self, batch_size, raw_u8=False):
+        from datasets import SyntheticDataset, raw_collate
         import torch
         import os
-        self.dataset = SyntheticDataset(self.synthetic_len, tuple(self.input_size), self.synthetic_gts, self.num_classes)
+        self.dataset = SyntheticDataset(self.synthetic_len, tuple(self.input_size), self.synthetic_gts, self.num_classes, raw=raw_u8)
         world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
         sampler = None
         if world > 1:                                     # every rank walks its own shard of the epoch
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
+        if raw_u8:                                        # lists of uint8 images + label rows: letterboxed on the GPU by the prefetcher
+            return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, drop_last=True, sampler=sampler,
+                                               collate_fn=raw_collate)
         return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True,
                                            sampler=sampler)
 

@@ -58,7 +58,9 @@ class Trainer:
         if not args.synthetic:
             print("note: the COCO24P loader of the reference reads hard-coded paths (datasets/coco24p.py:19-20) and is out of "
                   "scope; the synthetic source with the same label layout is used (--synthetic)")
-        self.train_loader = exp.get_data_loader(args.batch_size)
+        if args.raw_u8 and args.no_prefetch:
+            raise SystemExit("train_24p.py: --raw-u8 batches are letterboxed by the prefetcher (drop --no-prefetch)")
+        self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=True) if args.raw_u8 else exp.get_data_loader(args.batch_size)
         self.loss_func = Loss_Function(exp.num_classes)
         self.loss_func.draw = False
 
@@ -70,7 +72,8 @@ class Trainer:
         reducer = None
         if self.world > 1:
             torch.distributed.init_process_group("nccl", device_id=self.device)
-            reducer = dp.GradReducer()
+            # fp32 buckets like the reference's DDP (core/trainer.py:163) unless asked: --dp-wire bf16 halves the xGMI bytes
+            reducer = dp.GradReducer(comm_dtype=torch.bfloat16 if args.dp_wire == "bf16" else None)
         torch.manual_seed(0)                              # identical replicas on every rank (made explicit by the reducer's broadcast)
         model = exp.get_model()
         model.to(self.device)
@@ -80,7 +83,7 @@ class Trainer:
         # -c / --resume / -e: the reference's parser accepts them and its trainer never reads them (train_24p.py:180-211); here
         # they load what save_ckpt wrote.  The checkpoint goes in AFTER get_model() (which re-applies the bias prior on every
         # call, exp/yolox_base.py:70-71) so the loaded predictor biases survive; --resume also restores momentum and epoch.
-        self.start_epoch, ck = 0, None
+        self.start_epoch, ck, resumed_step = 0, None, None
         if args.ckpt:
             from utils import load_ckpt
             ck = torch.load(args.ckpt, map_location="cpu")
@@ -89,11 +92,15 @@ class Trainer:
                 if "optimizer" in ck:
                     self.optimizer.load_state_dict(ck["optimizer"])
                 self.start_epoch = int(ck.get("start_epoch", 0))
+                if "global_step" in ck:                   # written by this trainer: exact also when --steps cut an epoch short
+                    resumed_step = int(ck["global_step"])
         if args.start_epoch is not None:
-            self.start_epoch = args.start_epoch
+            self.start_epoch, resumed_step = args.start_epoch, None
         # progress = epoch * max_iter + iter, as the reference's schedulers / loggers count it: a resumed run continues the
         # learning-rate schedule and the TensorBoard axis where the checkpoint stopped instead of restarting the warm-up
-        self.current_step = self.resumed_step(self.start_epoch, self.max_iter)
+        self.current_step = self.resumed_step(self.start_epoch, self.max_iter) if resumed_step is None else resumed_step
+        # iterations of the start epoch that the checkpointed run had already done (a run cut short by --steps inside an epoch)
+        skip_iters = min(max(self.current_step - self.start_epoch * self.max_iter, 0), self.max_iter)
         self.tblogger = SummaryWriter(self.file_name) if (SummaryWriter and self.rank == 0) else None
         self.lr_scheduler = exp.get_lr_scheduler(args.learn_rate, self.max_iter) if args.sched else None
         self.ema_model = None
@@ -110,6 +117,8 @@ class Trainer:
         print("Training start... (rank %d/%d, %s)" % (self.rank, self.world, "captured step" if step_fn else "eager API"))
         done = False
         self.epoch = self.start_epoch
+        self.epoch_complete = False
+        tp_t0 = tp_seen = None                            # --throughput-json: a synchronised window over the run's last steps
         for epoch in range(self.start_epoch, self.max_epoch):
             self.epoch = epoch
             model.train()
@@ -120,7 +129,14 @@ class Trainer:
                 model.head.use_l1 = self.loss_func.use_l1 = True
                 if step_fn is not None:
                     step_fn.set_use_l1(True)
-            for images, labels in self.batches():
+            self.epoch_complete = False
+            for it, (images, labels) in enumerate(self.batches()):
+                if epoch == self.start_epoch and it + skip_iters >= self.max_iter:
+                    self.epoch_complete = True            # that was the rest of a resumed partial epoch
+                    break
+                if args.throughput_json and args.steps and self.run_steps == args.steps - args.throughput_window:
+                    torch.cuda.synchronize()
+                    tp_t0, tp_seen = time.perf_counter(), 0
                 self.current_step += 1
                 self.run_steps += 1
                 if self.lr_scheduler is not None:
@@ -146,15 +162,33 @@ class Trainer:
                         self.ema_model.update(model)
                     res = self.loss_func._ws.result
                 seen += images.shape[0]
+                if tp_t0 is not None:
+                    tp_seen += images.shape[0]
                 if self.current_step % args.log_interval == 0:
                     self.TB_data(res, seen * self.world / (time.time() - t0))
                 if args.steps and self.run_steps >= args.steps:
                     done = True
                     break
+            else:
+                self.epoch_complete = True
+            if self.current_step >= (epoch + 1) * self.max_iter:
+                self.epoch_complete = True                # --steps ended the run exactly on the epoch's last iteration
             if self.rank == 0:
                 self.save_ckpt("last_epoch")
             if done:
                 break
+        if tp_t0 is not None:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - tp_t0
+            if self.rank == 0:
+                import json
+                rec = {"images_per_s": round(tp_seen * self.world / dt, 2), "ms_per_step": round(dt / max(args.throughput_window, 1) * 1e3, 3),
+                       "window_steps": args.throughput_window, "run_steps": self.run_steps, "batch_per_gpu": args.batch_size, "world": self.world,
+                       "input_size": list(self.input_size), "prefetch": not args.no_prefetch, "raw_u8": bool(args.raw_u8),
+                       "captured_step": step_fn is not None, "log_interval": args.log_interval, "exp_file": args.exp_file}
+                with open(args.throughput_json, "w") as fh:
+                    json.dump(rec, fh)
+                print("throughput %s" % json.dumps(rec))
         if self.world > 1:
             torch.distributed.destroy_process_group()
 
@@ -164,11 +198,12 @@ class Trainer:
         return int(start_epoch) * int(max_iter)
 
     def batches(self):
-        """One epoch of (images, labels) on the device.  Default: the loader's tensors, uploaded on the compute stream (what the
-        reference's loop does, train_24p.py:86-88).  ``--prefetch``: the reference's ``DataPrefetcher`` (data/data_prefetcher.py:16-51)
-        in its ep24 form - the next batch is uploaded (and, for raw uint8 batches, letterboxed by ``TrainTransform.batch``) on a side
-        stream while the current step runs."""
-        if not self.args.prefetch:
+        """One epoch of (images, labels) on the device.  Default (round 4): the reference's ``DataPrefetcher``
+        (data/data_prefetcher.py:16-51) in its ep24 form - the next batch is uploaded (and, for ``--raw-u8`` batches, letterboxed by
+        ``TrainTransform.batch``) on a side stream while the current step runs.  ``--no-prefetch``: the loader's
+        tensors uploaded on the compute stream, what the reference's 24p loop does (train_24p.py:86-88) - measured at BASELINE
+        config 2 it leaves the GPU idle for the 98 MB upload of every step (profiles/r04_trainer.json)."""
+        if self.args.no_prefetch:
             for images, labels, _info, _ids in self.train_loader:
                 yield images.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True)
             return
@@ -199,7 +234,10 @@ class Trainer:
         self.tblogger.add_scalar("Weights/cls_w", r[54], s)
 
     def save_ckpt(self, ckpt_name, update_best_ckpt=False):
-        state = {"start_epoch": self.epoch + 1, "model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        # the reference's three keys (train_24p.py:144-148) plus the global step: "start_epoch" is the first epoch that is NOT complete
+        # (a run cut short by --steps inside an epoch resumes that epoch at the step it stopped, not at the next epoch's first step)
+        state = {"start_epoch": self.epoch + (1 if self.epoch_complete else 0), "model": self.model.state_dict(),
+                 "optimizer": self.optimizer.state_dict(), "global_step": self.current_step}
         if self.ema_model is not None:
             state["ema_model"], state["ema_updates"] = self.ema_model.ema.state_dict(), self.ema_model.updates
         save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name)
@@ -220,19 +258,29 @@ def make_parser():
     p.add_argument("--device", default="cuda", type=str, help="cuda or cuda:N (the ep24 path has no CPU fallback: cpu is refused)")
     p.add_argument("--synthetic", action="store_true", help="synthetic images / labels with the reference's layout (the only source here)")
     p.add_argument("--output-dir", default=None, type=str, help="overrides exp.output_dir")
+    p.add_argument("--synthetic-len", default=0, type=int, help="images per synthetic epoch (overrides exp.synthetic_len; a checkpoint is written per epoch)")
     p.add_argument("--steps", default=0, type=int, help="stop after this many steps (0 = run all epochs)")
     p.add_argument("--log-interval", default=10, type=int)
     p.add_argument("--no-graph", action="store_true", help="reference-style eager loop instead of the captured step")
     p.add_argument("--sched", action="store_true", help="follow exp.get_lr_scheduler (yoloxwarmcos) instead of a constant rate")
     p.add_argument("--ema", action="store_true", help="keep a ModelEMA copy of the model (saved as ema_model)")
     p.add_argument("--l1", action="store_true", help="switch use_l1 on from epoch exp.L1_epoch")
-    p.add_argument("--prefetch", action="store_true", help="upload (and letterbox) the next batch on a side stream: ep24.input.DataPrefetcher")
+    p.add_argument("--prefetch", action="store_true", help="(default since round 4; kept for old command lines) upload the next batch on a side stream: ep24.input.DataPrefetcher")
+    p.add_argument("--no-prefetch", action="store_true", help="the reference's loop: upload every batch on the compute stream (train_24p.py:86-88)")
+    p.add_argument("--raw-u8", action="store_true", help="the synthetic source hands over uint8 HWC images + normalised label rows; letterbox and label "
+                   "scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")
+    p.add_argument("--dp-wire", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce under torch.distributed.run")
+    p.add_argument("--throughput-json", default=None, type=str, help="with --steps N: write images/s over the run's last --throughput-window steps "
+                   "(synchronised at both ends) to this file")
+    p.add_argument("--throughput-window", default=200, type=int)
     return p
 
 
 def main(exp, args):
     if args.output_dir:
         exp.output_dir = args.output_dir
+    if args.synthetic_len:
+        exp.synthetic_len = args.synthetic_len
     trainer = Trainer(exp, args)
     trainer.train()
     return trainer

@@ -1,4 +1,4 @@
-"""The slice of the reference's ``utils`` package the 24p path uses: ``bboxes_iou`` (utils/boxes.py:166-243),
+"""The slice of the reference's ``utils`` package the 24p path uses: ``bboxes_iou`` / ``circle_inter`` (utils/boxes.py:102-243),
 ``postprocess`` (utils/boxes.py:29-99),
 ``save_checkpoint`` / ``load_ckpt`` (utils/checkpoint.py:11-43), the learning-rate schedules
 (utils/lr_scheduler.py:9-205) and ``ModelEMA`` (utils/ema.py:22-60)."""
@@ -7,7 +7,8 @@ import shutil
 
 import _path  # noqa: F401
 import torch
-from ep24.loss import bboxes_iou  # noqa: F401
+from ep24.loss import bboxes_iou, circle_inter  # noqa: F401   (utils/boxes.py:102-243)
+from . import boxes  # noqa: F401
 from ep24.infer import postprocess  # noqa: F401      (utils/boxes.py:29-99)
 from ep24.schedule import LRScheduler  # noqa: F401   (utils/lr_scheduler.py:9-92)
 from ep24.ema import ModelEMA, is_parallel  # noqa: F401   (utils/ema.py:13-60)

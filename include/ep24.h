@@ -33,6 +33,10 @@ extern "C" {
 #define EP24_NUM_SUMS 32         /* per-step loss accumulators, see ep24_loss_* */
 
 const char* ep24_last_error(void);
+/* Bumped whenever an exported signature or the meaning of an argument changes.  2 (round 4): ep24_bn_act_bwd_reduce / _apply /
+ * _apply_acc and ep24_pack_weights_batched took new arguments in round 3, ep24_conv_set_patch went away, the BatchNorm-backward sums
+ * became 2^-36 fixed point, ep24_circle_lens is new.  A caller built against another version must not call in. */
+#define EP24_ABI_VERSION 2
 int ep24_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -130,7 +134,8 @@ int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats
                     second BatchNorm module when two units share the launch (merged CSP / head pairs), else NULL */
 
 /* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
- * 2^-20 fixed-point int64 like the forward statistics, kept in `reps` replicas (replica r of either sum 2*C*r elements behind
+ * 2^-36 fixed-point int64 (NOT the forward statistics' 2^-20: gradient sums of the head are 1e-5 .. 1e-4 per workgroup; a workgroup's
+ * partial sum must stay below 2^17 in magnitude - one that does not, or is NaN, makes the channel's folded sum NaN), kept in `reps` replicas (replica r of either sum 2*C*r elements behind
  * the pointer, i.e. [reps][2][C] when dbeta = dgamma + C; a workgroup adds to replica blockIdx % reps): the memory-side atomic
  * units serialise the adds to one address, and with a single copy every workgroup of the launch hit the same 2 C addresses. */
 int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
@@ -309,6 +314,13 @@ int ep24_circle_pairwise(const float* gt50, const float* pred26, float* out, int
 int ep24_circle_matched_fwd(const float* pred26, const float* target50, float* loss24, int N, void* stream);
 int ep24_circle_matched_bwd(const float* pred26, const float* target50, const float* dloss24, float* dpred26, int N,
                             void* stream);
+/* circle_inter itself (IOUloss.circle_inter, losses.py:23-78; module-level utils.boxes.circle_inter, boxes.py:102-163):
+ * intersection area of the k-th gt circle (radius gt_r[g][k]) with the k-th predicted circle and the centre distance,
+ * res_inter / dist [pairs][24].  pairwise = 0: G == P rows matched one to one (the method); pairwise = 1: every gt row against
+ * every pred row, pair index g * P + p (the module function's repeat_interleave / repeat order).  Case order as the reference:
+ * |r1 - r2| >= d -> pi * rmin^2; d >= r1 + r2 -> 0 (overrides); else the lens with cosines clipped to +-0.99. */
+int ep24_circle_lens(const float* gt_cx, const float* gt_cy, const float* gt_r, const float* pd_cx, const float* pd_cy,
+                     const float* pd_r, float* res_inter, float* dist, int G, int P, int pairwise, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a11  optimizer (yolox_24p/exp/yolox_base.py:120-124: SGD momentum 0.9 nesterov, no decay)

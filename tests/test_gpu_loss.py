@@ -44,6 +44,55 @@ def test_pairwise_edge_cases(L):
     assert L.bboxes_iou(torch.zeros(3, 50, device=DEV), torch.zeros(0, 26, device=DEV)).shape == (3, 0)
 
 
+def test_circle_inter_vs_golden_g1_and_oracle(L, golden):
+    """circle_inter on the product surface: the method IOUloss.circle_inter (losses.py:23-78, matched rows) against
+    the reference's own output G1 - all three branches, branch by branch, and the empty input - and the module-level pairwise
+    form (utils/boxes.py:102-163) against the oracle's broadcast restatement in the reference's g-major pair order.
+    dist is a correctly rounded sqrt of uncontracted products: bit-exact.  The lens adds device acosf / sinf (a few ulp on
+    terms up to ten times the result): 3e-5 relative, 1e-3 px^2 absolute on areas of 1e2 .. 7e4 px^2."""
+    from oracle import geometry
+    z = golden("g1_circle_inter")
+    arg = [t(z[k]).to(DEV) for k in ("gt_cx", "gt_cy", "gt_r", "pd_cx", "pd_cy", "pd_r")]
+    iou = L.IOUloss("none")
+    res, dist = iou.circle_inter(*arg)
+    want_res, want_dist = t(z["res_inter"]), t(z["dist"])
+    assert torch.equal(dist.cpu(), want_dist)
+    gt_r, pd_r = t(z["gt_r"]), t(z["pd_r"])
+    contained = (gt_r - pd_r).abs() >= want_dist
+    disjoint = want_dist >= gt_r + pd_r
+    lens = ~(contained | disjoint)
+    assert contained.any() and disjoint.any() and lens.any()
+    got = res.cpu()
+    assert torch.equal(got[disjoint], want_res[disjoint]) and float(got[disjoint].abs().max()) == 0.0
+    assert torch.equal(got[contained & ~disjoint], want_res[contained & ~disjoint])       # pi * rmin^2: one rounded product
+    torch.testing.assert_close(got[lens], want_res[lens], rtol=3e-5, atol=1e-3)
+    # empty input: the reference returns the zero placeholder and the (empty) distances
+    e_res, e_dist = iou.circle_inter(*[a[:0] for a in arg])
+    assert list(e_res.shape) == list(z["empty_res_shape"]) and list(e_dist.shape) == list(z["empty_dist_shape"])
+    with pytest.raises(L._lib.Ep24Error):
+        iou.circle_inter(*[a.cpu() for a in arg])                                         # no CPU fallback
+
+    # pairwise form, also through the drop-in package path utils.boxes.circle_inter
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(L.__file__), "..", "yolox_24p"))
+    import utils
+    assert utils.boxes.circle_inter is L.circle_inter and utils.circle_inter is L.circle_inter
+    g = torch.Generator().manual_seed(5)
+    G, P = 7, 333
+    gx, gy = torch.rand(G, generator=g) * 600, torch.rand(G, generator=g) * 600
+    px, py = torch.rand(P, generator=g) * 600, torch.rand(P, generator=g) * 600
+    gr, pr_ = torch.rand(G, 24, generator=g) * 150 + 5, torch.rand(P, 24, generator=g) * 150 + 5
+    px[:3], py[:3] = gx[:3], gy[:3]                                                       # coincident centres: d = 0
+    res, dist = L.circle_inter(gx.to(DEV), gy.to(DEV), gr.to(DEV), px.to(DEV), py.to(DEV), pr_.to(DEV))
+    assert res.shape == (G * P, 24) and dist.shape == (G * P, 24)
+    ex = lambda a, n: a.reshape(G, 1, n).expand(G, P, n).reshape(G * P, n)                # repeat_interleave(P, 0)
+    ep = lambda a, n: a.reshape(1, P, n).expand(G, P, n).reshape(G * P, n)                # repeat(G, 1)
+    want_res, want_dist = geometry.matched_lens(ex(gx, 1)[:, 0], ex(gy, 1)[:, 0], ex(gr, 24), ep(px, 1)[:, 0], ep(py, 1)[:, 0], ep(pr_, 24))
+    assert torch.equal(dist.cpu(), want_dist)
+    torch.testing.assert_close(res.cpu(), want_res, rtol=3e-5, atol=1e-3)
+    assert L.circle_inter(gx[:0].to(DEV), gy[:0].to(DEV), gr[:0].to(DEV), px.to(DEV), py.to(DEV), pr_.to(DEV))[0].shape == (0, 24)
+
+
 def test_matched_loss_and_grad_vs_golden(L, golden):
     z = golden("g3_matched")
     pred = t(z["pred"]).to(DEV).requires_grad_(True)

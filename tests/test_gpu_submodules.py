@@ -272,6 +272,54 @@ def test_densenet_pieces_forward_vs_oracle():
         om.EMULATE_BF16 = False
 
 
+def test_dense_layer_on_its_own_draws_with_its_own_drop_rate():
+    """DenseLayer(..., drop_rate=p) run stand-alone in training mode is nn.Dropout2d(p) over its 32 new channels (darknet.py:569-577):
+    whole channels are zero with probability p and the kept ones carry 1 / (1 - p).  (the sub-plan used 0.3 for every p.)"""
+    from ep24 import nn as enn
+    lay = enn.DenseLayer(64, drop_rate=0.5)
+    synth.fill_state(lay, seed=2)
+    _set_bn(lay)
+    lay.to(DEV).train()
+    x = torch.randn(64, 64, 8, 8, generator=torch.Generator().manual_seed(1)).to(DEV)
+    lay(x)
+    eng = next(iter(lay.__dict__["_ep24_sub"].values()))
+    assert eng.drop_p == 0.5
+    keep = eng.drop_keep                                     # [1, B, 32] factors of the forward that just ran
+    vals = set(keep.unique().tolist())
+    assert vals <= {0.0, 2.0} and len(vals) == 2, vals
+    frac = float((keep == 0).float().mean())
+    assert 0.4 < frac < 0.6, frac                            # 2048 draws: 0.5 +- 5 sigma = 0.055
+    with pytest.raises(Exception):
+        blk = enn.DenseBlock(2, 64, drop_rate=0.3)
+        blk.denseblock[1].drop_rate = 0.5                    # one buffer of keep factors per plan: the layers must agree
+        blk.to(DEV).train()(x)
+
+
+def test_submodule_inherits_the_plan_options_of_its_model():
+    """A model built with non-default LAYOUT options (merge_csp off): its submodules have no options of their own and must take the
+    root's from the shared parameter home instead of the defaults (this raised "the merge options cannot change")."""
+    from ep24 import nn as enn
+    from ep24.options import PlanOptions, set_options
+    torch.manual_seed(2)
+    m = enn.YOLOX(enn.YOLOPAFPN(0.33, 0.25), enn.YOLOXHead(80, 0.25))
+    set_options(m, PlanOptions(merge_csp=False, merge_head=False))
+    m.to(DEV)
+    x = synth.make_images(2, (128, 160), seed=3).to(DEV)
+    with torch.no_grad():
+        whole = m(x, train=True)[3].clone()
+        pan = m.backbone(x)                                  # sub-plans of a model whose home is laid out unmerged
+        dark = m.backbone.backbone(x)
+        parts = m.head(pan, train=True)[3]
+        csp = m.backbone.C3_p4
+        y = csp(torch.randn(2, csp.conv1.conv.in_channels, 8, 10, device=DEV))
+        # with the merges off a CSP layer's conv1 is a unit of its own again: BaseConv.forward on it works
+        y1 = csp.conv1(torch.randn(2, csp.conv1.conv.in_channels, 8, 10, device=DEV))
+    assert torch.equal(whole, parts) and sorted(dark) == ["dark3", "dark4", "dark5"]
+    assert torch.isfinite(y).all() and y.shape[1] == csp.conv3.conv.out_channels and y1.shape[1] == csp.conv1.conv.out_channels
+    sub = next(iter(m.backbone.__dict__["_ep24_sub"].values()))
+    assert sub.options.merge_csp is False and sub.options is m.__dict__["_ep24_options"]
+
+
 @pytest.mark.parametrize("kind", ["resnet", "vgg", "densenet"])
 def test_swapped_backbone_forward_vs_oracle(kind):
     """resnet50() / vgg19() / densenet121() on their own: images -> {"dark3", "dark4", "dark5"}, against the oracle backbone with

@@ -33,7 +33,9 @@ def test_trainer_runs_and_checkpoint_round_trips(tmp_path):
     assert all(v == v and 0 < v < 1e4 for v in losses), losses
     path = os.path.join(out, "yolox_24p", "last_epoch_ckpt.pth")
     ck = torch.load(path, map_location="cpu")
-    assert set(ck) == {"start_epoch", "model", "optimizer"} and ck["start_epoch"] == 1
+    # the reference's three keys + the global step; 3 of the epoch's 16 iterations ran, so epoch 0 is NOT complete (the
+    # old "start_epoch = epoch + 1" made a resumed run skip the 13 iterations that never ran)
+    assert set(ck) == {"start_epoch", "model", "optimizer", "global_step"} and ck["start_epoch"] == 0 and ck["global_step"] == 3
     keys = set(ck["model"])
     # state-dict names of the reference tree: checkpoints are interchangeable
     for k in ("backbone.backbone.stem.conv.conv.weight", "backbone.backbone.dark3.1.m.0.conv2.bn.running_var",
@@ -52,13 +54,18 @@ def test_trainer_runs_and_checkpoint_round_trips(tmp_path):
     # resume: parameters (incl. the predictor biases) and momentum come back; zero further steps would change nothing,
     # so run with lr 0 for one step and compare what is saved
     out2 = str(tmp_path / "run2")
-    # (--prefetch: the batch comes through ep24.input.DataPrefetcher on its side stream)
-    env_log = _train(out2, "--steps", "1", "-c", path, "--resume", "-l", "0.0", "--prefetch")
-    # the global step continues at start_epoch * max_iter (64 synthetic images / batch 4 = 16 iterations per epoch), as the
-    # reference counts progress (epoch * max_iter + iter): the schedule and the TensorBoard axis do not restart
-    assert "step 17 " in env_log, env_log[-2000:]
+    # (--raw-u8: the batch is uint8 HWC images + normalised label rows, letterboxed on the GPU by ep24.input.DataPrefetcher on its
+    # side stream; the prefetcher is the default loop since round 4)
+    env_log = _train(out2, "--steps", "1", "-c", path, "--resume", "-l", "0.0", "--raw-u8", "--throughput-json", str(tmp_path / "tp.json"),
+                     "--throughput-window", "1")
+    # the global step continues where the checkpoint stopped (epoch * max_iter + iter, as the reference counts progress): the
+    # schedule and the TensorBoard axis neither restart nor jump to the next epoch
+    assert "step 4 " in env_log, env_log[-2000:]
     ck2 = torch.load(os.path.join(out2, "yolox_24p", "last_epoch_ckpt.pth"), map_location="cpu")
-    assert ck2["start_epoch"] == 2                                  # resumed at epoch 1
+    assert ck2["start_epoch"] == 0 and ck2["global_step"] == 4      # still inside epoch 0
+    import json
+    tp = json.load(open(str(tmp_path / "tp.json")))
+    assert tp["window_steps"] == 1 and tp["images_per_s"] > 0 and tp["raw_u8"] and tp["prefetch"]
     for k, v in ck["model"].items():
         if "running_" in k or "num_batches" in k:
             continue

@@ -69,6 +69,36 @@ def test_resume_continues_the_lr_schedule():
         sys.path.remove(Y24)
 
 
+def test_raw_u8_synthetic_source_matches_the_ready_made_one():
+    """--raw-u8: the synthetic items as a decoder would hand them over (uint8 HWC, label rows normalised by width / height).  Through the
+    oracle's TrainTransform restatement (data_augment.py:138-174) they give the label table of the ready-made source to fp32 rounding and
+    the same image up to the uint8 truncation; a long synthetic epoch repeats 64 distinct items instead of holding 5 MB per index."""
+    sys.path.insert(0, Y24)
+    try:
+        import numpy as np
+        import torch
+        from datasets import SyntheticDataset, raw_collate
+        from oracle import input as oin
+        ready, raw = SyntheticDataset(200, 64, 3), SyntheticDataset(200, 64, 3, raw=True)
+        for idx in (0, 5, 63, 64 + 5):
+            img, lab, hw, ident = ready[idx]
+            rimg, rows, rhw, rident = raw[idx]
+            assert ident == rident == idx and tuple(hw) == tuple(rhw) == (64, 64)
+            assert rimg.dtype == torch.uint8 and tuple(rimg.shape) == (64, 64, 3) and rows.shape == (3, 51)
+            out_img, out_lab = oin.train_transform(rimg.numpy(), rows.copy(), (64, 64))
+            assert np.array_equal(out_img, img.to(torch.uint8).float().numpy())
+            np.testing.assert_allclose(out_lab, lab.numpy(), rtol=1e-6, atol=1e-4)
+        assert torch.equal(raw[5][0], raw[64 + 5][0]) and len(raw._cache) <= 64
+        ims, rws, _, ids = raw_collate([raw[0], raw[1]])
+        assert len(ims) == 2 and ids == [0, 1] and rws[1].shape == (3, 51)
+        mod = __import__("train_24p")
+        a = mod.make_parser().parse_args(["--raw-u8", "--dp-wire", "bf16", "--no-prefetch", "--synthetic-len", "640"])
+        assert a.raw_u8 and a.dp_wire == "bf16" and a.no_prefetch and a.synthetic_len == 640
+        assert mod.make_parser().parse_args([]).dp_wire == "fp32"
+    finally:
+        sys.path.remove(Y24)
+
+
 def test_plan_options_are_per_model_objects():
     """What changes kernels or plans is an immutable option object attached to a model (ep24.options), not a process global."""
     sys.path.insert(0, os.path.join(ROOT, "exploration-of-potential_amd"))
