@@ -68,7 +68,7 @@ def pmc_traffic(prefix):
 
 
 # device-kernel name prefixes behind each member of the dominant family in a rocprofv3 kernel list
-REPLAY_PREFIX = {"conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_"}
+REPLAY_PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_"}
 
 
 def replayed_ms_per_step(prefix):
@@ -156,7 +156,11 @@ def instrumented_step(ts):
             return "igemm_dma_kernel"                      # kernel_opts bit 0: the tiled kernel was asked for
         kid = fn["ep24_conv_kernel_for"](0 if fwd else 1, B, H, W, Cin, Cout, k, s, int(bool(fwd and args[5] != 0)), int(bool(fwd and args[8] is not None)))
         assert kid >= 0, (name, _lib.lib().last_error())
-        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel")[kid]
+        if kid == 3 and ((name.endswith("_ex") and (args[-1] & 8)) or name.startswith("conv_dgrad_bnr")):
+            kid = 1                                        # kernel_opts bit 3 / the fused BatchNorm sums: the 8-wave halo-patch kernel
+        if name.endswith("_ex") and (args[-1] & 16) and kid == 0:      # kernel_opts bit 4: the ring without a patch where the shape fits it
+            kid = fn["ep24_conv_kernel_for_ex"](0 if fwd else 1, B, H, W, Cin, Cout, k, s, int(bool(fwd and args[5] != 0)), int(bool(fwd and args[8] is not None)), args[-1])
+        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel", "conv_ring_kernel", "conv_ring_generic_kernel")[kid]
 
     convs = [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]
     for (name, fl, e0, e1, by), (_, args) in zip(rec, convs):
@@ -382,10 +386,11 @@ def main():
     if rank == 0:
         fam = instrumented_step(ts)
         # The dominant kernel family: the conv forward / input-gradient gather-GEMM behind ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16.
-        # Since round 2 it has two tilings - conv_patch_kernel (3x3 stride-1 layers with >= 200 tiles of 256 x 128) and
-        # igemm_dma_kernel (everything else) - over the same 183 launches that were one kernel in round 1; the line carries the
+        # Since round 2 it has two tilings - the halo-patch form (3x3 stride-1 layers with >= 200 tiles of 256 x 128: conv_ring_kernel
+        # since round 4, conv_patch_kernel before and on request) and igemm_dma_kernel (everything else) - over the same 183 launches
+        # that were one kernel in round 1; the line carries the
         # family and, under "members", each kernel by itself (their average launch durations are what rocprofv3 reports).
-        members = [k for k in ("conv_patch_kernel", "igemm_dma_kernel") if k in fam]
+        members = [k for k in ("conv_ring_kernel", "conv_ring_generic_kernel", "conv_patch_kernel", "igemm_dma_kernel") if k in fam]
         dom = " + ".join(members)
         f = {key: sum(fam[k][key] for k in members) for key in ("flops", "ms", "launches", "bytes")}
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12

@@ -16,6 +16,10 @@ namespace {
 
 // kernel_opts of the _ex entry points (include/ep24.h): per call, no process-wide state
 constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_PER_CLASS = 4;     // bit 2: a stride-2 input gradient as one launch per parity class
+constexpr int KOPT_GRING = 16;             // bit 4: layers of the tiled kernel that fill the chip with 256 x 128 tiles run in the ring without a
+                                           // patch instead (conv_ring.hip; measured SLOWER on every layer of YOLOX-l at B = 20,
+                                           // profiles/r04_ring_generic_ab.txt: an A/B option, off by default)
+constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the MFMA-bound layers: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
@@ -477,7 +481,7 @@ int check_extents(const IgemmArgs& a) {
     return EP24_OK;
 }
 
-// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming)
+// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming, 3 loader / consumer ring)
 void prepare(IgemmArgs& a, int kernel_opts) {
     a.narrow_epi = (kernel_opts & KOPT_NARROW_EPI) ? 1 : 0;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
@@ -533,10 +537,26 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer &&
         !(kernel_opts & KOPT_TILED)) {
         int prc = EP24_OK;
+        if (!(kernel_opts & KOPT_PATCH8) && launch_ring(a, stream, dry, &prc)) {
+            if (dry) { *kernel_id = 3; return EP24_OK; }
+            if (prc) return prc;
+            EP24_LAUNCH_CHECK("ep24_conv_ring");
+            return EP24_OK;
+        }
         if (launch_patch(a, stream, dry, &prc)) {
             if (dry) { *kernel_id = 1; return EP24_OK; }
             if (prc) return prc;
             EP24_LAUNCH_CHECK("ep24_conv_patch");
+            return EP24_OK;
+        }
+    }
+    // A/B option: everything else that fills the chip with 256 x 128 tiles and stores bf16 in the ring without a patch
+    if (!out_f32 && (kernel_opts & KOPT_GRING) && !(kernel_opts & KOPT_TILED) && a.T * ep24_cdiv(a.K, BK) >= 4) {
+        int grc = EP24_OK;
+        if (launch_ring_generic(a, stream, dry, &grc)) {
+            if (dry) { *kernel_id = 4; return EP24_OK; }
+            if (grc) return grc;
+            EP24_LAUNCH_CHECK("ep24_conv_ring_generic");
             return EP24_OK;
         }
     }
@@ -747,12 +767,23 @@ extern "C" int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const voi
     return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, 0, B, H, W, Cin, Cout_k, ksize, 1, 0, stream, false, nullptr, &b);
 }
 
+static int kernel_for_impl(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias, int kernel_opts);
+
 extern "C" int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias) {
+    return kernel_for_impl(dgrad, B, H, W, Cin, Cout, ksize, stride, y_f32, has_bias, 0);
+}
+
+extern "C" int ep24_conv_kernel_for_ex(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias,
+                                       int kernel_opts) {
+    return kernel_for_impl(dgrad, B, H, W, Cin, Cout, ksize, stride, y_f32, has_bias, kernel_opts);
+}
+
+static int kernel_for_impl(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias, int kernel_opts) {
     int id = -1;
     const float* fake_bias = has_bias ? reinterpret_cast<const float*>(16) : nullptr;      // only tested for null
     const int c8 = (Cout + 7) / 8 * 8;
-    const int rc = dgrad ? conv_dgrad_impl(nullptr, c8, nullptr, nullptr, (Cin + 3) / 4 * 4, 0, B, H, W, Cin, c8, ksize, stride, 0, nullptr, true, &id)
+    const int rc = dgrad ? conv_dgrad_impl(nullptr, c8, nullptr, nullptr, (Cin + 3) / 4 * 4, 0, B, H, W, Cin, c8, ksize, stride, kernel_opts, nullptr, true, &id)
                          : conv_fwd_impl(nullptr, Cin, nullptr, nullptr, y_f32 ? Cout : (Cout + 3) / 4 * 4, y_f32, 0, 0, fake_bias, nullptr, 1, B, H, W, Cin, Cout,
-                                         ksize, stride, 0, nullptr, true, &id);
+                                         ksize, stride, kernel_opts, nullptr, true, &id);
     return rc ? rc : id;
 }

@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // channels of a pixel (8-byte packed bf16 stores).  Does: bias, BN batch statistics (2^-20 fixed-point int64 atomics, one
 // per channel per workgroup), bf16 / fp32 stores with optional accumulate, and for MODE 2 the inference form
 // y = act(acc + bias) + residual.
-template <int BN, bool OUT_F32, int MT, int MODE = 0, int NWV = 4>
+template <int BN, bool OUT_F32, int MT, int MODE = 0, int NWV = 4, bool BNR = true>      // BNR false: no fused BatchNorm-backward sums in this instantiation
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
     constexpr int WN = BN / 64, WM = NWV / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
         // fused BatchNorm-backward sums: the z rows of this wave's part of the tile are requested NOW, all of them (clamped indices, no
         // conditional load), so they arrive while the accumulators go through LDS - fetched inside the store loop they were eight
         // serial round trips per workgroup (+24 us per launch: more than the reduce kernel they replace)
-        const bool bnr = MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
+        const bool bnr = BNR && MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
         bf16x8 zr[MT * 2];
         if (bnr) {
             const int zc = n0 + wn * 64 + (lane & 7) * 8;
@@ -260,5 +260,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 // LDS budget (the caller then uses the generic tiled kernel).
 // dry = true only answers whether the shape is taken; *rc receives the error code of a failed launch set-up.
 bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
+// conv_ring.hip: the same layers as 4 consumer + 4 loader waves over an LDS ring with FULL / FREE counters (round 4); same contract.
+bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
+// ... and the ring without a patch, for any other gather-GEMM with bf16 output that fills the chip with 256 x 128 tiles.
+bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 
 }  // namespace ep24_igemm

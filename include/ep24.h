@@ -57,14 +57,22 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
 
 /* The same two entry points with an explicit kernel choice PER CALL (A/B timing, tests that compare two kernels on one shape;
  * there is no process-wide switch).  kernel_opts bit 0: the 3x3 stride-1 layers run in the generic tiled kernel instead of the
- * halo-patch kernel (csrc/conv_patch.hip); bit 1: the tiled kernels store their output 8 bytes per lane instead of staging
- * it for 16-byte stores; bit 2: a stride-2 input gradient runs as one launch per parity class (four) instead of one merged launch.
- * kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
+ * halo-patch kernels; bit 1: the tiled kernels store their output 8 bytes per lane instead of staging it for 16-byte stores;
+ * bit 2: a stride-2 input gradient runs as one launch per parity class (four) instead of one merged launch; bit 3: the 3x3
+ * stride-1 layers run in the 8-wave lockstep halo-patch kernel (csrc/conv_patch.hip) instead of the loader / consumer ring
+ * (csrc/conv_ring.hip, the default since round 4); bit 4: layers of the tiled kernel that fill the chip with 256 x 128 tiles run in
+ * the ring without a patch (measured slower on every layer of YOLOX-l at B = 20: off by default).  kernel_opts = 0 is exactly
+ * ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                           int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream);
 int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate,
                             int B, int H, int W, int Cin, int Cout_k, int ksize, int stride, int kernel_opts, void* stream);
+
+/* The 3x3 stride-1 layers run as a loader / consumer ring (csrc/conv_ring.hip: 4 MFMA waves fed by 4 LDS-DMA waves through counters
+ * in LDS).  Every wait on a counter is a bounded spin; this returns how many of them have given up since the library was loaded
+ * (reads a device word: synchronises with the device).  Always 0 unless the hand-off protocol is broken - tests assert it. */
+int ep24_conv_ring_timeouts(void);
 
 /* Input gradient of a stride-1 conv that is the ONLY consumer of the conv-BN-act unit below it (a Bottleneck's 3x3 over its 1x1,
  * network_blocks.py:54-79): dx IS that unit's dy, so the epilogue also takes the unit's two BatchNorm-backward sums - what
@@ -78,9 +86,14 @@ int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void
 
 /* Which device kernel ep24_conv_fwd_bf16 (dgrad = 0) / ep24_conv_dgrad_bf16 (dgrad = 1, stride 1) launches for a shape - the
  * library's own dispatch rule, for reports (bench.py attributes launch times to kernels with it).  Returns 0 =
- * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch), 2 = igemm_stream_kernel (1x1 streaming), < 0 on error.
+ * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch, 8 waves in lockstep), 2 = igemm_stream_kernel (1x1
+ * streaming), 3 = conv_ring_kernel (halo patch as a loader / consumer ring), 4 = conv_ring_generic_kernel (the ring without a
+ * patch; only with kernel_opts bit 4), < 0 on error.
  * y_f32 / has_bias as in ep24_conv_fwd_bf16 (both 0 for dgrad). */
 int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias);
+/* ... and for the _ex entry points with the given kernel_opts. */
+int ep24_conv_kernel_for_ex(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias,
+                            int kernel_opts);
 
 /* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,OH,OW,Cout_k], wt[Cin][k*k][Cout_k]); Cout_k % 8 == 0 (zero padded).
  * wt is the pure transpose of w (no tap flip).  Replaces autograd's conv input gradient. */

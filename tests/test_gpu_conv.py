@@ -119,6 +119,9 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # offset): rows past M in the last block and a whole block past the end (odd unit count), an N tail, K = 64 (two K steps),
     # a K tail inside a step (K = 120), two K halves with a tail (K = 200, M large enough for the streaming form)
     (3, 50, 64, 72, 1, 1, 50), (5, 36, 120, 200, 1, 1, 36), (17, 80, 200, 136, 1, 1, 79),
+    # the ring without a patch (round 4; kernel_opts bit 4; an 8th value is the kernel id the shape must dispatch to with it): the 4-step 1x1 layer of the
+    # 40x40 level, a 1x1 layer with M, N and K tails, a stride-2 3x3 layer with a K tail
+    (20, 40, 256, 256, 1, 1, 40, 4), (13, 50, 200, 264, 1, 1, 47, 4), (20, 90, 72, 136, 3, 2, 86, 4),
 ]
 
 
@@ -150,9 +153,11 @@ def test_conv_hot_shapes(shape):
     gy = rnd(B, Cout, OH, OW, seed=3)
     y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
     M = B * OH * OW
-    if len(shape) > 6:
-        want = 1 if k == 3 else 2
-        assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == want, "meant to exercise the patch / streaming kernel's tails"
+    if len(shape) > 7:
+        assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 16) == shape[7]
+    elif len(shape) > 6:
+        want = 3 if k == 3 else 2                                         # 3: the loader / consumer ring (round 4), 2: streaming
+        assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == want, "meant to exercise the ring / streaming kernel's tails"
 
     xd = nhwc(x).to(DEV)
     wf = w.permute(0, 2, 3, 1).contiguous().to(DEV)
@@ -160,8 +165,11 @@ def test_conv_hot_shapes(shape):
     gyd = nhwc(gy).to(DEV)
     R = 8
     outs = {}
-    for patch in (1, 0):                                                  # halo-patch kernel, then the generic tiled kernel
-        ko = 0 if patch else 1                                            # kernel_opts bit 0 of the _ex entry points: per call, no global switch
+    # kernel_opts of the _ex entry points (per call, no global switch): 0 = the shape's default (3x3 stride-1: the loader / consumer
+    # ring of conv_ring.hip where it fits), bit 3 = the 8-wave halo-patch kernel instead, bit 0 = the generic tiled kernel
+    # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
+    variants = ((2, 0), (1, 8), (0, 1)) if (k == 3 and s == 1) else ((2, 0), (0, 16))
+    for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
         call("conv_fwd_bf16_ex", ptr(xd), Cin, ptr(wf), ptr(y), Cout, 0, 0, 0, None, ptr(stats), R, B, H, W, Cin, Cout, k, s, ko, sp())
@@ -178,12 +186,14 @@ def test_conv_hot_shapes(shape):
         close(st[1], (y_ref * y_ref).sum((0, 2, 3)), rel=2e-3)
         close(dx.permute(0, 3, 1, 2), dx_ref)
         close(dx2.permute(0, 3, 1, 2), dx_ref + base.float().cpu().permute(0, 3, 1, 2))
-        outs[patch] = (y, dx)
-        if not (k == 3 and s == 1):
-            break                                                          # only the 3x3 stride-1 layers have two kernels
-    if len(outs) == 2:
-        # same products, same fp32 accumulation order per output element (channel chunks outer, taps inner): bit-equal
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        outs[patch] = (y, dx, dx2, stats.clone())
+    # same products, same fp32 accumulation order per output element (channel chunks outer, taps inner): bit-equal outputs, input
+    # gradients (plain and accumulated) and - integer sums - batch statistics, whichever kernel ran
+    for other in outs:
+        for a_, b_ in zip(outs[0], outs[other]):
+            assert torch.equal(a_, b_) if a_.dtype != torch.int64 else torch.equal(a_.sum(0), b_.sum(0)), other
+    # no bounded wait of the ring kernel ever gave up (a protocol error would show here even if the numbers happened to agree)
+    assert fn["ep24_conv_ring_timeouts"]() == 0
 
     splits = fn["ep24_conv_wgrad_splits"](B, H, W, Cin, Cout, k, s)
     numel = Cout * k * k * Cin

@@ -1,11 +1,12 @@
 """Per-class bounds of one training step from a layer table (bench.py with EP24_LAYER_TABLE=...): launches, serial ms (HIP events
 round every launch of the instrumented serial pass), algorithmic bytes / 6.3 TB/s (the achievable HBM rate, MI355X_MICROARCH.md) and
-conv FLOPs / 900 TFLOP/s (what the best layers of this library reach; the dense bf16 MFMA peak is 2 500).
+conv FLOPs over BOTH the chip's dense bf16 MFMA peak (2 500 TFLOP/s: the roofline) and 900 TFLOP/s (what a 128 x 128, two-barrier tile
+structure reaches on this chip - a property of that structure, not a bound).  "x over" columns are against the CHIP's bounds.
 usage: bound_table.py LAYER_TABLE.txt"""
 import collections
 import sys
 
-HBM, MFMA = 6.3e12, 900e12
+HBM, MFMA, MFMA_OLD = 6.3e12, 2500e12, 900e12
 conv = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])      # class -> launches, ms, bytes, flops
 other = collections.defaultdict(lambda: [0, 0.0, 0.0])
 sec = 0
@@ -13,7 +14,7 @@ for line in open(sys.argv[1]):
     if line.startswith("other kernels"):
         sec = 1
         continue
-    if ":" not in line or line.startswith("kernel "):
+    if ":" not in line or line.startswith("kernel ") or line.startswith("#"):
         continue
     left, right = line.split(":")
     f = left.split()
@@ -39,18 +40,18 @@ for line in open(sys.argv[1]):
             o[2] += 6.0 * a[1] * a[2] * n
         elif name == "wgrad_reduce":
             o[2] += 0.0
-print("| class | launches | serial ms | algorithmic GB | HBM bound ms (6.3 TB/s) | MFMA bound ms (900 TF) | serial / larger bound |")
-print("|---|---|---|---|---|---|---|")
+print("| class | launches | serial ms | algorithmic GB | HBM bound ms (6.3 TB/s) | MFMA bound ms (2 500 TF) | serial / larger bound | (MFMA ms at 900 TF) |")
+print("|---|---|---|---|---|---|---|---|")
 tot = [0, 0.0, 0.0]
 for k in ("1x1", "3x3 s1", "3x3 s2"):
     n, ms, by, fl = conv[k]
     hb, mb = by / HBM * 1e3, fl / MFMA * 1e3
-    print("| conv %s (fwd + dgrad + wgrad) | %d | %.2f | %.2f | %.2f | %.2f | %.2fx |" % (k, n, ms, by / 1e9, hb, mb, ms / max(hb, mb)))
+    print("| conv %s (fwd + dgrad + wgrad) | %d | %.2f | %.2f | %.2f | %.2f | %.2fx | %.2f |" % (k, n, ms, by / 1e9, hb, mb, ms / max(hb, mb), fl / MFMA_OLD * 1e3))
     tot[0] += n; tot[1] += ms; tot[2] += max(hb, mb)
 bn = [0, 0.0, 0.0]
 for k in ("bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"):
     n, ms, by = other[k]
-    print("| %s | %d | %.2f | %.2f | %.2f | - | %.2fx |" % (k, n, ms, by / 1e9, by / HBM * 1e3, ms / (by / HBM * 1e3)))
+    print("| %s | %d | %.2f | %.2f | %.2f | - | %.2fx | - |" % (k, n, ms, by / 1e9, by / HBM * 1e3, ms / (by / HBM * 1e3)))
     tot[0] += n; tot[1] += ms; tot[2] += by / HBM * 1e3
 STEM = ("focus_pack", "stem_conv_fwd_bf16", "stem_conv_wgrad_slab_bf16")
 st_n = sum(other[k][0] for k in STEM if k in other)
@@ -59,10 +60,10 @@ if st_n:
     # per pixel of the space-to-depth grid: pack 48 B in + 32 B out, conv 32 B in + 128 B out, weight gradient 128 + 32 B in
     Mst = [int(l.split()[1]) * int(l.split()[2]) * int(l.split()[3]) // 4 for l in open(sys.argv[1]) if l.startswith("focus_pack")][0]
     by = 400.0 * Mst
-    print("| Focus stem (focus_pack + gathering conv + weight gradient; no im2col buffer) | %d | %.2f | %.2f | %.2f | 0.06 | %.2fx |" % (
+    print("| Focus stem (focus_pack + gathering conv + weight gradient; no im2col buffer) | %d | %.2f | %.2f | %.2f | 0.02 | %.2fx | 0.06 |" % (
         st_n, st_ms, by / 1e9, by / HBM * 1e3, st_ms / (by / HBM * 1e3)))
     tot[0] += st_n; tot[1] += st_ms; tot[2] += by / HBM * 1e3
 rest_n = sum(v[0] for k, v in other.items() if not k.startswith("bn_act") and k not in STEM)
 rest_ms = sum(v[1] for k, v in other.items() if not k.startswith("bn_act") and k not in STEM)
-print("| everything else in the table (wgrad_reduce, SPP, upsample, decode, copies) | %d | %.2f | - | - | - | - |" % (rest_n, rest_ms))
-print("| sum | %d | %.2f | | %.2f (sum of the larger bounds) | | %.2fx |" % (tot[0] + rest_n, tot[1] + rest_ms, tot[2], (tot[1]) / tot[2]))
+print("| everything else in the table (wgrad_reduce, SPP, upsample, decode, copies) | %d | %.2f | - | - | - | - | - |" % (rest_n, rest_ms))
+print("| sum | %d | %.2f | | %.2f (sum of the larger bounds) | | %.2fx | |" % (tot[0] + rest_n, tot[1] + rest_ms, tot[2], (tot[1]) / tot[2]))

@@ -1,5 +1,5 @@
-"""GPU box helper: A/B of the halo-patch kernel against the generic tiled kernel on the 3x3 stride-1 layers of YOLOX-l
-(B = 20), interleaved rounds in ONE process (median of 5), launches replayed from a hipGraph.
+"""GPU box helper: A/B of the three kernels of the 3x3 stride-1 layers of YOLOX-l (B = 20) - generic tiled, 8-wave halo patch,
+loader / consumer ring - interleaved rounds in ONE process (median of 5 replays each, best of 3 rounds), launches replayed from a hipGraph.
 usage: conv_ab.py [fwd|dgrad ...]"""
 import os
 import sys
@@ -38,7 +38,7 @@ def graph_time(run, iters=20):
 def main():
     kinds = sys.argv[1:] or ["fwd", "dgrad"]
     fn = _lib.lib().fn
-    print("%-8s %-22s %10s %10s %10s %10s   (us: tiled narrow-epilogue, tiled, patch narrow-epilogue, patch)" % ("kind", "B,H,Cin,Cout", "tiled-n", "tiled", "patch-n", "patch"))
+    print("%-8s %-22s %10s %10s %10s   (us: generic tiled kernel, 8-wave halo-patch kernel, loader / consumer ring)" % ("kind", "B,H,Cin,Cout", "tiled", "patch8", "ring"))
     for B, H, Cin, Cout in SHAPES:
         W = H
         zero = os.environ.get("EP24_PROBE_ZERO") == "1"          # DVFS check: the same kernels on all-zero operands
@@ -65,12 +65,13 @@ def main():
                 else:
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
-            for rnd in range(2):
-                for mode in (2, 0, 3, 1):                # old numbering of the columns: bit 0 = patch kernel, bit 1 = narrow epilogue
-                    ko[0] = (0 if mode & 1 else 1) | (mode & 2)
+            for rnd in range(3):                         # interleaved rounds in one process
+                for mode in (1, 8, 0):                   # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring)
+                    ko[0] = mode
                     res.setdefault(mode, []).append(graph_time(run))
-            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f   best %.0f TF" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[2]), min(res[0]), min(res[3]), min(res[1]),
-                                                                    fl / min(min(v) for v in res.values()) / 1e6), flush=True)
+            print("%-8s %-22s %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]),
+                                                                       fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6), flush=True)
+    print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 
 main()
