@@ -19,6 +19,8 @@ constexpr int KOPT_TILED = 1, KOPT_NARROW_EPI = 2, KOPT_PER_CLASS = 4;     // bi
 constexpr int KOPT_GRING = 16;             // bit 4: layers of the tiled kernel that fill the chip with 256 x 128 tiles run in the ring without a
                                            // patch instead (conv_ring.hip; measured SLOWER on every layer of YOLOX-l at B = 20,
                                            // profiles/r04_ring_generic_ab.txt: an A/B option, off by default)
+constexpr int KOPT_RING32 = 32;            // bit 5: the ring's consumers multiply with v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (an A/B option: 12 % fewer
+                                           // cycles per step, a 9 % lower clock under load - slower in the step, profiles/r04_ring_ab.txt)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -537,7 +539,7 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer &&
         !(kernel_opts & KOPT_TILED)) {
         int prc = EP24_OK;
-        if (!(kernel_opts & KOPT_PATCH8) && launch_ring(a, stream, dry, &prc)) {
+        if (!(kernel_opts & KOPT_PATCH8) && launch_ring(a, stream, dry, &prc, (kernel_opts & KOPT_RING32) == 0)) {
             if (dry) { *kernel_id = 3; return EP24_OK; }
             if (prc) return prc;
             EP24_LAUNCH_CHECK("ep24_conv_ring");

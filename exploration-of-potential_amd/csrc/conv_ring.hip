@@ -72,6 +72,16 @@ __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& a, const bf16x8
 #endif
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16_;
+// ... and the 32 x 32 x 16 form: D[32 x 32] in 16 registers per lane (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column = lane & 31)
+__device__ __forceinline__ void mfma32_acc(f32x16_& c, const bf16x8& a, const bf16x8& b) {
+#if (RING_VAR & 8)
+    asm volatile("" : "+a"(c) : "v"(a), "v"(b));
+#else
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+
 // min over the four counters; the words sit in one 16-byte line, every lane reads the same addresses (broadcast)
 __device__ __forceinline__ unsigned min4(const unsigned* f) {
     const unsigned a = ld_flag(f), b = ld_flag(f + 1), c = ld_flag(f + 2), d = ld_flag(f + 3);
@@ -98,6 +108,8 @@ __device__ __forceinline__ void spin_until(const unsigned* f, unsigned need, uns
     }
     cbar();
 }
+
+__device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int n0, char* smem);
 
 // Epilogue with all eight waves (16-byte store path only).  The stamps of the first form - the four consumers alone, each staging and
 // storing its 128 x 64 piece - read 10.5 k cycles per tile, a quarter of a 36-step kernel: the tail is store-ISSUE bound (MI355X_MICROARCH
@@ -131,6 +143,39 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
         }
     }
     __syncthreads();
+    ring_store_tile(p, m0, n0, smem);
+    if (p.stats) {
+        __syncthreads();                                     // the staging areas have been read
+        float* red = reinterpret_cast<float*>(smem);         // [NCW waves][2][64]
+        if (consumer) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = s1[q], b = s2[q];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (fq == 0) {
+                    red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
+                    red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+                }
+            }
+        }
+        __syncthreads();
+        long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
+        if (tid < 2 * RBN) {
+            const int which = tid / RBN, c = tid - which * RBN;
+            const int wcol = c >> 6;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) v += red[((r * 2 + wcol) * 2 + which) * 64 + (c & 63)];
+            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+        }
+    }
+}
+
+// The staged 256 x 128 bf16 tile (four areas of [128 rows][128 B], 16-byte chunk index XOR (row & 7)) leaves as 16-byte stores, eight
+// chunks per lane of all eight waves, 8 lanes per 128-byte row segment.  Called behind the barrier that follows the staging writes.
+__device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int n0, char* smem) {
+    const int tid = threadIdx.x;
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 && p.dbs == (long)p.GH * p.GW);
     constexpr int CPT = NCW * MT * 16 * 8 / ((NCW + NLW) * 64);      // 16-byte chunks per thread: 8
     bf16* dptr[CPT];
@@ -165,20 +210,59 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
         if (ok[k]) *reinterpret_cast<bf16x8*>(dptr[k]) = val[k];
-    if (p.stats) {
-        __syncthreads();                                     // the staging areas have been read
-        float* red = reinterpret_cast<float*>(smem);         // [NCW waves][2][64]
-        if (consumer) {
+}
+
+// Epilogue of the 32 x 32 x 16 consumers.  A consumer holds D[channel][pixel] tiles: lane = pixel (lane & 31), register quad qd of a
+// tile = four consecutive channels 8 qd + 4 (lane >> 5) .. + 3 - one 8-byte packed store into the pixel's staging row, 32 per lane
+// as in the 16 x 16 form.  BatchNorm statistics: a lane's 32 channels (x 2 sums) summed over its four pixel tiles, then over the 32
+// lanes that share them through LDS (fixed order: bitwise reproducible).
+__device__ __forceinline__ void ring_epilogue32(const IgemmArgs& p, f32x16_ (&acc)[2][4], const bool consumer, long m0, int n0, int tile_m, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pr = lane & 31, h = lane >> 5;
+    float ps1[2][16], ps2[2][16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float a = s1[q], b = s2[q];
-                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-                if (fq == 0) {
-                    red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                    red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ps1[ct][r] = 0.f; ps2[ct][r] = 0.f; }
+    __syncthreads();                                         // every wave is out of the main loop: LDS is free
+    if (consumer) {
+        const int wm = wave >> 1;
+        char* stg = smem + wave * (MT * 16 * 128);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int row = pt * 32 + pr;
+            const bool live = m0 + wm * (MT * 16) + row < p.M;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[ct][pt][qd * 4 + e];
+                        if (live) { ps1[ct][qd * 4 + e] += v; ps2[ct][qd * 4 + e] += v * v; }
+                        w[e] = (bf16)v;
+                    }
+                    *reinterpret_cast<bf16x4*>(stg + row * 128 + (((ct * 4 + qd) ^ (row & 7)) << 4) + h * 8) = w;
                 }
             }
+        }
+    }
+    __syncthreads();
+    ring_store_tile(p, m0, n0, smem);
+    if (p.stats) {
+        __syncthreads();                                     // the staging areas have been read
+        constexpr int LP = 33;                               // 32 lanes + 1: lanes of one channel on consecutive banks
+        float* red = reinterpret_cast<float*>(smem);         // [NCW waves][2 sums][64 channels][LP]
+        if (consumer) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    red[((wave * 2 + 0) * 64 + ch) * LP + pr] = ps1[ct][r];
+                    red[((wave * 2 + 1) * 64 + ch) * LP + pr] = ps2[ct][r];
+                }
         }
         __syncthreads();
         long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
@@ -186,14 +270,26 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
             const int which = tid / RBN, c = tid - which * RBN;
             const int wcol = c >> 6;
             float v = 0.f;
+            for (int r = 0; r < 2; ++r) {
+                const float* src = red + (((r * 2 + wcol) * 2 + which) * 64 + (c & 63)) * LP;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) v += red[((r * 2 + wcol) * 2 + which) * 64 + (c & 63)];
+                for (int l = 0; l < 32; ++l) v += src[l];
+            }
             if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
 }
 
-template <int PPS>
+// M32: the consumers multiply with v_mfma_f32_32x32x16_bf16 (weights as the A operand, pixels as B: D[channel][pixel]) instead of
+// v_mfma_f32_16x16x32_bf16.  Same FLOPs per matrix-pipe cycle, HALF the MFMA instructions: a step is 32 MFMAs that leave 24 free
+// issue cycles each (768 per step) where the 64 of the 16 x 16 form leave 8 each (512) - and the stamps of the 16 x 16 consumer
+// said its other ~85 instructions per step need ~740 cycles of issue by themselves (profiles/r04_ring_variants_16x16.txt).
+// What changes with it: LDS rows keep 128 B, but the 16-byte chunk of k-step s (16 deep) and lane half h is 2 s + h, and the
+// swizzle key is (row >> 1) & 7 - conflict free for ds_read_b128 of 32 consecutive rows at ANY row shift (brute-forced over the
+// instruction's lane groups), which row & 7 is not for this fragment shape; the weight rows sit in natural channel order (a
+// register quad of D is four consecutive channels already); the sum over a 64-channel chunk runs in four k-steps of 16 instead of
+// two of 32, so results differ from the tiled kernel in the last bit of the fp32 sums (and agree run to run, bit for bit).
+template <int PPS, bool M32>
 __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const IgemmArgs p, const int NP, const int halo, const int npb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,10 +323,17 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     const bool wide = !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(p.dst) & 15) == 0;
 
     f32x4 acc[MT][NT];                                       // consumers only; zeros in the loaders (one epilogue call site for both)
+    f32x16_ acc32[2][4];                                     // M32: [channel tile][pixel tile]; whichever form is unused folds away
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[ct][pt][r] = 0.f;
 #ifdef EP24_STAMPS
     unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_spin = 0;
     unsigned st_nspin = 0;
@@ -239,16 +342,21 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     auto loader_main = [&]() {
         // =================================================================== LOADER
         const int lw = wave - NCW;
-        const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
+        // source chunk of the lane's LDS slot: slot ^ key(row).  16 x 16 form: key = row & 7 = (lane >> 3) & 7 for every 8-row piece.
+        // M32: key = (row >> 1) & 7 = (lane >> 4) | 4 (piece & 1): the odd pieces' chunk is the even pieces' with bit 2 flipped.
+        const int lchunk = M32 ? ((lane & 7) ^ ((lane >> 4) & 3)) : ((lane & 7) ^ ((lane >> 3) & 7));
+        const int lchunk_odd = M32 ? (lchunk ^ 4) : lchunk;
         const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.src), 0, p.src_bytes, 0x00020000);
         const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
         const int kmax = (p.K - lchunk * 8 + BK - 1) / BK;   // chunks kc < kmax hold real channels for this lane
+        const int kmax_odd = (p.K - lchunk_odd * 8 + BK - 1) / BK;
         const int ktail = (p.K & (BK - 1)) ? KC - 1 : KC;    // chunks >= ktail need the per-lane check
         const int NPW = (NP + NLW - 1) / NLW;                // patch pieces per loader and chunk (the last may be a duplicate)
         const unsigned msrc = (unsigned)((long)p.B * p.SH * p.SW);
         const int prow0 = (int)(m0 - halo) + (lane >> 3);
         const int ld2 = (int)p.ld_src * 2;
         const unsigned pv0 = (unsigned)prow0 * (unsigned)ld2 + lchunk * 16;
+        const unsigned pv0_odd = (unsigned)prow0 * (unsigned)ld2 + lchunk_odd * 16;
         // piece i of this loader = piece g = min(i * NLW + lw, NP - 1) of the patch (a clamped index re-loads the last piece:
         // identical bytes to the same place, so that every step issues a fixed number of DMAs and the waits are immediates)
         auto issue_patch = [&](int pbuf_off, int kc, int i) {
@@ -256,23 +364,26 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
             g = g < NP ? g : NP - 1;                           // scalar
             const unsigned ps = (unsigned)(prow0 + 8 * g);     // a row before the tensor wraps to a huge value and fails the test
             bool ok = ps < msrc;
-            if (kc >= ktail) ok = ok && kc < kmax;
-            const int vo = ok ? (int)(pv0 + (unsigned)(8 * g * ld2 + kc * (BK * 2))) : OOB;
+            const bool odd = M32 && (g & 1);                   // scalar
+            if (kc >= ktail) ok = ok && kc < (odd ? kmax_odd : kmax);
+            const int vo = ok ? (int)((odd ? pv0_odd : pv0) + (unsigned)(8 * g * ld2 + kc * (BK * 2))) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(smem + ZB + pbuf_off + g * 1024), 16, vo, 0, 0, 0);
         };
         int wvoff[B_INSTR];
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             const int q = (lw * B_INSTR + i) * 8 + (lane >> 3);
-            const int r = (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);            // channel relabelling of the shared epilogue
-            wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lchunk * 8) * 2) : OOB;
+            // 16 x 16 form: channel relabelling of the shared epilogue; M32: natural order (piece lw * 4 + i is odd when i is)
+            const int r = M32 ? q : (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
+            const int lc = (i & 1) ? lchunk_odd : lchunk;
+            wvoff[i] = n0 + r < p.N ? (int)((((long)(n0 + r) * p.WT * p.K) + lc * 8) * 2) : OOB;
         }
         auto issue_b = [&](int stage, int t, int kc) {
             const int b_s = (t * p.K + kc * BK) * 2;
 #pragma unroll
             for (int i = 0; i < B_INSTR; ++i) {
                 int vo = wvoff[i] == OOB ? OOB : wvoff[i] + b_s;
-                if (kc >= ktail) vo = kc < kmax ? vo : OOB;
+                if (kc >= ktail) vo = kc < ((i & 1) ? kmax_odd : kmax) ? vo : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(smem + ZB + bb + stage * B_BYTES + (lw * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
             }
         };
@@ -483,7 +594,167 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
 #endif
     };
 
+    // ======================================================================= CONSUMER, 32 x 32 x 16 form
+    auto consumer_main32 = [&]() {
+        const int cw = wave, wm = cw >> 1, wn = cw & 1;
+        const int pr = lane & 31, h = lane >> 5;
+        // per-lane tap masks of the four pixel tiles (9 bits each): two registers
+        unsigned vmp[2] = {0u, 0u};
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const long m = m0 + wm * (MT * 16) + pt * 32 + pr;
+            unsigned mk = 0;
+            if (m < p.M) {
+                const int mm = (int)m;
+                const int n = fdiv(mm, p.d_plane);
+                const int rem = mm - n * (p.GH * p.GW);
+                const int y = fdiv(rem, p.d_gw), x = rem - y * p.GW;
+                unsigned rowm = 0x038u, colm = 0x092u;
+                if (y - sgn >= 0 && y - sgn < p.SH) rowm |= 0x007u;
+                if (y + sgn >= 0 && y + sgn < p.SH) rowm |= 0x1C0u;
+                if (x - sgn >= 0 && x - sgn < p.SW) colm |= 0x049u;
+                if (x + sgn >= 0 && x + sgn < p.SW) colm |= 0x124u;
+                mk = rowm & colm;
+            }
+            vmp[pt >> 1] |= mk << (9 * (pt & 1));
+        }
+        // Fragment of (pixel tile pt, k-step s): patch row q = arow0 + 32 pt + shift(tap), chunk 2 s + h, key (q >> 1) & 7 - 32 pt
+        // leaves the key alone and s only flips bits 5..6 of the address: address = ((tap address + 4096 pt) & mask) ^ (s << 5).
+        // Masked rows read the zero bytes 0..127 (0 ^ 32 s stays inside them).
+        const int arow0 = wm * (MT * 16) + pr + halo;
+        auto tap_addr = [&](int pbuf_off, int sh) {
+            const int q0 = arow0 + sh;
+            return ZB + pbuf_off + q0 * 128 + ((h ^ ((q0 >> 1) & 7)) << 4);
+        };
+        auto row_addr = [&](int ta, int pt, int t) {
+            const int m = __builtin_amdgcn_sbfe((int)vmp[pt >> 1], (unsigned)(9 * (pt & 1) + t), 1u);
+            if constexpr ((RING_VAR & 4) != 0) return ta + pt * 4096;
+            return (ta + pt * 4096) & m;
+        };
+        // weight fragment (channel tile ct, k-step s): tile row wn * 64 + 32 ct + pr; stage as an offset constant
+        int wb[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int n = wn * 64 + ct * 32 + pr;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wb[ct][ks] = ZB + bb + n * 128 + (((2 * ks + h) ^ ((n >> 1) & 7)) << 4);
+        }
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag_p;
+        auto lds_frag = [&](int off) { return *reinterpret_cast<lds_frag_p>((unsigned long)(unsigned)off); };
+        auto pin = [](int& v) { asm volatile("" : "+v"(v)); };
+#ifdef EP24_STAMPS
+        st_t0 = STAMP(); st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // A step is 16 groups of 2 MFMAs (k-step s = g / 4, pixel tile pt = g % 4, both channel tiles: 64 matrix-pipe cycles); the
+        // pixel fragment of group g is requested LA groups earlier, the two weight fragments of a k-step during the k-step before.
+        spin_until(f_full, 1u, f_err);
+        bf16x8 pa[LA], wp[2];
+        int ra[4];
+        {
+            const int ta = tap_addr(0, sgn * (-p.SW - 1));
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) ra[pt] = row_addr(ta, pt, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < LA; ++g) pa[g] = lds_frag(ra[g & 3] ^ ((g >> 2) << 5));
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wp[ct] = lds_frag(wb[ct][0]);
+#ifdef EP24_STAMPS
+        st_t1 = STAMP();
+#endif
+        unsigned j = 0;
+        for (int kc = 0; kc < KC; ++kc) {
+            const int pcur = (npb == 2) ? (kc & 1) * PBYTES : 0;
+            const int pnext = ((kc + 1) & 1) * PBYTES;
+            const bool more = kc + 1 < KC;
+#pragma unroll 1
+            for (int ty = 0; ty < 3; ++ty) {
+                const int shrow = sgn * (ty - 1) * p.SW;
+                auto tap_step = [&](auto txc) {
+                    constexpr int tx = decltype(txc)::value;
+                    const int t = ty * 3 + tx;
+                    constexpr int so = tx * B_BYTES, son = ((tx + 1) % 3) * B_BYTES;     // ring stage of this step / the next
+                    const bool last = tx == 2 && ty == 2 && !more;
+                    const int tn = (tx < 2 || ty < 2) ? t + 1 : 0;
+                    const int tan = (tx < 2) ? tap_addr(pcur, shrow + sgn * tx)
+                                             : (ty < 2 ? tap_addr(pcur, shrow + sgn * (p.SW - 1))
+                                                       : tap_addr(pnext, sgn * (-p.SW - 1)));
+                    bf16x8 F[16], W[4][2];
+                    v4u fl = {0u, 0u, 0u, 0u};
+                    constexpr int G_CHECK = 8, G_FLAGS = 4;
+                    auto group = [&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        constexpr int gr = g + LA, ks = g >> 2, pt = g & 3;
+                        if constexpr (g == G_CHECK) {
+                            if (!last) {
+                                const unsigned have = __builtin_amdgcn_readfirstlane(min(min(fl.x, fl.y), min(fl.z, fl.w)));
+                                if (have < j + 2) {           // this is step j (0-based): the next one must have landed
+#ifdef EP24_STAMPS
+                                    const unsigned long long s0 = STAMP();
+                                    spin_until(f_full, j + 2, f_err);
+                                    st_spin += STAMP() - s0; ++st_nspin;
+#else
+                                    spin_until(f_full, j + 2, f_err);
+#endif
+                                }
+                                cbar();
+                            }
+                        }
+                        // pixel fragment of group g + LA (this step's, or the next step's behind the check)
+                        if constexpr (gr < 16) F[gr] = lds_frag(ra[gr & 3] ^ ((gr >> 2) << 5));
+                        else pa[gr - 16] = lds_frag(ra[(gr - 16) & 3] ^ (((gr - 16) >> 2) << 5));
+                        // weight fragments of the next k-step: two of the four groups of a k-step request one each
+                        if constexpr (pt < 2) {
+                            if constexpr (ks < 3) W[ks + 1][pt] = lds_frag(wb[pt][ks + 1] + so);
+                            else wp[pt] = lds_frag(wb[pt][0] + son);
+                        }
+                        if constexpr (g == G_FLAGS) fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                        if constexpr (g == 9) {
+                            // every fragment read of this step is issued (pixel fragments by group 7, the last weight fragments by
+                            // group 9): its ring stage may be refilled
+                            cbar();
+                            if (lane == 0) st_flag(f_free + cw, j + 1);
+                            cbar();
+                        }
+                        auto mma2 = [&](const bf16x8& fx) {
+                            if constexpr (ks == 0) { mfma32_acc(acc32[0][pt], wp[0], fx); mfma32_acc(acc32[1][pt], wp[1], fx); }
+                            else { mfma32_acc(acc32[0][pt], W[ks][0], fx); mfma32_acc(acc32[1][pt], W[ks][1], fx); }
+                        };
+                        if constexpr (g < LA) mma2(pa[g]); else mma2(F[g]);
+                        // the next tap's masked row addresses, in place: tile pt was last used by group 12 + pt - LA (its k-step 3
+                        // request) and is next needed by group 16 - LA + pt
+                        if constexpr (g >= 13 - LA && g < 13 - LA + 4) {
+                            constexpr int i = g - (13 - LA);
+                            ra[i] = row_addr(tan, i, tn);
+                            pin(ra[i]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
+                    group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+                    group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+                    group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+                    group(std::integral_constant<int, 8>{}); group(std::integral_constant<int, 9>{});
+                    group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+                    group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{});
+                    group(std::integral_constant<int, 14>{}); group(std::integral_constant<int, 15>{});
+                    ++j;
+                };
+                tap_step(std::integral_constant<int, 0>{});
+                tap_step(std::integral_constant<int, 1>{});
+                tap_step(std::integral_constant<int, 2>{});
+            }
+        }
+#ifdef EP24_STAMPS
+        st_t2 = STAMP();
+#endif
+    };
+
     const bool consumer = wave < NCW;
+    if constexpr (M32) {
+        if (consumer) consumer_main32(); else loader_main();
+        ring_epilogue32(p, acc32, consumer, m0, n0, tile_m, smem);      // the host admits M32 only with the 16-byte store path
+    } else {
     if (consumer) consumer_main(); else loader_main();
     // LDS is nobody's any more: the last DMA landed before the last full count.  16-byte store path: all eight waves (the loaders
     // carry half of the stores); otherwise the loaders are done (a terminated wave no longer counts at s_barrier) and the four
@@ -491,6 +762,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     if (wide) ring_epilogue(p, acc, consumer, m0, n0, tile_m, smem);
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
     else return;
+    }
     const int cw = wave; (void)cw;
 #ifdef EP24_STAMPS
     if (blockIdx.x < 32 && lane == 0 && (cw == 0 || cw == NCW - 1)) {
@@ -689,7 +961,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
 }
 
-template <int PPS>
+template <int PPS, bool M32>
 int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, hipStream_t stream) {
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, RBM) * (unsigned)ep24_cdiv(a.N, RBN);
     static std::atomic<unsigned long long> done{0};          // per-device attribute, set once (conv_patch.hip has the reasons)
@@ -697,12 +969,12 @@ int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, h
     EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipGetDevice failed");
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KB) failed on device %d: %s", dev,
                      hipGetErrorString(e));
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_ring_kernel<PPS>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
+    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
     return EP24_OK;
 }
 
@@ -725,7 +997,7 @@ namespace ep24_igemm {
 // Same shapes as the halo-patch kernel takes (3x3 stride-1, N > 64, >= 200 tiles of 256 x 128, row-major nine-tap table), plus
 // room for the counters behind the weight ring.  The patch is stored in whole 8-row pieces (NP of them), not rounded up to a
 // multiple of the loader count: at W = 80 that is what leaves the 64 bytes (2 x 53 KB + 48 KB + counters < 160 KB).
-bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
+bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16) {
     const int sgn = a.oy[0] < 0 ? 1 : -1;
     for (int t = 0; t < 9; ++t)
         if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return false;
@@ -742,9 +1014,17 @@ bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
     if ((size_t)npb * np * 1024 + NS * (size_t)B_BYTES < (size_t)NCW * MT * 16 * 128) return false;
     if (!dry) {
         const int pps = (npw + 6) / 7;
-        *rc = pps <= 1 ? launch_ring_pps<1>(a, np, halo, npb, lds, stream)
-            : pps == 2 ? launch_ring_pps<2>(a, np, halo, npb, lds, stream)
-                       : launch_ring_pps<3>(a, np, halo, npb, lds, stream);
+        // the 32 x 32 x 16 consumers need the 16-byte store path (bf16 rows aligned to 16 bytes) and room for the statistics fold
+        const bool m32 = !m16 && !a.narrow_epi && (a.N & 7) == 0 && (a.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(a.dst) & 15) == 0 &&
+                         lds >= (size_t)NCW * 2 * 64 * 33 * 4;
+        if (m32)
+            *rc = pps <= 1 ? launch_ring_pps<1, true>(a, np, halo, npb, lds, stream)
+                : pps == 2 ? launch_ring_pps<2, true>(a, np, halo, npb, lds, stream)
+                           : launch_ring_pps<3, true>(a, np, halo, npb, lds, stream);
+        else
+            *rc = pps <= 1 ? launch_ring_pps<1, false>(a, np, halo, npb, lds, stream)
+                : pps == 2 ? launch_ring_pps<2, false>(a, np, halo, npb, lds, stream)
+                           : launch_ring_pps<3, false>(a, np, halo, npb, lds, stream);
     }
     return true;
 }

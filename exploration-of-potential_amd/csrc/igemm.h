@@ -261,7 +261,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 // dry = true only answers whether the shape is taken; *rc receives the error code of a failed launch set-up.
 bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 // conv_ring.hip: the same layers as 4 consumer + 4 loader waves over an LDS ring with FULL / FREE counters (round 4); same contract.
-bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
+// m16 (the default): consumers with v_mfma_f32_16x16x32_bf16, bit-identical to the tiled kernel; false: the 32 x 32 x 16 form (A/B option).
+bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16 = true);
 // ... and the ring without a patch, for any other gather-GEMM with bf16 output that fills the chip with 256 x 128 tiles.
 bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 

@@ -61,8 +61,11 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * bit 2: a stride-2 input gradient runs as one launch per parity class (four) instead of one merged launch; bit 3: the 3x3
  * stride-1 layers run in the 8-wave lockstep halo-patch kernel (csrc/conv_patch.hip) instead of the loader / consumer ring
  * (csrc/conv_ring.hip, the default since round 4); bit 4: layers of the tiled kernel that fill the chip with 256 x 128 tiles run in
- * the ring without a patch (measured slower on every layer of YOLOX-l at B = 20: off by default).  kernel_opts = 0 is exactly
- * ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16. */
+ * the ring without a patch (measured slower on every layer of YOLOX-l at B = 20: off by default); bit 5: the ring's consumers
+ * multiply with v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_16x16x32_bf16 (same products; the fp32 sum of a 64-channel chunk in
+ * four steps of 16 instead of two of 32, so results differ from the other kernels in the last bit; fewer cycles, lower clock: an
+ * A/B option).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                           int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream);

@@ -13,8 +13,9 @@ from ep24 import synth  # noqa: E402
 for B in [int(v) for v in sys.argv[1:]] or [20]:
     ref, m = bs.build_pair()
     t0 = time.time()
-    rows, _ = bs.bridge_table(ref, m, synth.make_images(B, 640, seed=9))
+    rows, _, _ = bs.bridge_table(ref, m, synth.make_images(B, 640, seed=9))
     print("B = %d, 640 x 640 (%.0f s)" % (B, time.time() - t0))
-    print("%-16s %5s | %12s %12s %12s | %12s %12s" % ("stage", "units", "tf rms", "rms bound", "tf max/range", "chained rms", "ch max/range"))
-    for st, n, a, b, c, d in rows:
-        print("%-16s %5d | %12.3e %12.3e %12.3e | %12.3e %12.3e" % (st, n, a, bs.rms_bound(st), b, c, d), flush=True)
+    print("%-16s %5s | %12s %12s %12s | %12s %12s | %12s %12s" % ("stage", "units", "tf rms", "rms bound", "tf max/range", "chained rms", "ch max/range", "propagated", "ch bound"))
+    for st, n, a, b, c, d, pr in rows:
+        print("%-16s %5d | %12.3e %12.3e %12.3e | %12.3e %12.3e | %12s %12.3e" % (st, n, a, bs.rms_bound(st), b, c, d, "-" if pr is None else "%.3e" % pr,
+                                                                            bs.rms_bound(st) + bs.PROP_SLACK * (pr or 0.0)), flush=True)

@@ -168,7 +168,8 @@ def test_conv_hot_shapes(shape):
     # kernel_opts of the _ex entry points (per call, no global switch): 0 = the shape's default (3x3 stride-1: the loader / consumer
     # ring of conv_ring.hip where it fits), bit 3 = the 8-wave halo-patch kernel instead, bit 0 = the generic tiled kernel
     # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
-    variants = ((2, 0), (1, 8), (0, 1)) if (k == 3 and s == 1) else ((2, 0), (0, 16))
+    # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
+    variants = ((2, 0), (3, 32), (1, 8), (0, 1)) if (k == 3 and s == 1) else ((2, 0), (0, 16))
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
@@ -187,11 +188,28 @@ def test_conv_hot_shapes(shape):
         close(dx.permute(0, 3, 1, 2), dx_ref)
         close(dx2.permute(0, 3, 1, 2), dx_ref + base.float().cpu().permute(0, 3, 1, 2))
         outs[patch] = (y, dx, dx2, stats.clone())
-    # same products, same fp32 accumulation order per output element (channel chunks outer, taps inner): bit-equal outputs, input
-    # gradients (plain and accumulated) and - integer sums - batch statistics, whichever kernel ran
+    # same products, same fp32 accumulation order per output element (channel chunks outer, taps inner): bit-equal outputs and input
+    # gradients (plain and accumulated), whichever kernel ran; the batch statistics are sums of per-tile fp32 partial sums, and the
+    # tiles differ (256 rows against 128): equal to fp32 summation order
     for other in outs:
-        for a_, b_ in zip(outs[0], outs[other]):
-            assert torch.equal(a_, b_) if a_.dtype != torch.int64 else torch.equal(a_.sum(0), b_.sum(0)), other
+        if other == 3:
+            # The 32x32x16 consumers add the SAME products, the fp32 sum of a 64-channel chunk in four k-steps of 16 instead of two of
+            # 32: fp32 sums agree to rounding, so after the one rounding to bf16 an element differs by at most one bf16 ulp (2^-8
+            # relative; an element that is itself a cancelled sum by 1e-5 of the tensor's range), and only a few per cent do at all.
+            for a_, b_ in zip(outs[0][:3], outs[3][:3]):
+                a32, b32 = a_.float(), b_.float()
+                d = (a32 - b32).abs()
+                assert bool((d <= 2.0 ** -8 * b32.abs() + 1e-5 * float(b32.abs().max())).all()), float(d.max())
+                assert float((d > 0).float().mean()) < 0.05, float((d > 0).float().mean())
+        else:
+            for a_, b_ in zip(outs[0][:3], outs[other][:3]):
+                assert torch.equal(a_, b_), other
+        sa, sb = outs[0][3].sum(0).double(), outs[other][3].sum(0).double()
+        assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max()), other
+    if 3 in outs:                                                          # ... and is bitwise reproducible run to run
+        y_again = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
+        call("conv_fwd_bf16_ex", ptr(xd), Cin, ptr(wf), ptr(y_again), Cout, 0, 0, 0, None, None, R, B, H, W, Cin, Cout, k, s, 32, sp())
+        assert torch.equal(y_again, outs[3][0])
     # no bounded wait of the ring kernel ever gave up (a protocol error would show here even if the numbers happened to agree)
     assert fn["ep24_conv_ring_timeouts"]() == 0
 

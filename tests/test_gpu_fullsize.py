@@ -104,59 +104,46 @@ def test_config5_full_size_step_with_the_warp_in_the_loop():
     assert abs(sa) > 0                                                         # the input really is the warped, letterboxed batch
 
 
-def test_bf16_product_forward_vs_bf16_emulating_oracle_end_to_end():
-    """YOLOX-l, B = 2, 640 x 640.  Both paths store bf16 at the same points (conv inputs, packed weights, raw conv outputs,
-    activated outputs) and accumulate in fp32, so what is left is accumulation order and the 1-ulp differences it causes, carried
-    through 131 BatchNorm layers.  Asserted: the decoded head outputs of the product against the chained oracle at the tolerances
-    below, and the loss two ways.  Measured on MI355X: rms relative error 1.0e-2 on the centres, 0.11 on the log-radii, 5.4e-2 on the
-    logits - 131 BatchNorm layers over a batch of 2 amplify one-ulp differences, though 3 - 6 times less than the ~30 % rms between
-    the fp32 reference and either bf16 path.  The loss: the product's loss kernels against the ORACLE's loss on the product's own
-    head outputs (same inputs: 1e-4), and against the oracle's loss on the oracle's outputs (different inputs, and SimOTA's
-    matching is discrete: 44.780 against 44.557 with the gathering stem of round 3, 44.566 with the im2col stem before it - both
-    inside the 2 % asserted; the output errors are the same in both).  The output bounds are about twice the measured values."""
+def test_bf16_product_forward_vs_bf16_emulating_oracle_stage_by_stage():
+    """The bridge between the timed bf16 kernels and the restatement, as a MEASUREMENT with bounds that are not read off its own output
+    (tests/bridge_stages.py has the model).  YOLOX-l at the configuration's batch, B = 20, 640 x 640 (every
+    BatchNorm sees >= 8 000 values per channel), product against the oracle in its bf16-STORAGE-emulating mode:
+
+      * teacher-forced, stage by stage (stem, dark2 .. dark5, the two halves of the PAFPN, the head; each product stage on the
+        ORACLE's inputs): relative rms error <= 2 x 2.3e-3 x sqrt(conv units of the stage) - two bf16 stores per unit, fully
+        decorrelated roundings, quadrature - i.e. 4.6e-3 (stem) .. 2.2e-2 (22 units);
+      * chained (each product stage on the product's own inputs): <= that bound + 2 x what the ORACLE stage itself makes of random
+        input perturbations of the size of the chained input errors;
+      * the loss two ways: the product's loss kernels against the oracle's loss on the product's own head outputs (1e-4), and against
+        the oracle's loss on the oracle's outputs (2 %: different inputs, SimOTA's matching is discrete).
+    The table is printed (pytest -s) and kept in profiles/r04_bridge.txt."""
+    import bridge_stages as bs
     from ep24 import loss as eloss
-    from oracle import model as om
     from oracle.loss import LossOracle
-    torch.manual_seed(3)
-    ref = om.Net(1.0, 1.0)
-    for mod in ref.modules():
-        if isinstance(mod, torch.nn.BatchNorm2d):
-            mod.eps, mod.momentum = 1e-3, 0.03
-            torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
-            torch.nn.init.uniform_(mod.bias, -0.2, 0.2)
-    from ep24 import nn as enn
-    m = enn.YOLOX(enn.YOLOPAFPN(1.0, 1.0), enn.YOLOXHead(80, 1.0))
-    m.load_state_dict(ref.state_dict(), strict=True)
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.BatchNorm2d):
-            mod.eps, mod.momentum = 1e-3, 0.03
-    m.to(DEV)
-    B, S = 2, 640
+    ref, m = bs.build_pair(seed=3, dev=DEV)
+    B, S = 20, 640
     x = synth.make_images(B, S, seed=9)
-    labels = synth.make_labels(B, [6, 3], size=S, seed=2)
+    labels = synth.make_labels(B, 10, size=S, seed=2)
+    rows, head_out, head_ref = bs.bridge_table(ref, m, x, dev=DEV)
+    print("\nstage            units | teacher-forced rms   bound | chained rms   propagated   bound")
+    bad = []
+    for stage, n, tf_rms, tf_max, ch_rms, ch_max, prop in rows:
+        b_tf = bs.rms_bound(stage)
+        b_ch = b_tf + bs.PROP_SLACK * (prop or 0.0)
+        print("%-16s %5d | %18.3e %7.1e | %11.3e %12s %7.1e" % (stage, n, tf_rms, b_tf, ch_rms, "-" if prop is None else "%.3e" % prop, b_ch))
+        if not tf_rms <= b_tf:
+            bad.append((stage, "teacher-forced", tf_rms, b_tf))
+        if not ch_rms <= b_ch:
+            bad.append((stage, "chained", ch_rms, b_ch))
+    assert not bad, bad
+    # the loss on the product's own head outputs, and on the oracle's
     out = m(x.to(DEV), train=True)
     got = out[3].detach().float().cpu()
+    assert torch.equal(got, head_out.float().cpu())                                # the stage-wise chain IS the model's forward
     loss_got = float(eloss.Loss_Function(80).forward(out, labels.to(DEV))[0])
-    om.EMULATE_BF16 = True
-    try:
-        ref.train()
-        with torch.no_grad():
-            want_tuple = ref(x, train=True)
-    finally:
-        om.EMULATE_BF16 = False
-    want = want_tuple[3].float()
-    loss_want = float(LossOracle(80)(want_tuple, labels)[0])
     loss_same_inputs = float(LossOracle(80)(synth.outputs_train_tuple(got.clone(), size=S), labels)[0])
-
-    def rel(a, b):
-        return float((a - b).abs().max() / b.abs().max())
-
-    def rms(a, b):
-        return float(((a - b).pow(2).mean() / b.pow(2).mean()).sqrt())
-
-    e_xy, e_r, e_lg = rms(got[..., :2], want[..., :2]), rms(torch.log(got[..., 2:26]), torch.log(want[..., 2:26])), rms(got[..., 26:], want[..., 26:])
-    print("bf16 bridge: rms rel err centres %.3e, log-radii %.3e, logits %.3e; max rel logits %.3e; loss %.5f vs %.5f" %
-          (e_xy, e_r, e_lg, rel(got[..., 26:], want[..., 26:]), loss_got, loss_want))
-    assert e_xy < 2.5e-2 and e_r < 0.25 and e_lg < 0.12, (e_xy, e_r, e_lg)
+    want_tuple = synth.outputs_train_tuple(head_ref.float(), size=S)
+    loss_want = float(LossOracle(80)(want_tuple, labels)[0])
+    print("loss: product %.5f, oracle on the product's outputs %.5f, oracle on its own outputs %.5f" % (loss_got, loss_same_inputs, loss_want))
     assert abs(loss_got - loss_same_inputs) < 1e-4 * abs(loss_same_inputs), (loss_got, loss_same_inputs)
     assert abs(loss_got - loss_want) < 2e-2 * abs(loss_want), (loss_got, loss_want)

@@ -38,7 +38,7 @@ def graph_time(run, iters=20):
 def main():
     kinds = sys.argv[1:] or ["fwd", "dgrad"]
     fn = _lib.lib().fn
-    print("%-8s %-22s %10s %10s %10s   (us: generic tiled kernel, 8-wave halo-patch kernel, loader / consumer ring)" % ("kind", "B,H,Cin,Cout", "tiled", "patch8", "ring"))
+    print("%-8s %-22s %10s %10s %10s %10s   (us: generic tiled kernel, 8-wave halo-patch kernel, loader / consumer ring with 16x16x32 and with 32x32x16 consumers)" % ("kind", "B,H,Cin,Cout", "tiled", "patch8", "ring16", "ring32"))
     for B, H, Cin, Cout in SHAPES:
         W = H
         zero = os.environ.get("EP24_PROBE_ZERO") == "1"          # DVFS check: the same kernels on all-zero operands
@@ -66,11 +66,11 @@ def main():
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
             for rnd in range(3):                         # interleaved rounds in one process
-                for mode in (1, 8, 0):                   # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring)
+                for mode in (1, 8, 0, 32):               # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring, 16x16x32), bit 5 ring with 32x32x16
                     ko[0] = mode
                     res.setdefault(mode, []).append(graph_time(run))
-            print("%-8s %-22s %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]),
-                                                                       fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6), flush=True)
+            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f %5.0f" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]), min(res[32]),
+                                                                       fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6, fl / min(res[32]) / 1e6), flush=True)
     print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 
