@@ -980,10 +980,13 @@ int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, h
 
 }  // namespace
 
+namespace ep24_igemm { int wgrad_ring_timeouts(); }             // conv_wgrad.hip: the weight-gradient ring's counter
+
 extern "C" int ep24_conv_ring_timeouts(void) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_timeouts), sizeof(v)) != hipSuccess) return -1;
-    return (int)v;
+    const int w = ep24_igemm::wgrad_ring_timeouts();
+    return w < 0 ? -1 : (int)v + w;
 }
 
 #ifdef EP24_STAMPS

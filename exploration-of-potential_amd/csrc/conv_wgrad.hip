@@ -12,6 +12,8 @@
 // Workgroup = 128 co x 128 ci of one tap, 4 waves (2x2 of 64x64), 64 pixels per K-step; pixels are split
 // over blockIdx.y and combined with fp32 atomics (device scope, one 64-B segment per 16 lanes).
 #include <stdlib.h>
+#include <atomic>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -308,6 +310,308 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Loader / consumer ring form of the weight gradient for layers with Cout >= 256 (round 4; the structure of conv_ring.hip).
+// BUILT, MEASURED, OFF BY DEFAULT: correct (tests/test_gpu_conv.py runs it on every hot shape) and 10 % SLOWER than wgrad_kernel on
+// every layer it takes, 23.1 against 22.5 ms per step (profiles/r04_wgrad_ring_ab.txt).  The reasoning below holds for the LDS
+// traffic; what it leaves out is that wgrad_kernel's two workgroups per CU hide each other's epilogue (64 KB of fp32 slab stores
+// per workgroup, store-issue bound) and prologue, while one ring workgroup per CU exposes 128 KB of them at the end of its one round,
+// and that 48 transposing reads per step are 48 issue slots of a single wave.
+//
+// wgrad_kernel<128,128> is LDS-bound: per 64-pixel step its four 64 x 64 waves read 64 transposed fragments (32 KB each wave) for 32
+// MFMAs each, two workgroups per CU - 256 KB of LDS reads and 64 KB of DMA writes per 256 MFMAs, ~1 500 LDS cycles against 1 024
+// matrix cycles (its measured step pair: ~3 300 cycles).  Here a workgroup owns 256 co x 128 ci of one tap; four CONSUMER waves
+// (one per SIMD) hold 128 co x 64 ci each (8 x 4 accumulator tiles in AGPRs): 48 transposed reads per 64 MFMAs, 96 KB of LDS
+// reads per 256 MFMAs - 2.7 times less - and four LOADER waves issue every LDS-DMA (dY tile [64 px][256 co] 32 KB + X tile
+// [64 px][128 ci] 16 KB per step, three stages, two steps in flight) and carry the X row offsets in registers: every lane
+// follows the four tile rows its DMA instructions touch from step to step by constant deltas and at most one wrap of ow / oh, so
+// there is no offset table in LDS and no barrier.  FULL / FREE counters, bounded spins and the step schedule (16 groups of 4 MFMAs,
+// fragments requested 8 groups ahead) are conv_ring.hip's.  Products and the order of the sums inside a pixel split are those of
+// wgrad_kernel; the number of splits differs (one workgroup per CU here), so the folded gradient agrees with wgrad_kernel's to fp32
+// summation order, and with itself bit for bit from run to run (plain slab stores, ordered reduce).
+namespace wring {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int NCW = 4, NLW = 4, NS = 3, LA = 8;
+constexpr int TCO = 256, TCI = 128;
+constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2, STAGE = Y_BYTES + X_BYTES;       // 32 KB + 16 KB
+constexpr int YI = 64 * (TCO / 8) / 64 / NLW, XI = 64 * (TCI / 8) / 64 / NLW;                  // DMA instructions per loader and step: 8, 4
+constexpr int FM = 8, FN = 4;
+constexpr int SPIN_LIMIT = 1 << 14;
+constexpr int OOB = 0x7FFFFFF0, XOOB = 0x7FFF0000;
+
+__device__ unsigned g_timeouts;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void st_flag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned min4(const unsigned* f) {
+    const v4u v = *reinterpret_cast<const volatile v4u*>(f);
+    return __builtin_amdgcn_readfirstlane(min(min(v.x, v.y), min(v.z, v.w)));
+}
+__device__ __forceinline__ void spin_until(const unsigned* f, unsigned need) {
+    int tries = 0;
+    while (min4(f) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++tries > SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_timeouts, 1u);
+            break;
+        }
+    }
+    cbar();
+}
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// transposed fragment by LDS byte offset (the kernel's only LDS object starts at offset 0)
+__device__ __forceinline__ bf16x8 tr_at(int off_lo, int off_hi) {
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(unsigned long)(unsigned)off_lo);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(unsigned long)(unsigned)off_hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// row key of the 32-byte-block permutation for 512-byte rows: the block index has four bits, the key touches the low three (a
+// fragment read addresses ONE block column in eight rows: the eight keys spread it over the eight 32-byte slots of a 256-byte bank row)
+__device__ __forceinline__ int rkey256(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int tr_off256(int r, int cb, int pp) { return r * (TCO * 2) + ((cb ^ rkey256(r)) << 5) + (pp << 3); }
+
+__global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+        const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+        bx = v % p.tiles;
+        by = v / p.tiles;
+    }
+    const int tap = bx % p.T; bx /= p.T;
+    const int ci0 = (bx % p.tiles_ci) * TCI;
+    const int co0 = (bx / p.tiles_ci) * TCO;
+    const int kh = tap / p.ksize, kw = tap % p.ksize;
+    const long p_begin = (long)by * p.chunk;
+    const long p_end = min(p.M, p_begin + p.chunk);
+    const unsigned S = p_end > p_begin ? (unsigned)((p_end - p_begin + 63) / 64) : 0u;      // steps, uniform over the workgroup
+    unsigned* const flags = reinterpret_cast<unsigned*>(smem + NS * STAGE);
+    unsigned* const f_full = flags;
+    unsigned* const f_free = flags + 4;
+    if (reinterpret_cast<unsigned long>((lptr_t)smem) != 0ul) {
+        if (tid == 0) atomicAdd(&g_timeouts, 1u << 16);
+        return;
+    }
+    if (tid < 12) flags[tid] = 0u;
+    __syncthreads();
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto loader_main = [&]() {
+        const int lw = wave - NCW;
+        const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.dy), 0, p.dy_bytes, 0x00020000);
+        const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+        const int p_end_i = (int)p_end;
+        // dY: instruction j covers LDS units (lw * YI + j) * 64 + lane: two 512-byte rows, 32 chunks each
+        int y_row[YI], y_off[YI];
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            const int U = (lw * YI + j) * 64 + lane;
+            const int r = U >> 5, pc = U & 31;
+            const int c = ((((pc >> 1) ^ rkey256(r)) << 1) | (pc & 1));
+            y_row[j] = r;
+            y_off[j] = co0 + c * 8 < p.Cout ? (int)((((p_begin + r) * p.ld_dy) + co0 + c * 8) * 2) : OOB;
+        }
+        // X: instruction j covers four 256-byte rows; the lane follows ITS row (lw * XI + j) * 4 + lane / 16 through the steps
+        int x_colb[XI], t_p[XI], t_ys[XI], t_xs[XI], t_off[XI];
+        const int lo_y = p.pad - kh, lo_x = p.pad - kw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int U = (lw * XI + j) * 64 + lane;
+            const int r = U >> 4, pc = U & 15;
+            const int c = ((((pc >> 1) ^ rkey<TCI>(r)) << 1) | (pc & 1));
+            x_colb[j] = ci0 + c * 8 < p.Cin ? (ci0 + c * 8) * 2 : XOOB;
+            t_p[j] = (int)p_begin + r;
+            const int pd = t_p[j] < p.M ? t_p[j] : 0;
+            const int n = fdiv(pd, p.d_plane);
+            const int rem = pd - n * (p.OH * p.OW);
+            const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
+            t_ys[j] = oh * p.stride; t_xs[j] = ow * p.stride;
+            t_off[j] = n * p.c_n + oh * p.c_oh + ow * p.c_ow + ((kh - p.pad) * p.W + (kw - p.pad)) * p.c_pix;
+        }
+        const int y_step = (int)(64 * p.ld_dy * 2);
+        int st = 0;
+        for (unsigned it = 0; it < S; ++it) {
+            if (it >= (unsigned)NS) spin_until(f_free, it - (NS - 1));       // stage st was last read in step it - 3
+            char* stage = smem + st * STAGE;
+            const int rows_left = p_end_i - (int)p_begin - (int)it * 64;
+#pragma unroll
+            for (int j = 0; j < YI; ++j) {
+                const bool ok = y_row[j] < rows_left && y_off[j] != OOB;
+                const int vo = ok ? y_off[j] + (int)it * y_step : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (lptr_t)(stage + (lw * YI + j) * 1024), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < XI; ++j) {
+                const bool ok = t_p[j] < p_end_i && (unsigned)(t_ys[j] - lo_y) < (unsigned)p.H && (unsigned)(t_xs[j] - lo_x) < (unsigned)p.W;
+                const int xo = ok ? t_off[j] : XOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(stage + Y_BYTES + (lw * XI + j) * 1024), 16,
+                                                         (int)((unsigned)xo + (unsigned)x_colb[j]), 0, 0, 0);
+                t_p[j] += 64; t_ys[j] += p.s_dys; t_xs[j] += p.s_dxs; t_off[j] += p.s_doff;
+                if (t_xs[j] >= wrap_x) { t_xs[j] -= wrap_x; t_ys[j] += p.stride; t_off[j] += p.c_oh - p.OW * p.c_ow; }
+                if (t_ys[j] >= wrap_y) { t_ys[j] -= wrap_y; t_off[j] += p.c_n - p.OH * p.c_oh; }
+            }
+            st = st == NS - 1 ? 0 : st + 1;
+            if (it > 0) {                                     // two steps in flight: this wait retires step it - 1
+                wait_vmcnt_c<YI + XI>();
+                if (lane == 0) st_flag(f_full + lw, it);
+                cbar();
+            }
+        }
+        wait_vmcnt_c<0>();
+        if (lane == 0) st_flag(f_full + lw, S);
+        cbar();
+    };
+
+    auto consumer_main = [&]() {
+        const int cw = wave, wm = cw >> 1, wn = cw & 1;
+        const int fq = lane >> 4, q = (lane & 15) >> 2, pp4 = lane & 3;
+        // fragment addresses in stage 0, 32-pixel half 0, rows fq * 8 + q (the +4 rows, the other half and the stage are added below:
+        // none of them changes the row key)
+        int ya[FM], xa[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) ya[i] = tr_off256(fq * 8 + q, wm * FM + i, pp4);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) xa[j] = Y_BYTES + tr_off<TCI>(fq * 8 + q, wn * FN + j, pp4);
+        auto y_frag = [&](int i, int h, int so) { return tr_at(ya[i] + so + h * (32 * TCO * 2), ya[i] + so + h * (32 * TCO * 2) + 4 * TCO * 2); };
+        auto x_frag = [&](int j, int h, int so) { return tr_at(xa[j] + so + h * (32 * TCI * 2), xa[j] + so + h * (32 * TCI * 2) + 4 * TCI * 2); };
+        auto mma_row = [&](int i, const bf16x8& fa, const bf16x8 (&fb)[FN]) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mfma_acc(acc[i][j], fa, fb[j]);
+        };
+        if (S == 0) return;
+        spin_until(f_full, 1u);
+        bf16x8 pa[LA], fb0[FN], fb1[FN];
+#pragma unroll
+        for (int g = 0; g < LA; ++g) pa[g] = y_frag(g % FM, g / FM, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb0[j] = x_frag(j, 0, 0);
+        unsigned jdone = 0;
+        int st = 0;
+#pragma unroll 1
+        for (unsigned it = 0; it < S; ++it) {
+            const int stn = st == NS - 1 ? 0 : st + 1;
+            const bool last = it + 1 == S;
+            const int so = st * STAGE, son = stn * STAGE;
+            bf16x8 F[16];
+            v4u fl = {0u, 0u, 0u, 0u};
+            constexpr int G_CHECK = 8, G_FLAGS = 4;
+            auto group = [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int gr = g + LA;
+                if constexpr (g == G_CHECK) {
+                    if (!last) {
+                        const unsigned have = __builtin_amdgcn_readfirstlane(min(min(fl.x, fl.y), min(fl.z, fl.w)));
+                        if (have < jdone + 2) spin_until(f_full, jdone + 2);       // this is step jdone (0-based): the next one must have landed
+                        cbar();
+                    }
+                }
+                if constexpr (gr < 16) F[gr] = y_frag(gr % FM, gr / FM, so);
+                else pa[gr - 16] = y_frag((gr - 16) % FM, (gr - 16) / FM, son);    // behind the last step: bytes nobody uses
+                if constexpr (g < 4) fb1[g] = x_frag(g, 1, so);
+                if constexpr (g >= G_CHECK && g < G_CHECK + 4) fb0[g - G_CHECK] = x_frag(g - G_CHECK, 0, son);
+                if constexpr (g == G_FLAGS) fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                if constexpr (gr == 15) {
+                    cbar();                                   // every fragment read of this step is issued: its stage may be refilled
+                    if (lane == 0) st_flag(f_free + cw, jdone + 1);
+                    cbar();
+                }
+                if constexpr (g < LA) mma_row(g % FM, pa[g], g < FM ? fb0 : fb1);
+                else mma_row(g % FM, F[g], g < FM ? fb0 : fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
+            group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+            group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+            group(std::integral_constant<int, 8>{}); group(std::integral_constant<int, 9>{});
+            group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+            group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{});
+            group(std::integral_constant<int, 14>{}); group(std::integral_constant<int, 15>{});
+            ++jdone;
+            st = stn;
+        }
+    };
+
+    const bool consumer = wave < NCW;
+    if (consumer) consumer_main(); else loader_main();
+    // Epilogue, all eight waves: the accumulators go through LDS ([256 co][128 ci] fp32 = 128 KB over the three stages) and leave
+    // as 16-byte stores into this split's slab.
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+    if (consumer) {
+        const int wm = wave >> 1, wn = wave & 1, fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[(wm * (TCO / 2) + i * 16 + 4 * fq + r) * TCI + wn * (TCI / 2) + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    constexpr int C4 = TCI / 4;
+    float* base = p.slab + (long)by * p.slab_stride + (long)tap * p.cin_valid + ci0;
+    const bool vec = (p.cin_valid & 3) == 0 && (p.ld_dw & 3) == 0 && (reinterpret_cast<unsigned long long>(base) & 15) == 0;
+    for (int u = tid; u < TCO * C4; u += (NCW + NLW) * 64) {
+        const int row = u / C4, c4 = u - row * C4;
+        const int co = co0 + row;
+        if (co >= p.cout_valid) continue;
+        if (vec) {
+            if (ci0 + c4 * 4 < p.cin_valid)
+                *reinterpret_cast<f32x4*>(base + (long)co * p.ld_dw + c4 * 4) = *reinterpret_cast<const f32x4*>(tile + row * TCI + c4 * 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ci0 + c4 * 4 + e < p.cin_valid) base[(long)co * p.ld_dw + c4 * 4 + e] = tile[row * TCI + c4 * 4 + e];
+        }
+    }
+}
+
+// the ring takes a layer when its slab form has whole float4 groups, Cout >= 256 and the (tile, split) grid fills >= 3/4 of the CUs
+bool eligible(const WgradArgs& a, long* splits_out) {
+    if (a.Cout < TCO || a.T > 9) return false;
+    const int tiles = ep24_cdiv(a.Cin, TCI) * ep24_cdiv(a.Cout, TCO) * a.T;
+    const long steps = (a.M + 63) / 64;
+    long splits = 256 / tiles;                                // one workgroup per CU (its LDS is the CU's)
+    if (splits > steps / 8) splits = steps / 8;
+    if (splits < 1) splits = 1;
+    if (tiles * splits < 192) return false;
+    *splits_out = splits;
+    return true;
+}
+
+int launch(WgradArgs& a, long splits, hipStream_t stream) {
+    a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
+    a.tiles = a.tiles_ci * a.tiles_co * a.T;
+    const long steps = (a.M + 63) / 64;
+    a.chunk = ((steps + splits - 1) / splits) * 64;
+    a.xcd_remap = 1;
+    static std::atomic<unsigned long long> done{0};          // more than 64 KB of dynamic LDS: the attribute, once per device
+    int dev = 0;
+    EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "wgrad_ring: hipGetDevice failed");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "wgrad_ring: hipFuncSetAttribute failed on device %d: %s", dev, hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(wgrad_ring_kernel, dim3((unsigned)(a.tiles * splits)), dim3((NCW + NLW) * 64), NS * STAGE + 64, stream, a);
+    return EP24_OK;
+}
+
+}  // namespace wring
+
 // Pixel splits: fill the chip's resident-workgroup slots exactly once (LDS allows 2 / 3 / 4 workgroups per CU for
 // the 128x128 / mixed / 64x64 tiles): one slot more than a full round costs a whole extra round (576 workgroups on
 // 512 slots ran 1.9x slower than 504), fewer leave CUs idle.  A split keeps at least 8 (16 for the small tile)
@@ -378,7 +682,12 @@ void tile_choice(const WgradArgs& a, bool& co64, bool& ci64) {
     ci64 = a.Cin <= 64 || (a.ksize == 1 && a.Cout <= 256 && a.Cin <= 256);
 }
 
-long splits_of(const WgradArgs& a) {
+constexpr int WOPT_RING = 1;               // kernel_opts of the _ex entry points, bit 0: the loader / consumer ring where the layer is eligible (an A/B
+                                           // option: 10 % slower than wgrad_kernel on every layer, +0.6 ms per step - profiles/r04_wgrad_ring_ab.txt)
+
+long splits_of(const WgradArgs& a, int opts = 0) {
+    long rs = 0;
+    if ((opts & WOPT_RING) && wring::eligible(a, &rs)) return rs;
     bool co64, ci64;
     tile_choice(a, co64, ci64);
     if (co64 && ci64) return wgrad_splits<64, 64>(a);
@@ -387,13 +696,16 @@ long splits_of(const WgradArgs& a) {
     return wgrad_splits<128, 128>(a);
 }
 
-void dispatch(WgradArgs& a, hipStream_t stream) {
+int dispatch(WgradArgs& a, hipStream_t stream, int opts = 0) {
+    long rs = 0;
+    if (a.slab && (opts & WOPT_RING) && wring::eligible(a, &rs)) return wring::launch(a, rs, stream);
     bool co64, ci64;
     tile_choice(a, co64, ci64);
     if (co64 && ci64) launch_wgrad<64, 64>(a, stream);
     else if (co64) launch_wgrad<64, 128>(a, stream);
     else if (ci64) launch_wgrad<128, 64>(a, stream);
     else launch_wgrad<128, 128>(a, stream);
+    return EP24_OK;
 }
 
 // gflat[off + i] += sum_s slab[slab_off + s * numel + i] for a list of layers: desc rows (off, numel, splits, slab_off)
@@ -478,30 +790,49 @@ extern "C" int ep24_conv_wgrad_bf16(const void* x, int64_t ld_x, const void* dy,
     EP24_REQUIRE(x && dy && dw, EP24_E_ARG, "conv_wgrad: null pointer");
     WgradArgs a{};
     if (int rc = fill_args(a, x, ld_x, dy, ld_dy, dw, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
-    dispatch(a, (hipStream_t)stream);
+    if (int rc = dispatch(a, (hipStream_t)stream)) return rc;
     EP24_LAUNCH_CHECK("ep24_conv_wgrad");
     return EP24_OK;
 }
 
-extern "C" int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+extern "C" int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts) {
     WgradArgs a{};
     if (int rc = fill_args(a, nullptr, 8, nullptr, 8, nullptr, 0, Cout, Cin, B, H, W, Cin, Cout, ksize, stride)) return rc;
-    return (int)splits_of(a);
+    return (int)splits_of(a, kernel_opts);
 }
 
-extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
-                                         int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
-                                         int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+extern "C" int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    return ep24_conv_wgrad_splits_ex(B, H, W, Cin, Cout, ksize, stride, 0);
+}
+
+extern "C" int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
+                                            int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
+                                            int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream) {
     EP24_REQUIRE(x && dy && slab, EP24_E_ARG, "conv_wgrad_slab: null pointer");
     WgradArgs a{};
     if (int rc = fill_args(a, x, ld_x, dy, ld_dy, nullptr, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride)) return rc;
     a.slab = slab;
     a.slab_stride = (long)cout_valid * ld_dw;
-    EP24_REQUIRE(splits_of(a) * a.slab_stride <= slab_floats, EP24_E_ARG, "conv_wgrad_slab: slab holds %ld floats, %ld needed",
-                 (long)slab_floats, splits_of(a) * a.slab_stride);
-    dispatch(a, (hipStream_t)stream);
+    EP24_REQUIRE(splits_of(a, kernel_opts) * a.slab_stride <= slab_floats, EP24_E_ARG, "conv_wgrad_slab: slab holds %ld floats, %ld needed",
+                 (long)slab_floats, splits_of(a, kernel_opts) * a.slab_stride);
+    if (int rc = dispatch(a, (hipStream_t)stream, kernel_opts)) return rc;
     EP24_LAUNCH_CHECK("ep24_conv_wgrad_slab");
     return EP24_OK;
+}
+
+extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab,
+                                         int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
+                                         int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+    return ep24_conv_wgrad_slab_bf16_ex(x, ld_x, dy, ld_dy, slab, slab_floats, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride, 0, stream);
+}
+
+// bounded waits of the ring kernels of this translation unit that gave up (added to ep24_conv_ring_timeouts by conv_ring.hip)
+namespace ep24_igemm {
+int wgrad_ring_timeouts() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(wring::g_timeouts), sizeof(v)) != hipSuccess) return -1;
+    return (int)v;
+}
 }
 
 // Weight gradient of the Focus stem straight from the space-to-depth image (VTAP above): slab[s][Cout][108], column tap * 12 + channel

@@ -563,10 +563,18 @@ class Engine:
         return Act(Buf(self.dev, self.B * H * W, ld or C, self.dtype), 0, C, self.B, H, W)
 
     def _kopt(self, name, args):
-        """conv_fwd_bf16 / conv_dgrad_bf16 with the plan's kernel options (PlanOptions.conv_kernel_opts != 0: the _ex entry points)."""
-        if self.options.conv_kernel_opts and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
-            return name + "_ex", tuple(args) + (self.options.conv_kernel_opts,)
+        """conv_fwd_bf16 / conv_dgrad_bf16 with the plan's kernel options (PlanOptions.conv_kernel_opts != 0: the _ex entry points);
+        bit 8 of the options is the weight gradient's bit 0 (its loader / consumer ring form, an A/B option)."""
+        ko = self.options.conv_kernel_opts
+        if ko & 0xFF and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
+            return name + "_ex", tuple(args) + (ko & 0xFF,)
+        if ko & 0x100 and name in ("conv_wgrad_slab_bf16", "side:conv_wgrad_slab_bf16"):
+            return name + "_ex", tuple(args) + (1,)
         return name, tuple(args)
+
+    def _wsplits(self, B, H, W, cin, cout, k, s):
+        """Pixel splits of a weight-gradient launch (the slab it needs), for the kernel the plan's options select."""
+        return _lib.lib().fn["ep24_conv_wgrad_splits_ex"](B, H, W, cin, cout, k, s, 1 if self.options.conv_kernel_opts & 0x100 else 0)
 
     def _f(self, name, *args, ev=None):
         """Append a forward launch; `ev` = the (name, args) that replaces it in the eval-mode list (default: the same)."""
@@ -872,7 +880,7 @@ class Engine:
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
             # few layers folds them into the flat gradient in a fixed order (no atomics: bitwise reproducible)
             splits = _lib.lib().fn["ep24_stem_conv_wgrad_splits"](B, H, W, cout) if focus else \
-                _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k_, s)
+                self._wsplits(B, H, W, cin, cout, k_, s)
             assert splits >= 1, splits
             soff = self._slab_floats
             self._slab_floats += splits * seg.numel
@@ -1071,7 +1079,7 @@ class Engine:
 
         def build_bwd():
             assert out.gready(), "activation without a gradient producer"
-            splits = _lib.lib().fn["ep24_conv_wgrad_splits"](B, H, W, cin, cout, k, s)
+            splits = self._wsplits(B, H, W, cin, cout, k, s)
             soff = self._slab_floats
             self._slab_floats += splits * seg.numel
             idx = self._bwd_units
@@ -1322,7 +1330,7 @@ class Engine:
                     self._b("side:colsum_slab", (ptr(dsrc), ld_d, (lambda soff=soff: self.slab.data_ptr() + 4 * soff), M, n))
                     self._pending_reduce.append((bseg, sp, soff))
                 for feat_in, dsrc, ld_d, wseg, n, npad in ((rf, d_ro, 32, ro_seg, 27, 32), (cf, d_cl, ldc, cl_seg, C, ldc)):
-                    sp = fn["ep24_conv_wgrad_splits"](B, H, W, hch, npad, 1, 1)
+                    sp = self._wsplits(B, H, W, hch, npad, 1, 1)
                     soff = self._slab_floats
                     self._slab_floats += sp * wseg.numel
                     self._b("side:conv_wgrad_slab_bf16", (feat_in.ptr(), feat_in.ld, ptr(dsrc), ld_d,

@@ -18,29 +18,6 @@ def letterbox_geometry(h, w, input_size):
     return r, int(h * r), int(w * r)
 
 
-class _Staging:
-    """Three rotating (pinned host, device) byte buffers for the raw images of a batch: the host gathers the images into ONE pinned
-    buffer and the upload is one asynchronous copy (20 pageable copies of 1.2 MB each held the host for ~3 ms per batch and went
-    through the runtime's bounce buffer).  A set is reused three batches later, behind the event of its own upload."""
-
-    def __init__(self):
-        self.sets, self.i = [None, None, None], 0
-
-    def take(self, nbytes, dev):
-        self.i = (self.i + 1) % 3
-        st = self.sets[self.i]
-        if st is None or st[0].numel() < nbytes or st[1].device != dev:
-            cap = max(int(nbytes * 1.25), 1 << 20)
-            st = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None]
-            self.sets[self.i] = st
-        if st[2] is not None:
-            st[2].synchronize()                      # the upload that last used this pinned buffer (three batches ago)
-        return st
-
-
-_staging = _Staging()
-
-
 def preproc_batch(images, input_size, device="cuda:0", out=None):
     """images: list of uint8 [h,w,3] arrays / tensors (host or device).  Returns (tensor [n,3,S_h,S_w] fp32 on the
     device, list of r)."""
@@ -64,18 +41,9 @@ def preproc_batch(images, input_size, device="cuda:0", out=None):
         flat.append(im.reshape(-1))
         rs.append(r)
         off += h * w * 3
-    if all(not f.is_cuda for f in flat):
-        st = _staging.take(off, dev)
-        o = 0
-        for f in flat:
-            st[0][o:o + f.numel()].copy_(f)
-            o += f.numel()
-        buf = st[1][:off]
-        buf.copy_(st[0][:off], non_blocking=True)
-        st[2] = torch.cuda.Event()
-        st[2].record()
-    else:
-        buf = torch.cat([f.to(dev, non_blocking=True) for f in flat])
+    # (gathering the images into ONE pinned host buffer first was tried in round 4 and is slower: CPU writes into hipHostMalloc'ed
+    # memory are uncached - 24 MB took ~30 ms per batch; the runtime's own staging of pageable copies is the fast path here)
+    buf = torch.cat([f.to(dev, non_blocking=True) for f in flat])
     desc_t = torch.tensor(desc, dtype=torch.int64, device=dev)
     sc_t = torch.tensor(scales, dtype=torch.float64, device=dev)
     for lo in range(0, n, 65535):

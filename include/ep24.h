@@ -74,7 +74,8 @@ int ep24_conv_dgrad_bf16_ex(const void* dy, int64_t ld_dy, const void* wt, void*
 
 /* The 3x3 stride-1 layers run as a loader / consumer ring (csrc/conv_ring.hip: 4 MFMA waves fed by 4 LDS-DMA waves through counters
  * in LDS).  Every wait on a counter is a bounded spin; this returns how many of them have given up since the library was loaded
- * (reads a device word: synchronises with the device).  Always 0 unless the hand-off protocol is broken - tests assert it. */
+ * (reads a device word: synchronises with the device; the weight-gradient ring of csrc/conv_wgrad.hip counts in).  Always 0 unless
+ * the hand-off protocol is broken - tests assert it. */
 int ep24_conv_ring_timeouts(void);
 
 /* Input gradient of a stride-1 conv that is the ONLY consumer of the conv-BN-act unit below it (a Bottleneck's 3x3 over its 1x1,
@@ -120,6 +121,13 @@ int ep24_conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int ksize, in
 int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
                               int64_t ld_dw, int cout_valid, int cin_valid,
                               int B, int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+/* The same two with an explicit kernel choice per call (A/B timing, tests): kernel_opts bit 0 = the loader / consumer ring form
+ * (layers with Cout >= 256 whose (tile, split) grid fills the chip; csrc/conv_wgrad.hip, round 4: measured 10 % slower than
+ * wgrad_kernel, off by default).  The split count - and with it the slab size - depends on the kernel: ask with the same options. */
+int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts);
+int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
+                                 int64_t ld_dw, int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
+                                 int stride, int kernel_opts, void* stream);
 int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream);
 
 /* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad

@@ -213,14 +213,27 @@ def test_conv_hot_shapes(shape):
     # no bounded wait of the ring kernel ever gave up (a protocol error would show here even if the numbers happened to agree)
     assert fn["ep24_conv_ring_timeouts"]() == 0
 
-    splits = fn["ep24_conv_wgrad_splits"](B, H, W, Cin, Cout, k, s)
+    # weight gradient: wgrad_kernel (the default) and, where the layer is eligible (Cout >= 256, the grid fills the chip), its loader /
+    # consumer ring form (kernel_opts bit 0, an A/B option).  The kernels may split the pixels differently: equal to fp32 summation
+    # order; each is bitwise reproducible.
     numel = Cout * k * k * Cin
-    slab = torch.full((splits * numel,), float("nan"), device=DEV)
-    g = torch.zeros(numel, device=DEV)
-    desc = torch.tensor([[0, numel, splits, 0]], dtype=torch.int64, device=DEV)
-    call("conv_wgrad_slab_bf16", ptr(xd), Cin, ptr(gyd), Cout, ptr(slab), splits * numel, k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, sp())
-    call("wgrad_reduce", ptr(desc), 1, numel, ptr(g), ptr(slab), sp())
-    close(g.view(Cout, k, k, Cin).permute(0, 3, 1, 2), dw_ref, rel=5e-3)
+    grads = {}
+    for wo in (0, 1):
+        splits = fn["ep24_conv_wgrad_splits_ex"](B, H, W, Cin, Cout, k, s, wo)
+        reps = []
+        for rep in range(2):
+            slab = torch.full((splits * numel,), float("nan"), device=DEV)
+            g = torch.zeros(numel, device=DEV)
+            desc = torch.tensor([[0, numel, splits, 0]], dtype=torch.int64, device=DEV)
+            call("conv_wgrad_slab_bf16_ex", ptr(xd), Cin, ptr(gyd), Cout, ptr(slab), splits * numel, k * k * Cin, Cout, Cin, B, H, W, Cin, Cout, k, s, wo, sp())
+            call("wgrad_reduce", ptr(desc), 1, numel, ptr(g), ptr(slab), sp())
+            reps.append(g)
+        close(reps[0].view(Cout, k, k, Cin).permute(0, 3, 1, 2), dw_ref, rel=5e-3)
+        if len(reps) == 2:
+            assert torch.equal(reps[0], reps[1])
+        grads[wo] = (reps[0], splits)
+    assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-5 * float(grads[1][0].abs().max()), (grads[0][1], grads[1][1])
+    assert fn["ep24_conv_ring_timeouts"]() == 0
 
 
 @pytest.mark.parametrize("B,IH,IW,Cout", [(2, 32, 32, 64), (3, 96, 80, 64), (1, 64, 132, 24), (2, 48, 40, 8), (5, 160, 160, 64)])
