@@ -24,6 +24,7 @@ class Exp(BaseExp):
         self.train_ann = "instances_train2017.json"
         self.val_ann = "instances_val2017.json"
         self.synthetic_len = 64          # images per synthetic epoch
+        self.loader_workers = 0          # processes of the synthetic loader (train_24p.py --loader-workers)
         self.synthetic_gts = 10
         # training
         self.warmup_epochs = 5
@@ -59,7 +60,10 @@ class Exp(BaseExp):
         self.model.head.initialize_biases(1e-2)
         return self.model
 
-    def get_data_loader(self, batch_size, raw_u8=False):
+    def get_data_loader(self, batch_size, raw_u8=False, workers=None, pin=None):
+        """``workers``: loader processes (None: ``loader_workers`` of the Exp; collating a 98 MB fp32 batch in the training process
+        itself is what made the trainer host-bound, profiles/r04_trainer.json); ``pin``: page-locked batches (None: off - on the
+        MI355X boxes host writes into page-locked memory measured slower than the pageable upload they save)."""
         from datasets import SyntheticDataset, raw_collate
         import torch
         import os
@@ -68,11 +72,13 @@ class Exp(BaseExp):
         sampler = None
         if world > 1:                                     # every rank walks its own shard of the epoch
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
+        workers = int(getattr(self, "loader_workers", 0) if workers is None else workers)
+        kw = dict(batch_size=batch_size, num_workers=workers, drop_last=True, sampler=sampler, pin_memory=bool(pin))
+        if workers > 0:
+            kw.update(persistent_workers=True, prefetch_factor=2)
         if raw_u8:                                        # lists of uint8 images + label rows: letterboxed on the GPU by the prefetcher
-            return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, drop_last=True, sampler=sampler,
-                                               collate_fn=raw_collate)
-        return torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, num_workers=0, pin_memory=True, drop_last=True,
-                                           sampler=sampler)
+            kw["collate_fn"] = raw_collate
+        return torch.utils.data.DataLoader(self.dataset, **kw)
 
     def random_resize(self, data_loader=None, epoch=None):
         """A multiscale input size, multiple of 32, aspect ratio of input_size (exp/yolox_base.py:93-107); plans are cached per size."""

@@ -60,7 +60,7 @@ class Trainer:
                   "scope; the synthetic source with the same label layout is used (--synthetic)")
         if args.raw_u8 and args.no_prefetch:
             raise SystemExit("train_24p.py: --raw-u8 batches are letterboxed by the prefetcher (drop --no-prefetch)")
-        self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=True) if args.raw_u8 else exp.get_data_loader(args.batch_size)
+        self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=bool(args.raw_u8), workers=args.loader_workers, pin=args.loader_pin)
         self.loss_func = Loss_Function(exp.num_classes)
         self.loss_func.draw = False
 
@@ -137,6 +137,12 @@ class Trainer:
                 if args.throughput_json and args.steps and self.run_steps == args.steps - args.throughput_window:
                     torch.cuda.synchronize()
                     tp_t0, tp_seen = time.perf_counter(), 0
+                    host = {"loader_and_upload": 0.0, "step_enqueue": 0.0, "rest": 0.0}
+                    t_mark = tp_t0
+                elif tp_t0 is not None:                   # host time of the window by phase: what the loop's own thread spends where
+                    now = time.perf_counter()
+                    host["loader_and_upload"] += now - t_mark
+                    t_mark = now
                 self.current_step += 1
                 self.run_steps += 1
                 if self.lr_scheduler is not None:
@@ -164,8 +170,15 @@ class Trainer:
                 seen += images.shape[0]
                 if tp_t0 is not None:
                     tp_seen += images.shape[0]
+                    now = time.perf_counter()
+                    host["step_enqueue"] += now - t_mark
+                    t_mark = now
                 if self.current_step % args.log_interval == 0:
                     self.TB_data(res, seen * self.world / (time.time() - t0))
+                if tp_t0 is not None:
+                    now = time.perf_counter()
+                    host["rest"] += now - t_mark
+                    t_mark = now
                 if args.steps and self.run_steps >= args.steps:
                     done = True
                     break
@@ -185,7 +198,9 @@ class Trainer:
                 rec = {"images_per_s": round(tp_seen * self.world / dt, 2), "ms_per_step": round(dt / max(args.throughput_window, 1) * 1e3, 3),
                        "window_steps": args.throughput_window, "run_steps": self.run_steps, "batch_per_gpu": args.batch_size, "world": self.world,
                        "input_size": list(self.input_size), "prefetch": not args.no_prefetch, "raw_u8": bool(args.raw_u8),
-                       "captured_step": step_fn is not None, "log_interval": args.log_interval, "exp_file": args.exp_file}
+                       "captured_step": step_fn is not None, "log_interval": args.log_interval, "exp_file": args.exp_file,
+                       "loader_workers": self.train_loader.num_workers, "loader_pin": bool(self.train_loader.pin_memory),
+                       "host_ms_per_step": {k: round(v / max(args.throughput_window, 1) * 1e3, 3) for k, v in host.items()}}
                 with open(args.throughput_json, "w") as fh:
                     json.dump(rec, fh)
                 print("throughput %s" % json.dumps(rec))
@@ -266,6 +281,8 @@ def make_parser():
     p.add_argument("--ema", action="store_true", help="keep a ModelEMA copy of the model (saved as ema_model)")
     p.add_argument("--l1", action="store_true", help="switch use_l1 on from epoch exp.L1_epoch")
     p.add_argument("--prefetch", action="store_true", help="(default since round 4; kept for old command lines) upload the next batch on a side stream: ep24.input.DataPrefetcher")
+    p.add_argument("--loader-workers", default=None, type=int, help="processes of the synthetic loader (default: the Exp's loader_workers)")
+    p.add_argument("--loader-pin", action="store_true", help="page-locked batches from the loader (off: pageable upload)")
     p.add_argument("--no-prefetch", action="store_true", help="the reference's loop: upload every batch on the compute stream (train_24p.py:86-88)")
     p.add_argument("--raw-u8", action="store_true", help="the synthetic source hands over uint8 HWC images + normalised label rows; letterbox and label "
                    "scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")

@@ -7,23 +7,29 @@ OUT=$R/${1:-gpurun_out/trainer}
 mkdir -p $OUT
 cd $R/exploration-of-potential_amd/yolox_24p
 COMMON="-f load_train/yolox_24p_l_train.py -b 20 -l 0.01 --synthetic --steps 250 --synthetic-len 6000 --log-interval 50 --output-dir $OUT/run"
-python3 train_24p.py $COMMON --throughput-json $OUT/tp_prefetch.json > $OUT/prefetch.log 2>&1
-echo "prefetch (default) done"
-python3 train_24p.py $COMMON --raw-u8 --throughput-json $OUT/tp_raw_u8.json > $OUT/raw_u8.log 2>&1
-echo "raw-u8 done"
-python3 train_24p.py $COMMON --no-prefetch --throughput-json $OUT/tp_no_prefetch.json > $OUT/no_prefetch.log 2>&1
-echo "no-prefetch done"
+run() {   # name, flags
+  n=$1; shift
+  timeout -k 10 300 python3 train_24p.py $COMMON "$@" --throughput-json $OUT/tp_$n.json > $OUT/$n.log 2>&1
+  echo "$n done"
+}
+run prefetch
+run prefetch_w4 --loader-workers 4
+run prefetch_w4_pin --loader-workers 4 --loader-pin
+run raw_u8 --raw-u8
+run raw_u8_w4 --raw-u8 --loader-workers 4
+run no_prefetch --no-prefetch
 rm -rf $OUT/run
 cd $R
 python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_sustained.json 2> $OUT/bench.err
 python3 - <<PY
 import json
+MODES = ("prefetch", "prefetch_w4", "prefetch_w4_pin", "raw_u8", "raw_u8_w4", "no_prefetch")
 o = {"command": "tools/trainer_timing.sh: train_24p.py -f load_train/yolox_24p_l_train.py -b 20 -l 0.01 --synthetic --steps 250 --synthetic-len 6000 --log-interval 50 [mode]; window = the last 200 steps, synchronised at both ends"}
-for k in ("prefetch", "raw_u8", "no_prefetch"):
+for k in MODES:
     o[k] = json.load(open("$OUT/tp_%s.json" % k))
 b = json.loads([l for l in open("$OUT/bench_sustained.json") if l.startswith("{")][0])
 o["bench_py_same_box"] = {"images_per_s": b["value"], "ms_per_step": b["ms_per_step"], "steps": b["steps"], "warmup": b["warmup"]}
-for k in ("prefetch", "raw_u8", "no_prefetch"):
+for k in MODES:
     o[k]["vs_bench"] = round(o[k]["images_per_s"] / b["value"], 4)
 json.dump(o, open("$OUT/trainer.json", "w"), indent=1)
 print(json.dumps(o, indent=1))
