@@ -158,9 +158,9 @@ def instrumented_step(ts):
         assert kid >= 0, (name, _lib.lib().last_error())
         if kid == 3 and ((name.endswith("_ex") and (args[-1] & 8)) or name.startswith("conv_dgrad_bnr")):
             kid = 1                                        # kernel_opts bit 3 / the fused BatchNorm sums: the 8-wave halo-patch kernel
-        if name.endswith("_ex") and (args[-1] & 16) and kid == 0:      # kernel_opts bit 4: the ring without a patch where the shape fits it
+        if name.endswith("_ex") and (((args[-1] & 16) and kid == 0) or (args[-1] & 64)):      # bit 4: the ring without a patch; bit 6: the narrow ring
             kid = fn["ep24_conv_kernel_for_ex"](0 if fwd else 1, B, H, W, Cin, Cout, k, s, int(bool(fwd and args[5] != 0)), int(bool(fwd and args[8] is not None)), args[-1])
-        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel", "conv_ring_kernel", "conv_ring_generic_kernel")[kid]
+        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel", "conv_ring_kernel", "conv_ring_generic_kernel", "conv_ring_kernel")[kid]
 
     convs = [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]
     for (name, fl, e0, e1, by), (_, args) in zip(rec, convs):

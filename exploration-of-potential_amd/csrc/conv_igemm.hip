@@ -21,6 +21,7 @@ constexpr int KOPT_GRING = 16;             // bit 4: layers of the tiled kernel 
                                            // profiles/r04_ring_generic_ab.txt: an A/B option, off by default)
 constexpr int KOPT_RING32 = 32;            // bit 5: the ring's consumers multiply with v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (an A/B option: 12 % fewer
                                            // cycles per step, a 9 % lower clock under load - slower in the step, profiles/r04_ring_ab.txt)
+constexpr int KOPT_NARROW = 64;            // bit 6: A/B option - 3x3 stride-1 layers in the ring with the NARROW tile (256 x 64; also the 20 x 20 level and N = 64)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -483,7 +484,7 @@ int check_extents(const IgemmArgs& a) {
     return EP24_OK;
 }
 
-// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming, 3 loader / consumer ring)
+// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming, 3 loader / consumer ring, 4 ring without a patch, 5 narrow ring)
 void prepare(IgemmArgs& a, int kernel_opts) {
     a.narrow_epi = (kernel_opts & KOPT_NARROW_EPI) ? 1 : 0;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
@@ -539,8 +540,13 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer &&
         !(kernel_opts & KOPT_TILED)) {
         int prc = EP24_OK;
-        if (!(kernel_opts & KOPT_PATCH8) && launch_ring(a, stream, dry, &prc, (kernel_opts & KOPT_RING32) == 0)) {
-            if (dry) { *kernel_id = 3; return EP24_OK; }
+        int ring = 0;
+        if (!(kernel_opts & KOPT_PATCH8)) {
+            if (kernel_opts & KOPT_NARROW) ring = launch_ring(a, stream, dry, &prc, true, true);
+            if (!ring) ring = launch_ring(a, stream, dry, &prc, (kernel_opts & KOPT_RING32) == 0, false);
+        }
+        if (ring) {
+            if (dry) { *kernel_id = ring == 2 ? 5 : 3; return EP24_OK; }
             if (prc) return prc;
             EP24_LAUNCH_CHECK("ep24_conv_ring");
             return EP24_OK;

@@ -55,8 +55,15 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }          // compiler barrier: no memory access moves across
 
-__device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void st_flag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The counters are addressed as LDS (address space 3) objects.  Through generic pointers (the first form) every access was a FLAT
+// instruction: it counts on vmcnt AND lgkmcnt, so the compiler drained both before using the value - a consumer's look at the FULL
+// counters stalled on every fragment read in flight, and a loader's poll of the FREE counters waited for every DMA it had in flight
+// (running further ahead made the loaders slower, which is how it was found: stamps of the narrow tile, round 4).
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+__device__ __forceinline__ unsigned ld_flag(const lds_u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_flag(lds_u32* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ v4u ld_flags4(const lds_u32* p) { return *reinterpret_cast<const volatile lds_v4u*>(p); }
 
 // One MFMA with its accumulator tile in the ACCUMULATOR half of the register file, destination = source.  Left to the builtin the
 // compiler kept all 128 accumulator registers in the VGPR class, gave most MFMAs a destination different from their C operand (tiles
@@ -83,7 +90,7 @@ __device__ __forceinline__ void mfma32_acc(f32x16_& c, const bf16x8& a, const bf
 }
 
 // min over the four counters; the words sit in one 16-byte line, every lane reads the same addresses (broadcast)
-__device__ __forceinline__ unsigned min4(const unsigned* f) {
+__device__ __forceinline__ unsigned min4(const lds_u32* f) {
     const unsigned a = ld_flag(f), b = ld_flag(f + 1), c = ld_flag(f + 2), d = ld_flag(f + 3);
     return __builtin_amdgcn_readfirstlane(min(min(a, b), min(c, d)));
 }
@@ -96,7 +103,7 @@ __device__ __forceinline__ unsigned min4(const unsigned* f) {
 #endif
 
 // bounded wait until min(f[0..3]) >= need
-__device__ __forceinline__ void spin_until(const unsigned* f, unsigned need, unsigned* err) {
+__device__ __forceinline__ void spin_until(const lds_u32* f, unsigned need, lds_u32* err) {
     int tries = 0;
     while (min4(f) < need) {
         if constexpr ((RING_VAR & 2) != 0) { if (threadIdx.x >= NCW * 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1); }
@@ -109,6 +116,7 @@ __device__ __forceinline__ void spin_until(const unsigned* f, unsigned need, uns
     cbar();
 }
 
+template <int TBN>
 __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int n0, char* smem);
 
 // Epilogue with all eight waves (16-byte store path only).  The stamps of the first form - the four consumers alone, each staging and
@@ -117,20 +125,22 @@ __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int
 // areas ([128 rows][128 B], 16-byte chunk index XOR (row & 7), as igemm_epilogue) and keep the BatchNorm statistics of what they
 // rounded FROM (fp32, as the tiled kernels); after a barrier every wave stores 8 chunks per lane, 8 lanes per 128-byte row segment.
 // Same values, same statistics and the same order of the fixed-point sums as igemm_epilogue: bit-identical outputs.
-__device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][NT], const bool consumer, long m0, int n0, int tile_m, char* smem) {
+// TBN = 64 (the narrow tile, 256 x 64): the four consumers hold 64 x 64 pieces stacked over the rows, CMT = 4.
+template <int TBN, int CMT>
+__device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[CMT][NT], const bool consumer, long m0, int n0, int tile_m, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                         // every wave is out of the main loop: LDS is free
     if (consumer) {
-        const int wm = wave >> 1;
-        char* stg = smem + wave * (MT * 16 * 128);
+        const int wm = TBN == 128 ? wave >> 1 : wave;
+        char* stg = smem + wave * (CMT * 16 * 128);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < CMT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + 4 * fq + r;
-                const bool live = m0 + wm * (MT * 16) + row < p.M;
+                const bool live = m0 + wm * (CMT * 16) + row < p.M;
                 bf16x4 w;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -143,7 +153,7 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
         }
     }
     __syncthreads();
-    ring_store_tile(p, m0, n0, smem);
+    ring_store_tile<TBN>(p, m0, n0, smem);
     if (p.stats) {
         __syncthreads();                                     // the staging areas have been read
         float* red = reinterpret_cast<float*>(smem);         // [NCW waves][2][64]
@@ -161,12 +171,17 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
         }
         __syncthreads();
         long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
-        if (tid < 2 * RBN) {
-            const int which = tid / RBN, c = tid - which * RBN;
+        if (tid < 2 * TBN) {
+            const int which = tid / TBN, c = tid - which * TBN;
             const int wcol = c >> 6;
             float v = 0.f;
+            if constexpr (TBN == 128) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) v += red[((r * 2 + wcol) * 2 + which) * 64 + (c & 63)];
+                for (int r = 0; r < 2; ++r) v += red[((r * 2 + wcol) * 2 + which) * 64 + (c & 63)];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NCW; ++r) v += red[(r * 2 + which) * 64 + c];
+            }
             if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
         }
     }
@@ -174,20 +189,22 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[M
 
 // The staged 256 x 128 bf16 tile (four areas of [128 rows][128 B], 16-byte chunk index XOR (row & 7)) leaves as 16-byte stores, eight
 // chunks per lane of all eight waves, 8 lanes per 128-byte row segment.  Called behind the barrier that follows the staging writes.
+template <int TBN>
 __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int n0, char* smem) {
     const int tid = threadIdx.x;
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 && p.dbs == (long)p.GH * p.GW);
-    constexpr int CPT = NCW * MT * 16 * 8 / ((NCW + NLW) * 64);      // 16-byte chunks per thread: 8
+    constexpr int CMT = TBN == 128 ? 8 : 4;
+    constexpr int CPT = NCW * CMT * 16 * 8 / ((NCW + NLW) * 64);     // 16-byte chunks per thread: 8 (4 for the narrow tile)
     bf16* dptr[CPT];
     bf16x8 val[CPT], old[CPT];
     bool ok[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = k * ((NCW + NLW) * 64) + tid;
-        const int area = c >> 10, row = (c >> 3) & 127, ch = c & 7;
-        val[k] = *reinterpret_cast<const bf16x8*>(smem + area * (MT * 16 * 128) + row * 128 + ((ch ^ (row & 7)) << 4));
-        const long m = m0 + (area >> 1) * (MT * 16) + row;
-        const int cc = n0 + (area & 1) * 64 + ch * 8;
+        const int area = TBN == 128 ? c >> 10 : c >> 9, row = (c >> 3) & (CMT * 16 - 1), ch = c & 7;
+        val[k] = *reinterpret_cast<const bf16x8*>(smem + area * (CMT * 16 * 128) + row * 128 + ((ch ^ (row & 7)) << 4));
+        const long m = m0 + (TBN == 128 ? area >> 1 : area) * (CMT * 16) + row;
+        const int cc = n0 + (TBN == 128 ? (area & 1) * 64 : 0) + ch * 8;
         ok[k] = m < p.M && cc < p.N;
         long dpix = ok[k] ? m : 0;
         if (!fast_dst) {
@@ -249,7 +266,7 @@ __device__ __forceinline__ void ring_epilogue32(const IgemmArgs& p, f32x16_ (&ac
         }
     }
     __syncthreads();
-    ring_store_tile(p, m0, n0, smem);
+    ring_store_tile<128>(p, m0, n0, smem);
     if (p.stats) {
         __syncthreads();                                     // the staging areas have been read
         constexpr int LP = 33;                               // 32 lanes + 1: lanes of one channel on consecutive banks
@@ -289,24 +306,34 @@ __device__ __forceinline__ void ring_epilogue32(const IgemmArgs& p, f32x16_ (&ac
 // instruction's lane groups), which row & 7 is not for this fragment shape; the weight rows sit in natural channel order (a
 // register quad of D is four consecutive channels already); the sum over a 64-channel chunk runs in four k-steps of 16 instead of
 // two of 32, so results differ from the tiled kernel in the last bit of the fp32 sums (and agree run to run, bit for bit).
-template <int PPS, bool M32>
+//
+// TBN = 64: the NARROW tile, 256 pixels x 64 channels, for the layers that 256 x 128 tiles do not spread over the chip (the 20 x 20
+// level at B = 20: 128 tiles) or whose N is 64.  Consumers are stacked over the rows (64 x 64 each, 4 x 4 accumulator tiles): a step is
+// 8 groups of 4 MFMAs and 16 fragment reads, LDS read bandwidth and MFMA issue in balance (512 cycles each), so the loaders run TWO
+// steps ahead here (the next step's DMAs are issued before the wait for this step's: one step per round trip would bound the loop).
+template <int PPS, bool M32, int TBN = RBN>
 __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const IgemmArgs p, const int NP, const int halo, const int npb) {
+    static_assert(TBN == 128 || (TBN == 64 && !M32), "tile widths: 128, or 64 with the 16 x 16 consumers");
+    constexpr int CMT = TBN == 128 ? MT : 4;                 // accumulator row tiles per consumer
+    constexpr int TB_BYTES = TBN * 128;                      // one weight tile: [TBN channels][64 k] bf16
+    constexpr int TB_INSTR = TBN / 8 / NLW;                  // weight-tile DMA instructions per loader and step
+    constexpr int TNS = TBN == 128 ? NS : 9;                 // weight ring stages; the narrow tile: one per tap (8 KB each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
     const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int tiles_n = (p.N + RBN - 1) / RBN;
+    const int tiles_n = (p.N + TBN - 1) / TBN;
     const int tile_m = tile_id / tiles_n;
     const long m0 = (long)tile_m * RBM;
-    const int n0 = (tile_id - tile_m * tiles_n) * RBN;
+    const int n0 = (tile_id - tile_m * tiles_n) * TBN;
     const int KC = (p.K + BK - 1) / BK;
     // LDS: [128 zero bytes][patch buffers: npb x NP pieces of 8 rows x 128 B][weight ring: 3 x 16 KB][counters]
     const int PBYTES = NP * 1024;
     const int bb = npb * PBYTES;                             // offset of the weight ring behind ZB
-    unsigned* const flags = reinterpret_cast<unsigned*>(smem + ZB + bb + NS * B_BYTES);
-    unsigned* const f_full = flags;                          // [NLW]
-    unsigned* const f_free = flags + 4;                      // [NCW]
-    unsigned* const f_err = flags + 8;
+    unsigned* const flags = reinterpret_cast<unsigned*>(smem + ZB + bb + TNS * TB_BYTES);
+    lds_u32* const f_full = (lds_u32*)(lptr_t)flags;         // [NLW]
+    lds_u32* const f_free = f_full + 4;                      // [NCW]
+    lds_u32* const f_err = f_full + 8;
     // taps in row-major order; forward reads pixel (y + ty - 1, x + tx - 1), the input gradient (y + 1 - ty, x + 1 - tx)
     const int sgn = p.oy[0] < 0 ? 1 : -1;
 
@@ -322,7 +349,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     // the 16-byte store path of the epilogue (bf16 output, rows aligned): uniform over the launch
     const bool wide = !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(p.dst) & 15) == 0;
 
-    f32x4 acc[MT][NT];                                       // consumers only; zeros in the loaders (one epilogue call site for both)
+    f32x4 acc[MT][NT];                                       // consumers only; zeros in the loaders (one epilogue call site for both);
+                                                             // the narrow tile uses rows 0..3, the rest folds away
     f32x16_ acc32[2][4];                                     // M32: [channel tile][pixel tile]; whichever form is unused folds away
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -369,10 +397,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
             const int vo = ok ? (int)((odd ? pv0_odd : pv0) + (unsigned)(8 * g * ld2 + kc * (BK * 2))) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lptr_t)(smem + ZB + pbuf_off + g * 1024), 16, vo, 0, 0, 0);
         };
-        int wvoff[B_INSTR];
+        int wvoff[TB_INSTR];
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int q = (lw * B_INSTR + i) * 8 + (lane >> 3);
+        for (int i = 0; i < TB_INSTR; ++i) {
+            const int q = (lw * TB_INSTR + i) * 8 + (lane >> 3);
             // 16 x 16 form: channel relabelling of the shared epilogue; M32: natural order (piece lw * 4 + i is odd when i is)
             const int r = M32 ? q : (q & ~63) + ((q & 15) << 2) + ((q >> 4) & 3);
             const int lc = (i & 1) ? lchunk_odd : lchunk;
@@ -381,15 +409,65 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
         auto issue_b = [&](int stage, int t, int kc) {
             const int b_s = (t * p.K + kc * BK) * 2;
 #pragma unroll
-            for (int i = 0; i < B_INSTR; ++i) {
+            for (int i = 0; i < TB_INSTR; ++i) {
                 int vo = wvoff[i] == OOB ? OOB : wvoff[i] + b_s;
                 if (kc >= ktail) vo = kc < ((i & 1) ? kmax_odd : kmax) ? vo : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(smem + ZB + bb + stage * B_BYTES + (lw * B_INSTR + i) * 1024), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lptr_t)(smem + ZB + bb + stage * TB_BYTES + (lw * TB_INSTR + i) * 1024), 16, vo, 0, 0, 0);
             }
         };
         // the whole patch of chunk 0 first: the wait behind the first weight tile covers it
         for (int i = 0; i < NPW; ++i) issue_patch(0, 0, i);
         unsigned j = 0;
+        if constexpr (TBN == 64) {
+            // DEPTH + 1 steps in flight: a consumer step is ~600 - 900 cycles here and a DMA round trip 1 - 3 k (the 20 x 20 layers'
+            // weights do not fit one XCD's L2), so the loaders run DEPTH steps ahead of the step they wait for; the ring has a stage
+            // per tap (stage = tap) and the wait is counted exactly (loads return in order): the DMAs of the steps behind step jj stay
+            // outstanding.  Patch pieces of the next chunk ride on taps >= S0 = DEPTH, so that running ahead never waits for the
+            // consumers to leave the buffer they go to (chunk kc - 1's: read once min(free) >= 9 kc).
+            constexpr int DEPTH = 5, S0 = 5;
+            const int nsteps = 9 * KC;
+            int t1 = 0, kc1 = 0, nissued = 0;                  // (tap, chunk) of the next step to issue
+            auto issue_step = [&]() {
+                if (nissued >= TNS) spin_until(f_free, (unsigned)(nissued - (TNS - 1)), f_err);
+                issue_b(t1, t1, kc1);
+                if (kc1 + 1 < KC && t1 >= S0) {
+                    if (kc1 >= 1) spin_until(f_free, (unsigned)(9 * kc1), f_err);
+                    const int pn = ((kc1 + 1) & 1) * PBYTES;
+#pragma unroll
+                    for (int i = 0; i < PPS; ++i) issue_patch(pn, kc1 + 1, (t1 - S0) * PPS + i);
+                }
+                if (++t1 == 9) { t1 = 0; ++kc1; }
+                ++nissued;
+            };
+            auto wait_n = [&](int n) {                         // s_waitcnt takes an immediate
+                switch (n) {
+#define EP24_WCASE(N) case N: wait_vmcnt_c<N>(); break;
+                    EP24_WCASE(0) EP24_WCASE(1) EP24_WCASE(2) EP24_WCASE(3) EP24_WCASE(4) EP24_WCASE(5) EP24_WCASE(6) EP24_WCASE(7)
+                    EP24_WCASE(8) EP24_WCASE(9) EP24_WCASE(10) EP24_WCASE(11) EP24_WCASE(12) EP24_WCASE(13) EP24_WCASE(14) EP24_WCASE(15)
+                    EP24_WCASE(16) EP24_WCASE(17) EP24_WCASE(18) EP24_WCASE(19) EP24_WCASE(20) EP24_WCASE(21) EP24_WCASE(22) EP24_WCASE(23)
+                    EP24_WCASE(24) EP24_WCASE(25)
+#undef EP24_WCASE
+                    default: wait_vmcnt_c<0>(); break;
+                }
+            };
+            static_assert(DEPTH * (TB_INSTR + PPS) <= 25 && DEPTH <= TNS - 2, "counted wait range / ring depth");
+            for (int i = 0; i <= DEPTH && i < nsteps; ++i) issue_step();
+            int tj = 1, kj = 0;                                // (tap, chunk) of step jj + 1
+#pragma unroll 1
+            for (int jj = 0; jj < nsteps; ++jj) {
+                int n = 0, ts = tj, ks = kj;
+                for (int q = jj + 1; q < nissued; ++q) {
+                    n += TB_INSTR + ((ks + 1 < KC && ts >= S0) ? PPS : 0);
+                    if (++ts == 9) { ts = 0; ++ks; }
+                }
+                wait_n(n);
+                if (lane == 0) st_flag(f_full + lw, (unsigned)(jj + 1));
+                cbar();
+                if (nissued < nsteps) issue_step();
+                if (++tj == 9) { tj = 0; ++kj; }
+            }
+            return;
+        }
         for (int kc = 0; kc < KC; ++kc) {
             const int pnext = ((kc + 1) & 1) * PBYTES;
             const bool more = kc + 1 < KC;
@@ -554,7 +632,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
                         fb0[g - G_CHECK] = lds_frag(bsn + (g - G_CHECK) * 2048);
                     }
                     if constexpr (g == G_FLAGS) {
-                        fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                        fl = ld_flags4(f_full);
                     }
                     if constexpr (gr == 15) {
                         // every fragment read of this step is issued (LDS executes a wave's operations in order): its ring stage
@@ -591,6 +669,148 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     }
 #ifdef EP24_STAMPS
     st_t2 = STAMP();
+#endif
+    };
+
+    // ======================================================================= CONSUMER of the narrow tile (TBN = 64)
+    // Consumer cw multiplies rows [64 cw, 64 cw + 64) with all 64 channels.  A step is 8 groups of 4 MFMAs (k half h = g / 4, fragment
+    // row i = g % 4); the A fragment of a group is requested 4 groups earlier, this step's second-half weight fragments in groups 0 - 1,
+    // the next step's first-half ones in groups 4 - 5 behind the FULL check of group 4 (flags requested in group 2).
+    auto consumer_main_narrow = [&]() {
+        const int cw = wave;
+        const int frow = lane & 15, fq = lane >> 4;
+        unsigned vmp[2] = {0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + cw * 64 + i * 16 + frow;
+            unsigned mk = 0;
+            if (m < p.M) {
+                const int mm = (int)m;
+                const int n = fdiv(mm, p.d_plane);
+                const int rem = mm - n * (p.GH * p.GW);
+                const int y = fdiv(rem, p.d_gw), x = rem - y * p.GW;
+                unsigned rowm = 0x038u, colm = 0x092u;
+                if (y - sgn >= 0 && y - sgn < p.SH) rowm |= 0x007u;
+                if (y + sgn >= 0 && y + sgn < p.SH) rowm |= 0x1C0u;
+                if (x - sgn >= 0 && x - sgn < p.SW) colm |= 0x049u;
+                if (x + sgn >= 0 && x + sgn < p.SW) colm |= 0x124u;
+                mk = rowm & colm;
+            }
+            vmp[i >> 1] |= mk << (9 * (i & 1));
+        }
+        const int arow0 = cw * 64 + frow + halo;
+        const int bo0 = ZB + bb + frow * 128 + ((fq ^ (frow & 7)) << 4);
+        auto tap_addr = [&](int pbuf_off, int sh) {
+            const int q0 = arow0 + sh;
+            return ZB + pbuf_off + q0 * 128 + ((fq ^ (q0 & 7)) << 4);
+        };
+        auto row_addr = [&](int ta, int i, int t) {
+            const int m = __builtin_amdgcn_sbfe((int)vmp[i >> 1], (unsigned)(9 * (i & 1) + t), 1u);      // 0 or -1
+            return (ta + i * 2048) & m;
+        };
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag_p;
+        auto lds_frag = [&](int off) { return *reinterpret_cast<lds_frag_p>((unsigned long)(unsigned)off); };
+        auto pin = [](int& v) { asm volatile("" : "+v"(v)); };
+        auto mma_row = [&](int i, const bf16x8& fa, const bf16x8 (&fb)[NT]) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) mfma_acc(acc[i][q], fa, fb[q]);
+        };
+#ifdef EP24_STAMPS
+        st_t0 = STAMP(); st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        spin_until(f_full, 1u, f_err);
+        bf16x8 pa[4], fb0[NT], fb1[NT];
+        int ra[4];
+        {
+            const int ta = tap_addr(0, sgn * (-p.SW - 1));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = row_addr(ta, i, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pa[g] = lds_frag(ra[g]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) fb0[q] = lds_frag(bo0 + q * 2048);
+#ifdef EP24_STAMPS
+        st_t1 = STAMP();
+#endif
+        unsigned j = 0;
+        for (int kc = 0; kc < KC; ++kc) {
+            const int pcur = (npb == 2) ? (kc & 1) * PBYTES : 0;
+            const int pnext = ((kc + 1) & 1) * PBYTES;
+            const bool more = kc + 1 < KC;
+#pragma unroll 1
+            for (int ty = 0; ty < 3; ++ty) {
+                const int shrow = sgn * (ty - 1) * p.SW;
+                auto tap_step = [&](auto txc) {
+                    constexpr int tx = decltype(txc)::value;
+                    const int t = ty * 3 + tx;
+                    const bool last = tx == 2 && ty == 2 && !more;
+                    const int tn = (tx < 2 || ty < 2) ? t + 1 : 0;
+                    const int bst = bo0 + t * TB_BYTES;        // ring stage = tap
+                    const int bsn = bo0 + tn * TB_BYTES;
+                    const int tan = (tx < 2) ? tap_addr(pcur, shrow + sgn * tx)
+                                             : (ty < 2 ? tap_addr(pcur, shrow + sgn * (p.SW - 1))
+                                                       : tap_addr(pnext, sgn * (-p.SW - 1)));
+                    bf16x8 F[4];                               // this step's k half 1 fragments (k half 0 arrives as pa[])
+                    v4u fl = {0u, 0u, 0u, 0u};
+                    auto group = [&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        if constexpr (g == 4) {
+                            if (!last) {
+                                const unsigned have = __builtin_amdgcn_readfirstlane(min(min(fl.x, fl.y), min(fl.z, fl.w)));
+                                if (have < j + 2) {            // this is step j (0-based): the next one must have landed
+#ifdef EP24_STAMPS
+                                    const unsigned long long s0 = STAMP();
+                                    spin_until(f_full, j + 2, f_err);
+                                    st_spin += STAMP() - s0; ++st_nspin;
+#else
+                                    spin_until(f_full, j + 2, f_err);
+#endif
+                                }
+                                cbar();
+                            }
+                        }
+                        if constexpr (g < 4) F[g] = lds_frag(ra[g] ^ 64);
+                        else pa[g - 4] = lds_frag(ra[g - 4]);
+                        if constexpr (g < 2) {
+                            fb1[2 * g] = lds_frag((bst ^ 64) + (2 * g) * 2048);
+                            fb1[2 * g + 1] = lds_frag((bst ^ 64) + (2 * g + 1) * 2048);
+                        }
+                        if constexpr (g == 4 || g == 5) {
+                            fb0[2 * (g - 4)] = lds_frag(bsn + (2 * (g - 4)) * 2048);
+                            fb0[2 * (g - 4) + 1] = lds_frag(bsn + (2 * (g - 4) + 1) * 2048);
+                        }
+                        if constexpr (g == 2) fl = ld_flags4(f_full);
+                        if constexpr (g == 3) {
+                            // every fragment read of this step is issued: its ring stage may be refilled
+                            cbar();
+                            if (lane == 0) st_flag(f_free + cw, j + 1);
+                            cbar();
+                        }
+                        if constexpr (g < 4) mma_row(g, pa[g], fb0);
+                        else mma_row(g - 4, F[g - 4], fb1);
+                        // the next tap's masked row addresses, in place: row i was last used by group i (its k half 1 request) and is next
+                        // needed by group 4 + i (the next step's k half 0 request)
+                        if constexpr (g >= 1 && g < 5) {
+                            constexpr int i = g - 1;
+                            ra[i] = row_addr(tan, i, tn);
+                            pin(ra[i]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
+                    group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+                    group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+                    group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+                    ++j;
+                };
+                tap_step(std::integral_constant<int, 0>{});
+                tap_step(std::integral_constant<int, 1>{});
+                tap_step(std::integral_constant<int, 2>{});
+            }
+        }
+#ifdef EP24_STAMPS
+        st_t2 = STAMP();
 #endif
     };
 
@@ -708,7 +928,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
                             if constexpr (ks < 3) W[ks + 1][pt] = lds_frag(wb[pt][ks + 1] + so);
                             else wp[pt] = lds_frag(wb[pt][0] + son);
                         }
-                        if constexpr (g == G_FLAGS) fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                        if constexpr (g == G_FLAGS) fl = ld_flags4(f_full);
                         if constexpr (g == 9) {
                             // every fragment read of this step is issued (pixel fragments by group 7, the last weight fragments by
                             // group 9): its ring stage may be refilled
@@ -755,13 +975,15 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
         if (consumer) consumer_main32(); else loader_main();
         ring_epilogue32(p, acc32, consumer, m0, n0, tile_m, smem);      // the host admits M32 only with the 16-byte store path
     } else {
-    if (consumer) consumer_main(); else loader_main();
-    // LDS is nobody's any more: the last DMA landed before the last full count.  16-byte store path: all eight waves (the loaders
-    // carry half of the stores); otherwise the loaders are done (a terminated wave no longer counts at s_barrier) and the four
-    // consumers run the shared epilogue as a 2 x 2 grid of 128 x 64 pieces.
-    if (wide) ring_epilogue(p, acc, consumer, m0, n0, tile_m, smem);
-    else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
-    else return;
+        if constexpr (TBN == 64) { if (consumer) consumer_main_narrow(); else loader_main(); }
+        else { if (consumer) consumer_main(); else loader_main(); }
+        // LDS is nobody's any more: the last DMA landed before the last full count.  16-byte store path: all eight waves (the loaders
+        // carry half of the stores); otherwise the loaders are done (a terminated wave no longer counts at s_barrier) and the four
+        // consumers run the shared epilogue (a 2 x 2 grid of 128 x 64 pieces; the narrow tile: four 64 x 64 pieces over the rows).
+        f32x4 (&acc_t)[CMT][NT] = reinterpret_cast<f32x4 (&)[CMT][NT]>(acc);
+        if (wide) ring_epilogue<TBN, CMT>(p, acc_t, consumer, m0, n0, tile_m, smem);
+        else if (consumer) igemm_epilogue<TBN, false, CMT, 0, NCW, false>(p, acc_t, m0, n0, tile_m, smem);
+        else return;
     }
     const int cw = wave; (void)cw;
 #ifdef EP24_STAMPS
@@ -796,9 +1018,9 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
     const int KC = (p.K + BK - 1) / BK;
     const unsigned S = (unsigned)(p.T * KC);                 // steps
     unsigned* const flags = reinterpret_cast<unsigned*>(smem + ZB + NS * GSTAGE);
-    unsigned* const f_full = flags;
-    unsigned* const f_free = flags + 4;
-    unsigned* const f_err = flags + 8;
+    lds_u32* const f_full = (lds_u32*)(lptr_t)flags;
+    lds_u32* const f_free = f_full + 4;
+    lds_u32* const f_err = f_full + 8;
     if (reinterpret_cast<unsigned long>((lptr_t)smem) != 0ul) {
         if (tid == 0) atomicAdd(&g_ring_timeouts, 1u << 16);
         return;
@@ -931,7 +1153,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
                     fb0[g - G_CHECK] = lds_frag(bsn + (g - G_CHECK) * 2048);
                 }
                 if constexpr (g == G_FLAGS) {
-                    fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                    fl = ld_flags4(f_full);
                 }
                 if constexpr (gr == 15) {
                     cbar();
@@ -957,24 +1179,24 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
 
     const bool consumer = wave < NCW;
     if (consumer) consumer_main(); else loader_main();
-    if (wide) ring_epilogue(p, acc, consumer, m0, n0, tile_m, smem);
+    if (wide) ring_epilogue<RBN, MT>(p, acc, consumer, m0, n0, tile_m, smem);
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
 }
 
-template <int PPS, bool M32>
+template <int PPS, bool M32, int TBN = RBN>
 int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, hipStream_t stream) {
-    const unsigned tiles = (unsigned)ep24_cdiv(a.M, RBM) * (unsigned)ep24_cdiv(a.N, RBN);
+    const unsigned tiles = (unsigned)ep24_cdiv(a.M, RBM) * (unsigned)ep24_cdiv(a.N, TBN);
     static std::atomic<unsigned long long> done{0};          // per-device attribute, set once (conv_patch.hip has the reasons)
     int dev = 0;
     EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipGetDevice failed");
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS, M32, TBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KB) failed on device %d: %s", dev,
                      hipGetErrorString(e));
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
+    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32, TBN>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
     return EP24_OK;
 }
 
@@ -1000,27 +1222,40 @@ namespace ep24_igemm {
 // Same shapes as the halo-patch kernel takes (3x3 stride-1, N > 64, >= 200 tiles of 256 x 128, row-major nine-tap table), plus
 // room for the counters behind the weight ring.  The patch is stored in whole 8-row pieces (NP of them), not rounded up to a
 // multiple of the loader count: at W = 80 that is what leaves the 64 bytes (2 x 53 KB + 48 KB + counters < 160 KB).
-bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16) {
+// `narrow_ok` (an A/B option, off by default): the NARROW tile (256 x 64) for every layer with at least 128 of those - also the ones
+// 256 x 128 tiles do not spread over the chip (the 20 x 20 level) or whose N is 64, which otherwise stay with the tiled kernel.
+// Measured slower than what it replaces on every layer.  Returns 0: not this kernel, 1: the 256 x 128 ring, 2: the narrow one.
+int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16, bool narrow_ok) {
     const int sgn = a.oy[0] < 0 ? 1 : -1;
     for (int t = 0; t < 9; ++t)
-        if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return false;
-    if (a.K % 8 != 0 || a.N <= 64) return false;
-    if (a.bnr_z) return false;                               // the fused BatchNorm-backward sums (an A/B option) stay with the 8-wave kernel
-    if ((long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, RBN) < 200) return false;
+        if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return 0;
+    if (a.K % 8 != 0) return 0;
+    if (a.bnr_z) return 0;                                   // the fused BatchNorm-backward sums (an A/B option) stay with the 8-wave kernel
+    const bool narrow = narrow_ok;
+    if (!narrow && (a.N <= 64 || (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, RBN) < 200)) return 0;
+    if (narrow && (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, 64) < 128) return 0;
+    const int tb_bytes = (narrow ? 64 : RBN) * 128;
     const int halo = a.SW + 1;
     const int npb = a.K > BK ? 2 : 1;
     const int np = (RBM + 2 * halo + 7) / 8;
-    const size_t lds = ZB + (size_t)npb * np * 1024 + NS * (size_t)B_BYTES + 64;
+    const int ns = narrow ? 9 : NS;                            // the narrow ring: a stage per tap
+    const size_t lds = ZB + (size_t)npb * np * 1024 + ns * (size_t)tb_bytes + 64;
     const int npw = (np + NLW - 1) / NLW;
-    if (lds > 160 * 1024 || npw > 7 * 3) return false;
-    // the epilogue stages 4 x 16 KB through the patch area
-    if ((size_t)npb * np * 1024 + NS * (size_t)B_BYTES < (size_t)NCW * MT * 16 * 128) return false;
+    // patch pieces of the next chunk ride on taps 2..8 (the narrow ring: 5..8), at most three per loader and step
+    // (a single-chunk layer has no next chunk: its whole patch is requested up front, <= 21 pieces per loader beside 12 weight DMAs)
+    if (lds > 160 * 1024 || npw > ((narrow && npb == 2) ? 4 : 7) * 3) return 0;
+    // the epilogue stages the tile (4 x 16 KB, the narrow one 4 x 8 KB) through the patch area
+    if ((size_t)npb * np * 1024 + ns * (size_t)tb_bytes < (size_t)NCW * (narrow ? 4 : MT) * 16 * 128) return 0;
     if (!dry) {
-        const int pps = (npw + 6) / 7;
+        const int pps = narrow ? (npb == 2 ? (npw + 3) / 4 : 1) : (npw + 6) / 7;
         // the 32 x 32 x 16 consumers need the 16-byte store path (bf16 rows aligned to 16 bytes) and room for the statistics fold
-        const bool m32 = !m16 && !a.narrow_epi && (a.N & 7) == 0 && (a.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(a.dst) & 15) == 0 &&
+        const bool m32 = !narrow && !m16 && !a.narrow_epi && (a.N & 7) == 0 && (a.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(a.dst) & 15) == 0 &&
                          lds >= (size_t)NCW * 2 * 64 * 33 * 4;
-        if (m32)
+        if (narrow)
+            *rc = pps <= 1 ? launch_ring_pps<1, false, 64>(a, np, halo, npb, lds, stream)
+                : pps == 2 ? launch_ring_pps<2, false, 64>(a, np, halo, npb, lds, stream)
+                           : launch_ring_pps<3, false, 64>(a, np, halo, npb, lds, stream);
+        else if (m32)
             *rc = pps <= 1 ? launch_ring_pps<1, true>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, true>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, true>(a, np, halo, npb, lds, stream);
@@ -1029,7 +1264,7 @@ bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool
                 : pps == 2 ? launch_ring_pps<2, false>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, false>(a, np, halo, npb, lds, stream);
     }
-    return true;
+    return narrow ? 2 : 1;
 }
 
 // Generic form: any gather-GEMM with bf16 output, no bias, N > 64 and enough 256 x 128 tiles to fill the chip.

@@ -262,7 +262,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 // conv_ring.hip: the same layers as 4 consumer + 4 loader waves over an LDS ring with FULL / FREE counters (round 4); same contract.
 // m16 (the default): consumers with v_mfma_f32_16x16x32_bf16, bit-identical to the tiled kernel; false: the 32 x 32 x 16 form (A/B option).
-bool launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16 = true);
+// narrow_ok (A/B option): the 256 x 64 tile wherever at least 128 of them exist.  Returns 0: not this kernel, 1: the 256 x 128 ring, 2: the narrow one.
+int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16 = true, bool narrow_ok = false);
 // ... and the ring without a patch, for any other gather-GEMM with bf16 output that fills the chip with 256 x 128 tiles.
 bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 

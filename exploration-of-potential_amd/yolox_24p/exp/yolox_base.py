@@ -24,7 +24,7 @@ class Exp(BaseExp):
         self.train_ann = "instances_train2017.json"
         self.val_ann = "instances_val2017.json"
         self.synthetic_len = 64          # images per synthetic epoch
-        self.loader_workers = 0          # processes of the synthetic loader (train_24p.py --loader-workers)
+        self.loader_workers = 4          # processes of the synthetic fp32 loader (train_24p.py --loader-workers)
         self.synthetic_gts = 10
         # training
         self.warmup_epochs = 5
@@ -61,9 +61,10 @@ class Exp(BaseExp):
         return self.model
 
     def get_data_loader(self, batch_size, raw_u8=False, workers=None, pin=None):
-        """``workers``: loader processes (None: ``loader_workers`` of the Exp; collating a 98 MB fp32 batch in the training process
-        itself is what made the trainer host-bound, profiles/r04_trainer.json); ``pin``: page-locked batches (None: off - on the
-        MI355X boxes host writes into page-locked memory measured slower than the pageable upload they save)."""
+        """``workers``: loader processes (None: ``loader_workers`` of the Exp for ready-made fp32 batches - collating 98 MB per step in
+        the training process itself left the trainer at 0.21 of bench.py, four processes + page-locked batches bring 0.91 - and 0 for
+        the raw uint8 source, whose batches are lists of cached images: 0.96, profiles/r04_trainer.json); ``pin``: page-locked batches
+        (None: with loader processes and fp32 batches only)."""
         from datasets import SyntheticDataset, raw_collate
         import torch
         import os
@@ -72,7 +73,11 @@ class Exp(BaseExp):
         sampler = None
         if world > 1:                                     # every rank walks its own shard of the epoch
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
-        workers = int(getattr(self, "loader_workers", 0) if workers is None else workers)
+        if workers is None:
+            workers = 0 if raw_u8 else getattr(self, "loader_workers", 0)
+        workers = int(workers)
+        if pin is None:
+            pin = workers > 0 and not raw_u8
         kw = dict(batch_size=batch_size, num_workers=workers, drop_last=True, sampler=sampler, pin_memory=bool(pin))
         if workers > 0:
             kw.update(persistent_workers=True, prefetch_factor=2)

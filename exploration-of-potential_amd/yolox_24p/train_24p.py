@@ -60,7 +60,8 @@ class Trainer:
                   "scope; the synthetic source with the same label layout is used (--synthetic)")
         if args.raw_u8 and args.no_prefetch:
             raise SystemExit("train_24p.py: --raw-u8 batches are letterboxed by the prefetcher (drop --no-prefetch)")
-        self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=bool(args.raw_u8), workers=args.loader_workers, pin=args.loader_pin)
+        self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=bool(args.raw_u8), workers=args.loader_workers,
+                                                 pin=None if args.loader_pin is None else bool(args.loader_pin))
         self.loss_func = Loss_Function(exp.num_classes)
         self.loss_func.draw = False
 
@@ -282,7 +283,7 @@ def make_parser():
     p.add_argument("--l1", action="store_true", help="switch use_l1 on from epoch exp.L1_epoch")
     p.add_argument("--prefetch", action="store_true", help="(default since round 4; kept for old command lines) upload the next batch on a side stream: ep24.input.DataPrefetcher")
     p.add_argument("--loader-workers", default=None, type=int, help="processes of the synthetic loader (default: the Exp's loader_workers)")
-    p.add_argument("--loader-pin", action="store_true", help="page-locked batches from the loader (off: pageable upload)")
+    p.add_argument("--loader-pin", default=None, type=int, choices=(0, 1), help="page-locked batches from the loader (default: with loader processes and fp32 batches)")
     p.add_argument("--no-prefetch", action="store_true", help="the reference's loop: upload every batch on the compute stream (train_24p.py:86-88)")
     p.add_argument("--raw-u8", action="store_true", help="the synthetic source hands over uint8 HWC images + normalised label rows; letterbox and label "
                    "scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")

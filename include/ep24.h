@@ -64,7 +64,10 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * the ring without a patch (measured slower on every layer of YOLOX-l at B = 20: off by default); bit 5: the ring's consumers
  * multiply with v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_16x16x32_bf16 (same products; the fp32 sum of a 64-channel chunk in
  * four steps of 16 instead of two of 32, so results differ from the other kernels in the last bit; fewer cycles, lower clock: an
- * A/B option).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * A/B option); bit 6: the ring with its NARROW tile (256 pixels x 64 channels, four consumers of 64 x 64, a weight-ring stage per
+ * tap and loaders five steps ahead) for every 3x3 stride-1 layer with at least 128 such tiles - also the 20 x 20 level and N = 64,
+ * which the 256 x 128 ring does not take (bit-identical results; measured slower than the tiled kernel it would replace: an A/B
+ * option).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
@@ -92,7 +95,7 @@ int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void
  * library's own dispatch rule, for reports (bench.py attributes launch times to kernels with it).  Returns 0 =
  * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch, 8 waves in lockstep), 2 = igemm_stream_kernel (1x1
  * streaming), 3 = conv_ring_kernel (halo patch as a loader / consumer ring), 4 = conv_ring_generic_kernel (the ring without a
- * patch; only with kernel_opts bit 4), < 0 on error.
+ * patch; only with kernel_opts bit 4), 5 = conv_ring_kernel with the narrow tile (only with kernel_opts bit 6), < 0 on error.
  * y_f32 / has_bias as in ep24_conv_fwd_bf16 (both 0 for dgrad). */
 int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias);
 /* ... and for the _ex entry points with the given kernel_opts. */

@@ -122,6 +122,11 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # the ring without a patch (round 4; kernel_opts bit 4; an 8th value is the kernel id the shape must dispatch to with it): the 4-step 1x1 layer of the
     # 40x40 level, a 1x1 layer with M, N and K tails, a stride-2 3x3 layer with a K tail
     (20, 40, 256, 256, 1, 1, 40, 4), (13, 50, 200, 264, 1, 1, 47, 4), (20, 90, 72, 136, 3, 2, 86, 4),
+    # the NARROW ring (256 x 64 tiles, kernel_opts bit 6, an A/B option; a 9th value = the kernel_opts the id is asked under): the 20 x 20
+    # level of YOLOX-l, which 256 x 128 tiles do not spread over the chip; M and N tails; a K tail over two patch buffers; N = 64 with one chunk and the widest patch
+    # (W = 160: three patch pieces per loader and step); N = 64 with an M tail
+    (20, 20, 512, 512, 3, 1, 20, 5, 64), (21, 20, 256, 200, 3, 1, 19, 5, 64), (21, 20, 72, 256, 3, 1, 19, 5, 64), (4, 160, 64, 64, 3, 1, 160, 5, 64),
+    (7, 52, 64, 64, 3, 1, 100, 5, 64), (20, 40, 256, 256, 3, 1, 40, 5, 64),
 ]
 
 
@@ -154,7 +159,9 @@ def test_conv_hot_shapes(shape):
     y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
     M = B * OH * OW
     if len(shape) > 7:
-        assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 16) == shape[7]
+        assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, shape[8] if len(shape) > 8 else 16) == shape[7]
+        if shape[7] == 5:                                                  # ... which no layer takes by default
+            assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 0) in (0, 1, 3)
     elif len(shape) > 6:
         want = 3 if k == 3 else 2                                         # 3: the loader / consumer ring (round 4), 2: streaming
         assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == want, "meant to exercise the ring / streaming kernel's tails"
@@ -169,7 +176,7 @@ def test_conv_hot_shapes(shape):
     # ring of conv_ring.hip where it fits), bit 3 = the 8-wave halo-patch kernel instead, bit 0 = the generic tiled kernel
     # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
-    variants = ((2, 0), (3, 32), (1, 8), (0, 1)) if (k == 3 and s == 1) else ((2, 0), (0, 16))
+    variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64)) if (k == 3 and s == 1) else ((2, 0), (0, 16))      # key 4: the narrow ring where it fits
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
@@ -192,7 +199,7 @@ def test_conv_hot_shapes(shape):
     # gradients (plain and accumulated), whichever kernel ran; the batch statistics are sums of per-tile fp32 partial sums, and the
     # tiles differ (256 rows against 128): equal to fp32 summation order
     for other in outs:
-        if other == 3:
+        if other == 3 and fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 32) == 3:
             # The 32x32x16 consumers add the SAME products, the fp32 sum of a 64-channel chunk in four k-steps of 16 instead of two of
             # 32: fp32 sums agree to rounding, so after the one rounding to bf16 an element differs by at most one bf16 ulp (2^-8
             # relative; an element that is itself a cancelled sum by 1e-5 of the tensor's range), and only a few per cent do at all.

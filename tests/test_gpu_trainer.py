@@ -19,6 +19,8 @@ def _train(cwd_out, *extra):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(Y24, "train_24p.py"), "-f", os.path.join(Y24, "load_train", "yolox_24p_train.py"),
            "-b", "4", "-l", "0.01", "--synthetic", "--log-interval", "1", "--output-dir", cwd_out] + list(extra)
+    if "--loader-workers" not in extra:                   # loader processes inherit the GPU's file handles: the box allows six such processes
+        cmd += ["--loader-workers", "0"]
     p = subprocess.run(cmd, cwd=Y24, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout

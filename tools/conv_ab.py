@@ -15,6 +15,10 @@ SHAPES = [(20, 40, 256, 256), (20, 80, 128, 128), (20, 20, 512, 512), (20, 80, 2
           (20, 40, 256, 512), (20, 20, 256, 256)]
 
 
+if os.environ.get("EP24_AB_SHAPES"):                    # "B,H,Cin,Cout;..." (e.g. channel counts whose weight-row stride is not a power of two)
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["EP24_AB_SHAPES"].split(";")]
+
+
 def graph_time(run, iters=20):
     run()
     torch.cuda.synchronize()
@@ -66,11 +70,12 @@ def main():
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
             for rnd in range(3):                         # interleaved rounds in one process
-                for mode in (1, 8, 0, 32):               # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring, 16x16x32), bit 5 ring with 32x32x16
+                for mode in (1, 8, 0, 32, 64):           # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring, 16x16x32), bit 5 ring with 32x32x16, bit 6 narrow ring
                     ko[0] = mode
                     res.setdefault(mode, []).append(graph_time(run))
-            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f %5.0f" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]), min(res[32]),
-                                                                       fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6, fl / min(res[32]) / 1e6), flush=True)
+            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f %5.0f %5.0f" % (
+                kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]), min(res[32]), min(res[64]),
+                fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6, fl / min(res[32]) / 1e6, fl / min(res[64]) / 1e6), flush=True)
     print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 

@@ -21,14 +21,16 @@ def main():
     rd = L.cdll.ep24_debug_read_ring_stamps
     rd.argtypes = [ctypes.c_void_p, ctypes.c_int]
     print("shape                steps  prologue   loop  epilogue | cycles per step  of which waiting for FULL  steps that waited | clock GHz | kernel us | MFMA issue share of the loop")
-    for B, H, Cin, Cout in [(20, 40, 256, 256), (20, 80, 128, 128), (20, 80, 256, 256), (20, 40, 256, 512)]:
+    # the last three: the narrow tile (256 x 64; its MFMA issue per step is 512 cycles, so the last column reads half of the real share)
+    for B, H, Cin, Cout in [(20, 40, 256, 256), (20, 80, 128, 128), (20, 80, 256, 256), (20, 40, 256, 512), (20, 20, 512, 512), (20, 20, 256, 256), (20, 160, 64, 64)]:
         W = H
         x = torch.randn(B * H * W, Cin, device=DEV).to(torch.bfloat16)
         w = (torch.randn(Cout, 9, Cin, device=DEV) * 0.05).to(torch.bfloat16)
         y = torch.zeros(B * H * W, Cout, device=DEV, dtype=torch.bfloat16)
         stats = torch.zeros(8, 2, Cout, dtype=torch.int64, device=DEV)
         for _ in range(50):                                  # sustained load: the clock under load, not the idle clock
-            call("conv_fwd_bf16", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, stream_ptr())
+            call("conv_fwd_bf16_ex", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1,
+                 int(os.environ.get("EP24_STAMP_OPTS", "0")), stream_ptr())
         torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * 512)()
         assert rd(buf, 512) == 0

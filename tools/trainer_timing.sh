@@ -12,18 +12,19 @@ run() {   # name, flags
   timeout -k 10 300 python3 train_24p.py $COMMON "$@" --throughput-json $OUT/tp_$n.json > $OUT/$n.log 2>&1
   echo "$n done"
 }
-run prefetch
-run prefetch_w4 --loader-workers 4
-run prefetch_w4_pin --loader-workers 4 --loader-pin
+run prefetch                                          # the default: 3 loader processes, page-locked fp32 batches, side-stream upload
+run prefetch_w0 --loader-workers 0
+run prefetch_w4 --loader-workers 4 --loader-pin 0
+run prefetch_w4_pin --loader-workers 4 --loader-pin 1
 run raw_u8 --raw-u8
 run raw_u8_w4 --raw-u8 --loader-workers 4
-run no_prefetch --no-prefetch
+run no_prefetch --no-prefetch --loader-workers 0
 rm -rf $OUT/run
 cd $R
 python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/bench_sustained.json 2> $OUT/bench.err
 python3 - <<PY
 import json
-MODES = ("prefetch", "prefetch_w4", "prefetch_w4_pin", "raw_u8", "raw_u8_w4", "no_prefetch")
+MODES = ("prefetch", "prefetch_w0", "prefetch_w4", "prefetch_w4_pin", "raw_u8", "raw_u8_w4", "no_prefetch")
 o = {"command": "tools/trainer_timing.sh: train_24p.py -f load_train/yolox_24p_l_train.py -b 20 -l 0.01 --synthetic --steps 250 --synthetic-len 6000 --log-interval 50 [mode]; window = the last 200 steps, synchronised at both ends"}
 for k in MODES:
     o[k] = json.load(open("$OUT/tp_%s.json" % k))
