@@ -344,12 +344,18 @@ __device__ unsigned g_timeouts;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
-__device__ __forceinline__ void st_flag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ unsigned min4(const unsigned* f) {
-    const v4u v = *reinterpret_cast<const volatile v4u*>(f);
+// the counters are LDS (address space 3) objects: through generic pointers every look at them was a FLAT load that drained vmcnt and
+// lgkmcnt - a loader's poll waited for every DMA it had in flight (conv_ring.hip has the story)
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+typedef __attribute__((address_space(3))) void* lds_void_p;
+__device__ __forceinline__ void st_flag(lds_u32* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ v4u ld_flags4(const lds_u32* f) { return *reinterpret_cast<const volatile lds_v4u*>(f); }
+__device__ __forceinline__ unsigned min4(const lds_u32* f) {
+    const v4u v = ld_flags4(f);
     return __builtin_amdgcn_readfirstlane(min(min(v.x, v.y), min(v.z, v.w)));
 }
-__device__ __forceinline__ void spin_until(const unsigned* f, unsigned need) {
+__device__ __forceinline__ void spin_until(const lds_u32* f, unsigned need) {
     int tries = 0;
     while (min4(f) < need) {
         __builtin_amdgcn_s_sleep(1);
@@ -392,8 +398,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(const Wgra
     const long p_end = min(p.M, p_begin + p.chunk);
     const unsigned S = p_end > p_begin ? (unsigned)((p_end - p_begin + 63) / 64) : 0u;      // steps, uniform over the workgroup
     unsigned* const flags = reinterpret_cast<unsigned*>(smem + NS * STAGE);
-    unsigned* const f_full = flags;
-    unsigned* const f_free = flags + 4;
+    lds_u32* const f_full = (lds_u32*)(lds_void_p)flags;
+    lds_u32* const f_free = f_full + 4;
     if (reinterpret_cast<unsigned long>((lptr_t)smem) != 0ul) {
         if (tid == 0) atomicAdd(&g_timeouts, 1u << 16);
         return;
@@ -520,7 +526,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(const Wgra
                 else pa[gr - 16] = y_frag((gr - 16) % FM, (gr - 16) / FM, son);    // behind the last step: bytes nobody uses
                 if constexpr (g < 4) fb1[g] = x_frag(g, 1, so);
                 if constexpr (g >= G_CHECK && g < G_CHECK + 4) fb0[g - G_CHECK] = x_frag(g - G_CHECK, 0, son);
-                if constexpr (g == G_FLAGS) fl = *reinterpret_cast<const volatile v4u*>(f_full);
+                if constexpr (g == G_FLAGS) fl = ld_flags4(f_full);
                 if constexpr (gr == 15) {
                     cbar();                                   // every fragment read of this step is issued: its stage may be refilled
                     if (lane == 0) st_flag(f_free + cw, jdone + 1);
