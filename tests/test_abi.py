@@ -107,3 +107,12 @@ def test_no_half_swapped_packed_fp32(tmp_path):
                 bad.append((kernel, line.strip().split("//")[0].strip()))
     assert n_kernels > 50 and n_instr > 100000, (n_kernels, n_instr)          # the disassembly really covered the library
     assert not bad, "packed fp32 with a half-swapping op_sel in: %s" % bad[:5]
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: make (a no-op on a built tree), import of the package and of the oracle, and the ABI
+    version of the built library against the header's (a stale constant in build() went unnoticed through the version bump of round 4)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
