@@ -113,6 +113,8 @@ def test_graft_entry_build_runs():
     """The driver's "does it build" check: make (a no-op on a built tree), import of the package and of the oracle, and the ABI
     version of the built library against the header's (a stale constant in build() went unnoticed through the version bump of round 4)."""
     import importlib
-    sys.path.insert(0, ROOT)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
     ge = importlib.import_module("__graft_entry__")
     ge.build()
