@@ -158,7 +158,11 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
     constexpr int act = ACT;
     // Wide blocks (NT threads) so that one batch of UNROLL rows per thread covers the tensor with few blocks: the
     // per-block cost is 2*C memory-side int64 atomics, and all of a thread's loads are in flight at once.
-    __shared__ float red[NT][16 + 1];
+    // [NT][8 + 1]: the two sums go through it one after the other (round 4).  As [NT][16 + 1] it took 34.8 KB per workgroup - and beside
+    // the two weight-gradient workgroups of a CU (64 KB each) that did not fit the 160 KB, so in the step this kernel could only start
+    // on a CU when a weight-gradient workgroup had left it: 17 us alone, 32 us in the replayed step, the most stretched kernel of the
+    // main lane.  Same values added in the same order as before: bit-identical sums.
+    __shared__ float red[NT][8 + 1];
     const RowMap rm(C, NT);
     const int tid = threadIdx.x;
     for (int cg0 = 0; cg0 < (C >> 3); cg0 += NT) {               // only loops when C > 8*NT
@@ -208,21 +212,24 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { red[tid][j] = sg[j]; red[tid][8 + j] = sb[j]; }
-        __syncthreads();
-        // thread t sums value t%16 of channel group t/16 over the block's row slots and publishes it
         const int ngrp = min(rm.tpr, (C >> 3) - cg0);
-        for (int t = tid; t < ngrp * 16; t += NT) {
-            const int g = t >> 4, v = t & 15;
-            float a = 0.f;
-            for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
-            // replica blockIdx % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
-            // addresses at about the same time - 256 serial adds per address at the memory-side atomic units, ~5 us of tail
-            long long* dst = (v < 8 ? dgamma : dbeta) + (long)(blockIdx.x % reps) * 2 * C + (cg0 + g) * 8 + (v & 7);
-            atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix_g(a));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                   // 0: sum of du * zhat (dgamma), 1: sum of du (dbeta)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid][j] = half ? sb[j] : sg[j];
+            __syncthreads();
+            // thread t sums value t%8 of channel group t/8 over the block's row slots and publishes it
+            for (int t = tid; t < ngrp * 8; t += NT) {
+                const int g = t >> 3, v = t & 7;
+                float a = 0.f;
+                for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
+                // replica blockIdx % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
+                // addresses at about the same time - 256 serial adds per address at the memory-side atomic units, ~5 us of tail
+                long long* dst = (half ? dbeta : dgamma) + (long)(blockIdx.x % reps) * 2 * C + (cg0 + g) * 8 + v;
+                atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix_g(a));
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -1130,10 +1137,14 @@ extern "C" int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void*
                                       int act, int reps, void* stream) {
     EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && reps > 0, EP24_E_ARG, "bn_act_bwd_reduce: null pointer / reps");
     EP24_REQUIRE(C % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0, EP24_E_ARG, "bn_act_bwd_reduce: alignment");
-    int red_cap = 256;                                      // one 512-thread block per CU: tools/bn_probe.py sweep
+    // 256-thread blocks, two per CU (round 4).  Alone, one 512-thread block per CU is as fast or 0.5 us faster (tools/bn_probe.py,
+    // tools/bn_ab.py) - but in the step this kernel runs beside the weight-gradient lane, whose two workgroups per CU hold 368 of a
+    // SIMD's 512 registers: a 512-thread block (two waves per SIMD, 240 registers) does not fit beside them and waited for one of them to
+    // leave, a 256-thread block (one wave per SIMD, 120) does.  21.73 against 22.22 ms per step, twice, one box.
+    int red_cap = 512;
     int red_rows = 4;
-    auto kfn = act == 1 ? bn_act_bwd_reduce_kernel<4, 512, 1> : act == 2 ? bn_act_bwd_reduce_kernel<4, 512, 2> : act == 3 ? bn_act_bwd_reduce_kernel<4, 512, 3> : bn_act_bwd_reduce_kernel<4, 512, 0>;
-    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, red_rows, red_cap, 512)), dim3(512), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
+    auto kfn = act == 1 ? bn_act_bwd_reduce_kernel<4, 256, 1> : act == 2 ? bn_act_bwd_reduce_kernel<4, 256, 2> : act == 3 ? bn_act_bwd_reduce_kernel<4, 256, 3> : bn_act_bwd_reduce_kernel<4, 256, 0>;
+    hipLaunchKernelGGL(kfn, dim3(rows_grid(M, C, red_rows, red_cap, 256)), dim3(256), 0, S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z,
                        save, gamma, beta, (long long*)dgamma, (long long*)dbeta, M, C, reps);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_reduce");
     return EP24_OK;
