@@ -8,6 +8,7 @@
 // lane owns 4 consecutive channels of a pixel: 8-byte packed stores, 128 B per pixel per wave.
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 #include "igemm.h"
 
 using namespace ep24_igemm;
@@ -22,6 +23,7 @@ constexpr int KOPT_GRING = 16;             // bit 4: layers of the tiled kernel 
 constexpr int KOPT_RING32 = 32;            // bit 5: the ring's consumers multiply with v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (an A/B option: 12 % fewer
                                            // cycles per step, a 9 % lower clock under load - slower in the step, profiles/r04_ring_ab.txt)
 constexpr int KOPT_NARROW = 64;            // bit 6: A/B option - 3x3 stride-1 layers in the ring with the NARROW tile (256 x 64; also the 20 x 20 level and N = 64)
+constexpr int KOPT_NO_DEEP = 128;          // bit 7: A/B option - no three-stage form of the tiled kernel (the 20 x 20 level runs in 64-wide two-stage tiles, as before round 4)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -38,7 +40,10 @@ constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through
 // A second variant kept two tiles in flight WITHOUT a third stage (both stages requested up front, tile it+2 requested as soon as
 // tile `it` had been read, a second barrier per step): within +-4 % of this loop on the 1x1 layers, 613 against 627 us over all of
 // them, nothing in the step (22.68 against 22.78 ms) - profiles/r03_ring_ab.txt.  Removed as well.
-template <int BN, bool OUT_F32, int EPI>
+// NSTG = 3 (round 4, BN = 128 only): three LDS stages, two tiles in flight behind a counted wait and a raw barrier - for the layers
+// whose 128-wide tiles leave at most one workgroup per CU anyway (the 20 x 20 level at B = 20), where the second co-resident workgroup
+// that made two stages the better choice everywhere else (round 3, profiles/r03_ring_ab.txt) does not exist.
+template <int BN, bool OUT_F32, int EPI, int NSTG = 2>
 __device__ __forceinline__ void igemm_dma_body(const IgemmArgs& p, const int bid, const int nwg) {
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 16, NT = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -148,11 +153,31 @@ __device__ __forceinline__ void igemm_dma_body(const IgemmArgs& p, const int bid
                     acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
         }
     };
+    if constexpr (NSTG >= 3) {
+        // NSTG - 1 tiles in flight: before tile `it` is read this wave's DMAs of it have landed (the younger tiles may stay in flight),
+        // then everybody's (barrier) - which also says that every wave is through with tile it - 1, whose stage tile it + NSTG - 1 takes
+#pragma unroll
+        for (int i = 0; i < NSTG - 1; ++i)
+            if (i < n_iter) issue(i);
+        int st = 0;                                          // stage of tile `it`
+        for (int it = 0; it < n_iter; ++it) {
+            const int ahead = n_iter - 1 - it;               // tiles issued behind this one
+            if (NSTG >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_INSTR + B_INSTR)) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + NSTG - 1 < n_iter) issue(st == 0 ? NSTG - 1 : st - 1);
+            compute(smem + st * STAGE);
+            st = st == NSTG - 1 ? 0 : st + 1;
+        }
+    } else {
     issue(0);
     for (int it = 0; it < n_iter; ++it) {
         __syncthreads();                       // vmcnt(0) + barrier: tile `it` has landed, stage (it+1)&1 is free
         if (it + 1 < n_iter) issue((it + 1) & 1);
         compute(smem + (it & 1) * STAGE);
+    }
     }
 
     igemm_epilogue<BN, OUT_F32, MT, EPI>(p, acc, m0, n0, tile_m, smem);
@@ -161,6 +186,13 @@ __device__ __forceinline__ void igemm_dma_body(const IgemmArgs& p, const int bid
 template <int BN, bool OUT_F32, int EPI = 0>                // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
     igemm_dma_body<BN, OUT_F32, EPI>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+#ifndef EP24_DEEP_STAGES
+#define EP24_DEEP_STAGES 3
+#endif
+__global__ __launch_bounds__(256) void igemm_dma_deep_kernel(const IgemmArgs p) {       // 128-wide tiles, three stages, bf16 training form
+    igemm_dma_body<128, false, 0, EP24_DEEP_STAGES>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to four gather-GEMMs in ONE launch: the parity classes of a stride-2 input gradient (same M, N and K; 1, 2, 2 and 4 taps) used
@@ -572,6 +604,25 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     // 128-wide N tiles unless that leaves at most one workgroup per CU (the 20x20 level at B = 20): 64-wide tiles then
     // double the workgroups (+3 .. +27 % on those layers)
     const bool wide = a.N > 64 && (long)ep24_cdiv(a.M, BM) * ep24_cdiv(a.N, 128) > 256;
+    // ... unless the K loop is long enough for a deeper pipeline to pay: 128-wide tiles (half the A-tile traffic of two 64-wide ones),
+    // one workgroup per CU, three stages
+    // (forced on the layers with two workgroups per CU as well it costs +0.6 ms per step, with four stages instead of three nothing changes:
+    // profiles/r04_tiled_deep_ab.txt)
+    if (!wide && a.N > 64 && !out_f32 && !a.epi_infer && !(kernel_opts & KOPT_NO_DEEP) && a.T * ep24_cdiv(a.K, BK) >= 8) {
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv: hipGetDevice failed");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute((const void*)igemm_dma_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", dev, hipGetErrorString(e));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+        const unsigned t128 = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, 128);
+        hipLaunchKernelGGL(igemm_dma_deep_kernel, dim3(t128), dim3(256), EP24_DEEP_STAGES * (BM * 128 + 128 * 128), stream, a);
+        EP24_LAUNCH_CHECK("ep24_conv_igemm_deep");
+        return EP24_OK;
+    }
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, wide ? 128 : 64);
     if (wide) {
         if (out_f32) launch_variant<128, true>(a, tiles, stream);

@@ -176,7 +176,8 @@ def test_conv_hot_shapes(shape):
     # ring of conv_ring.hip where it fits), bit 3 = the 8-wave halo-patch kernel instead, bit 0 = the generic tiled kernel
     # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
-    variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64)) if (k == 3 and s == 1) else ((2, 0), (0, 16))      # key 4: the narrow ring where it fits
+    # key 4: the narrow ring where it fits; key 5 (bits 0 + 7): the tiled kernel WITHOUT its three-stage form (the 20 x 20 level)
+    variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((2, 0), (0, 16), (5, 128))
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)

@@ -70,12 +70,12 @@ def main():
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
             for rnd in range(3):                         # interleaved rounds in one process
-                for mode in (1, 8, 0, 32, 64):           # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring, 16x16x32), bit 5 ring with 32x32x16, bit 6 narrow ring
+                for mode in (1, 8, 0, 32, 64, 129):           # kernel_opts: bit 0 tiled kernel, bit 3 8-wave halo-patch kernel, 0 the default (ring, 16x16x32), bit 5 ring with 32x32x16, bit 6 narrow ring
                     ko[0] = mode
                     res.setdefault(mode, []).append(graph_time(run))
-            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f %5.0f %5.0f" % (
-                kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]), min(res[32]), min(res[64]),
-                fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6, fl / min(res[32]) / 1e6, fl / min(res[64]) / 1e6), flush=True)
+            print("%-8s %-22s %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f   TF: %5.0f %5.0f %5.0f %5.0f %5.0f %5.0f" % (
+                kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), min(res[1]), min(res[8]), min(res[0]), min(res[32]), min(res[64]), min(res[129]),
+                fl / min(res[1]) / 1e6, fl / min(res[8]) / 1e6, fl / min(res[0]) / 1e6, fl / min(res[32]) / 1e6, fl / min(res[64]) / 1e6, fl / min(res[129]) / 1e6), flush=True)
     print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 
