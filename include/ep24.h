@@ -67,7 +67,9 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * A/B option); bit 6: the ring with its NARROW tile (256 pixels x 64 channels, four consumers of 64 x 64, a weight-ring stage per
  * tap and loaders five steps ahead) for every 3x3 stride-1 layer with at least 128 such tiles - also the 20 x 20 level and N = 64,
  * which the 256 x 128 ring does not take (bit-identical results; measured slower than the tiled kernel it would replace: an A/B
- * option).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * option); bit 7: the tiled kernel without its three-stage form (round 4: layers whose 128-wide tiles leave at most one workgroup per
+ * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
+ * two-stage tiles as before; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
