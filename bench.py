@@ -403,6 +403,10 @@ def main():
         default_cfg = (a.batch, a.size, a.gts, a.backbone, a.width, a.depth) == (20, 640, 10, "darknet", 1.0, 1.0) and not (a.fisheye or a.long_run or a.no_graph or a.plan)
         rep_ms = sum(r[0] for r in reps) if (default_cfg and all(r[0] for r in reps)) else None     # the committed profile is of the default workload
         rep_src = reps[0][1]
+        from ep24 import _lib as _l
+        ring_timeouts = int(_l.lib().fn["ep24_conv_ring_timeouts"]())
+        if ring_timeouts != 0:
+            sys.exit("bench.py: %d bounded waits of the ring kernels gave up (ep24_conv_ring_timeouts): results are not valid" % ring_timeouts)
         out = {
             "metric": "training images/sec, YOLOX-l 24p 640x640 bf16", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -415,6 +419,9 @@ def main():
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
                        **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),
+            # bounded waits of the loader / consumer ring kernels that gave up in this process (0 unless their hand-off protocol is
+            # broken: wrong numbers would follow, so the benchmark refuses to report a rate beside them)
+            "ring_timeouts": ring_timeouts,
             "ranks": ranks_info,
             "distributed": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                              "distinct_devices": len({(r["uuid"], r["pci_bus_id"]) for r in ranks_info}),

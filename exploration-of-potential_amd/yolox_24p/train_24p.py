@@ -205,6 +205,9 @@ class Trainer:
                 with open(args.throughput_json, "w") as fh:
                     json.dump(rec, fh)
                 print("throughput %s" % json.dumps(rec))
+        from ep24 import _lib
+        if _lib.lib().fn["ep24_conv_ring_timeouts"]() != 0:       # never seen; a broken hand-off would have produced wrong numbers
+            raise RuntimeError("train_24p.py: bounded waits of the loader / consumer ring kernels gave up during this run (ep24_conv_ring_timeouts)")
         if self.world > 1:
             torch.distributed.destroy_process_group()
 
