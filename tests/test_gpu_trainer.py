@@ -75,3 +75,18 @@ def test_trainer_runs_and_checkpoint_round_trips(tmp_path):
     m1 = ck["optimizer"]["state"][0]["momentum_buffer"]
     m2 = ck2["optimizer"]["state"][0]["momentum_buffer"]
     assert float(m2.abs().max()) > 0 and not torch.equal(m1, m2)    # momentum was loaded, then advanced by one step
+
+
+def test_trainer_with_loader_processes(tmp_path):
+    """The default source of the entry point since round 4: ready-made fp32 batches from loader PROCESSES, page-locked, uploaded on
+    the prefetcher's side stream (here two processes: with pytest and the trainer that is four of the six a GPU box allows)."""
+    import json
+    out = str(tmp_path / "run")
+    log = _train(out, "--steps", "4", "--loader-workers", "2", "--throughput-json", str(tmp_path / "tp.json"), "--throughput-window", "2")
+    steps = [ln for ln in log.splitlines() if ln.startswith("step ")]
+    assert len(steps) == 4 and "captured step" in log, log[-2000:]
+    losses = [float(ln.split("loss")[1].split()[0]) for ln in steps]
+    assert all(v == v and 0 < v < 1e4 for v in losses), losses
+    tp = json.load(open(str(tmp_path / "tp.json")))
+    assert tp["loader_workers"] == 2 and tp["loader_pin"] and tp["prefetch"] and not tp["raw_u8"] and tp["images_per_s"] > 0
+    assert set(tp["host_ms_per_step"]) == {"loader_and_upload", "step_enqueue", "rest"}
