@@ -1,0 +1,56 @@
+"""The committed profile set of the round is ONE set: the bench line's replayed fraction and PMC traffic follow from the kernel trace /
+counter files stored beside it ("the judge can recompute every figure of the bench line from profiles/r04_*"),
+every file carries the same commit, and no row of the HBM table exceeds the memory system."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel",
+          "igemm_dma_kernel": "igemm_dma_"}
+
+
+def _latest_tag():
+    files = sorted(glob.glob(os.path.join(PROF, "*_kernel_meta.json")))
+    assert files, "no committed kernel trace summary"
+    return os.path.basename(files[-1])[: -len("_kernel_meta.json")]
+
+
+def test_bench_line_follows_from_the_committed_profiles():
+    tag = _latest_tag()
+    bench = json.load(open(os.path.join(PROF, tag + "_bench.json")))
+    meta = json.load(open(os.path.join(PROF, tag + "_kernel_meta.json")))
+    pmc = json.load(open(os.path.join(PROF, tag + "_pmc_traffic.json")))
+    sq = json.load(open(os.path.join(PROF, tag + "_pmc_sq.json")))
+    heads = {bench["git_head"], meta["git_head"], pmc["git_head"], sq["git_head"]}
+    assert len(heads) == 1 and "unknown" not in heads, heads
+    r = bench["roofline"]
+    members = list(r["members"])
+    # every launch of the family is counted: the members' launches per step against the trace's calls over its executions of the step
+    steps = meta["steps_in_profiled_process"]
+    calls = sum(v["calls"] for k, v in meta["kernels"].items() for m in members if k.startswith(PREFIX[m]))
+    assert calls == r["launches_per_step"] * steps, (calls, r["launches_per_step"], steps)
+    ms = sum(v["ms_per_step"] for k, v in meta["kernels"].items() for m in members if k.startswith(PREFIX[m]))
+    flops = r["algorithmic_gflop_per_launch"] * r["launches_per_step"] * 1e9
+    assert abs(flops / (ms * 1e-3) / 1e12 / r["peak"] - r["frac_replayed"]) < 5e-3, (ms, r["frac_replayed"])
+    # the serial figure: achieved = FLOPs over the sum of the launch durations, frac = achieved / peak
+    assert abs(r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3 - r["achieved"]) / r["achieved"] < 1e-2
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3 and r["peak"] == 2500.0 and r["bound"] == "mfma"
+    n = b = 0
+    for name, v in pmc["kernels"].items():
+        if any(name.startswith(PREFIX[m]) for m in members):
+            n += v["launches"]
+            b += v["traffic_bytes"] * v["launches"]
+    assert abs(b / n - r["traffic"]) / r["traffic"] < 1e-3
+    assert bench["metric"].startswith("training images/sec") and bench["unit"] == "images/s" and bench["vs_baseline"] is None
+    assert abs(bench["value"] - 20 * 1e3 / bench["ms_per_step"]) / bench["value"] < 1e-3          # batch 20 per step
+
+
+def test_hbm_table_rows_stay_below_the_memory_system():
+    tag = _latest_tag()
+    rows = [ln for ln in open(os.path.join(PROF, tag + "_hbm_table.md")) if ln.startswith("| `")]
+    assert len(rows) > 20
+    for ln in rows:
+        cells = [c.strip() for c in ln.strip().strip("|").split("|")]
+        assert float(cells[-1]) <= 100.0, ln
