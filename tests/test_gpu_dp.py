@@ -98,9 +98,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     args = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "4", "--size", "256", "--width", "0.25", "--depth", "0.33"]
-    # fp32 wire for the bit-equality with one rank; the bench's default at --gpus > 1 is the bf16 wire (half the xGMI bytes),
-    # whose update differs by the bf16 rounding of the gradients: checked below at bf16 tolerance
-    two = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dp-wire", "fp32"] + args, env, timeout=900)
+    # fp32 wire (the default, as the reference's DDP and the trainer): bit-equality with one rank
+    two = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env, timeout=900)
     line2 = [ln for ln in two.splitlines() if ln.startswith("{")]
     assert len(line2) == 1, two[-3000:]
     r2 = json.loads(line2[0])
@@ -108,7 +107,13 @@ def test_bench_starts_its_own_ranks(tmp_path):
     r1 = json.loads([ln for ln in one.splitlines() if ln.startswith("{")][0])
     assert r2["n_gpus"] == 2 and r2["config"]["global_batch"] == 8 and r2["scaling"] == "weak"
     assert r2["loss"] == r1["loss"], (r2["loss"], r1["loss"])
-    assert r2["value"] > 0 and "roofline" in r2
-    bf = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env, timeout=900)        # default wire: bf16
+    assert r2["value"] > 0 and "roofline" in r2 and r2["ring_timeouts"] == 0 and r1["ring_timeouts"] == 0
+    # the line says what the collective backend saw: one entry per rank, gathered over the process group
+    assert r2["distributed"]["world_size"] == 2 and r2["distributed"]["dp_wire"] == "fp32" and len(r2["ranks"]) == 2
+    assert sorted(r["rank"] for r in r2["ranks"]) == [0, 1] and len({r["pid"] for r in r2["ranks"]}) == 2
+    assert r1["distributed"] is None and len(r1["ranks"]) == 1
+    # the opt-in bf16 wire (half the xGMI bytes): the update differs by the bf16 rounding of the gradients
+    bf = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dp-wire", "bf16"] + args, env, timeout=900)
     rb = json.loads([ln for ln in bf.splitlines() if ln.startswith("{")][0])
-    assert rb["n_gpus"] == 2 and abs(rb["loss"] - r1["loss"]) < 0.05 * abs(r1["loss"]), (rb["loss"], r1["loss"])
+    assert rb["n_gpus"] == 2 and rb["distributed"]["dp_wire"] == "bf16"
+    assert abs(rb["loss"] - r1["loss"]) < 0.05 * abs(r1["loss"]), (rb["loss"], r1["loss"])
