@@ -569,7 +569,10 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
         return EP24_OK;
     }
     // 3x3 stride-1 (forward and input gradient): the halo-patch kernel, when the shape fits its LDS budget
-    if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && !a.bias && !a.epi_infer &&
+    // (training form, or the eval-mode unit with its bias / activation / residual epilogue - the ring's 16-byte store path carries it)
+    const bool infer_ring = a.epi_infer && !a.narrow_epi && (a.N & 7) == 0 && (a.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(a.dst) & 15) == 0 &&
+                            (!a.epi_res || ((a.epi_ldres & 3) == 0 && (reinterpret_cast<unsigned long long>(a.epi_res) & 7) == 0));
+    if (a.T == 9 && a.sy == 1 && a.sx == 1 && a.GH == a.SH && a.GW == a.SW && plain_dst && !out_f32 && ((!a.bias && !a.epi_infer) || infer_ring) &&
         !(kernel_opts & KOPT_TILED)) {
         int prc = EP24_OK;
         int ring = 0;
@@ -583,7 +586,7 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
             EP24_LAUNCH_CHECK("ep24_conv_ring");
             return EP24_OK;
         }
-        if (launch_patch(a, stream, dry, &prc)) {
+        if (!a.epi_infer && launch_patch(a, stream, dry, &prc)) {      // (the 8-wave kernel has no eval-mode epilogue)
             if (dry) { *kernel_id = 1; return EP24_OK; }
             if (prc) return prc;
             EP24_LAUNCH_CHECK("ep24_conv_patch");

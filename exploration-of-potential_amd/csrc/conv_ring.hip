@@ -126,7 +126,7 @@ __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int
 // rounded FROM (fp32, as the tiled kernels); after a barrier every wave stores 8 chunks per lane, 8 lanes per 128-byte row segment.
 // Same values, same statistics and the same order of the fixed-point sums as igemm_epilogue: bit-identical outputs.
 // TBN = 64 (the narrow tile, 256 x 64): the four consumers hold 64 x 64 pieces stacked over the rows, CMT = 4.
-template <int TBN, int CMT>
+template <int TBN, int CMT, bool INFER = false>
 __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[CMT][NT], const bool consumer, long m0, int n0, int tile_m, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -134,17 +134,35 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
     __syncthreads();                                         // every wave is out of the main loop: LDS is free
     if (consumer) {
         const int wm = TBN == 128 ? wave >> 1 : wave;
+        const int wn = TBN == 128 ? wave & 1 : 0;
         char* stg = smem + wave * (CMT * 16 * 128);
+        // eval-mode unit: y = act(acc + bias) + residual on the way into the staging area, the expressions and their
+        // order as in igemm_epilogue's inference form (a lane's four values of a row are four consecutive channels c0 .. c0 + 3)
+        constexpr bool infer = INFER;                          // its own instantiation: the training kernel carries no trace of it
+        const int c0 = n0 + wn * 64 + 4 * frow;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (infer && p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + q < p.N) bias4[q] = p.bias[c0 + q];
+        }
 #pragma unroll
         for (int i = 0; i < CMT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + 4 * fq + r;
-                const bool live = m0 + wm * (CMT * 16) + row < p.M;
+                const long m = m0 + wm * (CMT * 16) + row;
+                const bool live = m < p.M;
                 bf16x4 w;
+                bf16x4 res4 = {0, 0, 0, 0};
+                if (infer && p.epi_res && live && c0 + 3 < p.N) res4 = *reinterpret_cast<const bf16x4*>(p.epi_res + m * p.epi_ldres + c0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = acc[i][q][r];
+                    float v = acc[i][q][r];
+                    if (infer) {
+                        v = act_fwd(v + bias4[q], p.epi_act);
+                        if (p.epi_res) v += (float)res4[q];
+                    }
                     if (live) { s1[q] += v; s2[q] += v * v; }
                     w[q] = (bf16)v;
                 }
@@ -311,7 +329,7 @@ __device__ __forceinline__ void ring_epilogue32(const IgemmArgs& p, f32x16_ (&ac
 // level at B = 20: 128 tiles) or whose N is 64.  Consumers are stacked over the rows (64 x 64 each, 4 x 4 accumulator tiles): a step is
 // 8 groups of 4 MFMAs and 16 fragment reads, LDS read bandwidth and MFMA issue in balance (512 cycles each), so the loaders run TWO
 // steps ahead here (the next step's DMAs are issued before the wait for this step's: one step per round trip would bound the loop).
-template <int PPS, bool M32, int TBN = RBN>
+template <int PPS, bool M32, int TBN = RBN, bool INFER = false>
 __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const IgemmArgs p, const int NP, const int halo, const int npb) {
     static_assert(TBN == 128 || (TBN == 64 && !M32), "tile widths: 128, or 64 with the 16 x 16 consumers");
     constexpr int CMT = TBN == 128 ? MT : 4;                 // accumulator row tiles per consumer
@@ -981,7 +999,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
         // carry half of the stores); otherwise the loaders are done (a terminated wave no longer counts at s_barrier) and the four
         // consumers run the shared epilogue (a 2 x 2 grid of 128 x 64 pieces; the narrow tile: four 64 x 64 pieces over the rows).
         f32x4 (&acc_t)[CMT][NT] = reinterpret_cast<f32x4 (&)[CMT][NT]>(acc);
-        if (wide) ring_epilogue<TBN, CMT>(p, acc_t, consumer, m0, n0, tile_m, smem);
+        if (wide) ring_epilogue<TBN, CMT, INFER>(p, acc_t, consumer, m0, n0, tile_m, smem);
         else if (consumer) igemm_epilogue<TBN, false, CMT, 0, NCW, false>(p, acc_t, m0, n0, tile_m, smem);
         else return;
     }
@@ -1183,7 +1201,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
 }
 
-template <int PPS, bool M32, int TBN = RBN>
+template <int PPS, bool M32, int TBN = RBN, bool INFER = false>
 int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, hipStream_t stream) {
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, RBM) * (unsigned)ep24_cdiv(a.N, TBN);
     static std::atomic<unsigned long long> done{0};          // per-device attribute, set once (conv_patch.hip has the reasons)
@@ -1191,12 +1209,12 @@ int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, h
     EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipGetDevice failed");
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS, M32, TBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute((const void*)conv_ring_kernel<PPS, M32, TBN, INFER>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv_ring: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KB) failed on device %d: %s", dev,
                      hipGetErrorString(e));
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32, TBN>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
+    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32, TBN, INFER>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
     return EP24_OK;
 }
 
@@ -1232,6 +1250,7 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
     if (a.K % 8 != 0) return 0;
     if (a.bnr_z) return 0;                                   // the fused BatchNorm-backward sums (an A/B option) stay with the 8-wave kernel
     const bool narrow = narrow_ok;
+    if (a.epi_infer && (narrow || !m16)) return 0;            // the eval-mode epilogue lives in the 256 x 128 tile's 16 x 16 form
     if (!narrow && (a.N <= 64 || (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, RBN) < 200)) return 0;
     if (narrow && (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, 64) < 128) return 0;
     const int tb_bytes = (narrow ? 64 : RBN) * 128;
@@ -1259,6 +1278,10 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
             *rc = pps <= 1 ? launch_ring_pps<1, true>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, true>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, true>(a, np, halo, npb, lds, stream);
+        else if (a.epi_infer)
+            *rc = pps <= 1 ? launch_ring_pps<1, false, RBN, true>(a, np, halo, npb, lds, stream)
+                : pps == 2 ? launch_ring_pps<2, false, RBN, true>(a, np, halo, npb, lds, stream)
+                           : launch_ring_pps<3, false, RBN, true>(a, np, halo, npb, lds, stream);
         else
             *rc = pps <= 1 ? launch_ring_pps<1, false>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, false>(a, np, halo, npb, lds, stream)

@@ -509,3 +509,29 @@ def test_upsample_stem_decode_sgd():
         gd[:n] = g.to(DEV)
         call("sgd_nesterov", ptr(p), ptr(gd), ptr(buf), 1004, 0.01, 0.9, 1.0, ptr(first), sp())
         torch.testing.assert_close(p[:n].cpu(), pt.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act,with_res", [(20, 40, 40, 256, 256, 3, 1, True), (20, 80, 80, 128, 128, 3, 1, False), (12, 52, 100, 64, 128, 3, 1, True),
+                                                            (20, 20, 20, 512, 512, 3, 1, True), (4, 40, 40, 256, 256, 1, 1, True)])
+def test_conv_infer_unit(B, H, W, Cin, Cout, k, act, with_res):
+    """The eval-mode unit y = act(conv(x) + bias) + residual (ep24_conv_fwd_infer_bf16) on shapes of every kernel that
+    carries its epilogue - the loader / consumer ring (round 4: 3x3 stride-1 with >= 200 tiles of 256 x 128), the tiled kernel (the
+    20 x 20 level) and the 1x1 path - against torch on the bf16-rounded operands."""
+    call, ptr, sp = _abi()
+    pad = (k - 1) // 2
+    x = rnd(B, Cin, H, W, seed=11)
+    w = rnd(Cout, Cin, k, k, seed=12, scale=(Cin * k * k) ** -0.5)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(13))
+    res = rnd(B, Cout, H, W, seed=14) if with_res else None
+    ref = F.conv2d(x.float().to(DEV), w.float().to(DEV), bias.to(DEV), 1, pad)
+    ref = ref * torch.sigmoid(ref) if act == 1 else ref
+    if with_res:
+        ref = ref + res.float().to(DEV)
+    xd, wf = nhwc(x).to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rd = nhwc(res).to(DEV) if with_res else None
+    y = torch.zeros(B, H, W, Cout, dtype=BF, device=DEV)
+    call("conv_fwd_infer_bf16", ptr(xd), Cin, ptr(wf), ptr(bias.to(DEV)), act, ptr(rd) if with_res else None, Cout, ptr(y), Cout, B, H, W, Cin, Cout, k, 1, sp())
+    torch.cuda.synchronize()
+    close(y.permute(0, 3, 1, 2), ref.cpu())
+    from ep24 import _lib
+    assert _lib.lib().fn["ep24_conv_ring_timeouts"]() == 0
