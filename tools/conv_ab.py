@@ -19,13 +19,20 @@ if os.environ.get("EP24_AB_SHAPES"):                    # "B,H,Cin,Cout;..." (e.
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["EP24_AB_SHAPES"].split(";")]
 
 
-def graph_time(run, iters=20):
-    run()
+# EP24_AB_SETS=n (n > 1): every launch of a replay works on the next of n operand sets, so that it finds its operands as cold as a
+# launch of the training step does (round 4: the three-stage tiled form wins in the step and loses on one hot set - the answer of an A/B
+# depends on what the launch finds in the caches)
+NSET = max(1, int(os.environ.get("EP24_AB_SETS", "1")))
+
+
+def graph_time(run, iters=24):
+    for i in range(NSET):
+        run(i)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(iters):
-            run()
+        for i in range(iters):
+            run(i % NSET)
     g.replay()
     torch.cuda.synchronize()
     ts = []
@@ -46,12 +53,12 @@ def main():
     for B, H, Cin, Cout in SHAPES:
         W = H
         zero = os.environ.get("EP24_PROBE_ZERO") == "1"          # DVFS check: the same kernels on all-zero operands
-        x = torch.randn(B * H * W, Cin, device=DEV).to(torch.bfloat16) * (0 if zero else 1)
-        w = (torch.randn(Cout, 9, Cin, device=DEV) * 0.05).to(torch.bfloat16) * (0 if zero else 1)
-        wd = (torch.randn(Cin, 9, Cout, device=DEV) * 0.05).to(torch.bfloat16) * (0 if zero else 1)
-        y = torch.zeros(B * H * W, Cout, device=DEV, dtype=torch.bfloat16)
-        dy = torch.randn(B * H * W, Cout, device=DEV).to(torch.bfloat16) * (0 if zero else 1)
-        dx = torch.zeros(B * H * W, Cin, device=DEV, dtype=torch.bfloat16)
+        xs = [torch.randn(B * H * W, Cin, device=DEV).to(torch.bfloat16) * (0 if zero else 1) for _ in range(NSET)]
+        ws = [(torch.randn(Cout, 9, Cin, device=DEV) * 0.05).to(torch.bfloat16) * (0 if zero else 1) for _ in range(NSET)]
+        wds = [(torch.randn(Cin, 9, Cout, device=DEV) * 0.05).to(torch.bfloat16) * (0 if zero else 1) for _ in range(NSET)]
+        ys = [torch.zeros(B * H * W, Cout, device=DEV, dtype=torch.bfloat16) for _ in range(NSET)]
+        dys = [torch.randn(B * H * W, Cout, device=DEV).to(torch.bfloat16) * (0 if zero else 1) for _ in range(NSET)]
+        dxs = [torch.zeros(B * H * W, Cin, device=DEV, dtype=torch.bfloat16) for _ in range(NSET)]
         z = torch.randn(B * H * W, Cin, device=DEV).to(torch.bfloat16)
         stats = torch.zeros(8, 2, Cout, dtype=torch.int64, device=DEV)
         save = torch.ones(2, Cin, device=DEV)
@@ -61,11 +68,11 @@ def main():
         for kind in kinds:
             ko = [0]                                     # kernel_opts of the _ex entry points: bit 0 tiled kernel, bit 1 narrow epilogue
 
-            def run():
+            def run(s=0):
                 if kind == "fwd":
-                    call("conv_fwd_bf16_ex", ptr(x), Cin, ptr(w), ptr(y), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
+                    call("conv_fwd_bf16_ex", ptr(xs[s]), Cin, ptr(ws[s]), ptr(ys[s]), Cout, 0, 0, 0, None, ptr(stats), 8, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
                 elif kind == "dgrad":
-                    call("conv_dgrad_bf16_ex", ptr(dy), Cout, ptr(wd), ptr(dx), Cin, 0, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
+                    call("conv_dgrad_bf16_ex", ptr(dys[s]), Cout, ptr(wds[s]), ptr(dxs[s]), Cin, 0, B, H, W, Cin, Cout, 3, 1, ko[0], stream_ptr())
                 else:
                     raise SystemExit("kinds: fwd dgrad")
             res = {}
