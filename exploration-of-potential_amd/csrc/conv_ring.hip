@@ -79,6 +79,13 @@ __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& a, const bf16x8
 #endif
 }
 
+// The MFMAs above are plain inline asm: the compiler's hazard recogniser does not see an XDL write, so nothing is inserted between
+// the last v_mfma of the main loop and the first v_accvgpr_read of the epilogue.  The ISA asks for 11 wait states behind an 8-pass
+// MFMA (16 x 16 x 32) and 19 behind a 16-pass one (32 x 32 x 16) before a VALU instruction reads its destination; the epilogues open
+// with an s_barrier that takes far longer in practice, but "in practice" is not the contract.  20 wait states, once per
+// kernel, in front of every epilogue call.
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+
 typedef __attribute__((ext_vector_type(16))) float f32x16_;
 // ... and the 32 x 32 x 16 form: D[32 x 32] in 16 registers per lane (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column = lane & 31)
 __device__ __forceinline__ void mfma32_acc(f32x16_& c, const bf16x8& a, const bf16x8& b) {
@@ -991,10 +998,12 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
     const bool consumer = wave < NCW;
     if constexpr (M32) {
         if (consumer) consumer_main32(); else loader_main();
+        mfma_drain();
         ring_epilogue32(p, acc32, consumer, m0, n0, tile_m, smem);      // the host admits M32 only with the 16-byte store path
     } else {
         if constexpr (TBN == 64) { if (consumer) consumer_main_narrow(); else loader_main(); }
         else { if (consumer) consumer_main(); else loader_main(); }
+        mfma_drain();
         // LDS is nobody's any more: the last DMA landed before the last full count.  16-byte store path: all eight waves (the loaders
         // carry half of the stores); otherwise the loaders are done (a terminated wave no longer counts at s_barrier) and the four
         // consumers run the shared epilogue (a 2 x 2 grid of 128 x 64 pieces; the narrow tile: four 64 x 64 pieces over the rows).
@@ -1197,6 +1206,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
 
     const bool consumer = wave < NCW;
     if (consumer) consumer_main(); else loader_main();
+    mfma_drain();
     if (wide) ring_epilogue<RBN, MT>(p, acc, consumer, m0, n0, tile_m, smem);
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
 }

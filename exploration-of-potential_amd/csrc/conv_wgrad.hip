@@ -551,6 +551,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(const Wgra
 
     const bool consumer = wave < NCW;
     if (consumer) consumer_main(); else loader_main();
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");         // inline-asm MFMAs: the wait states in front of the first accumulator read (conv_ring.hip)
     // Epilogue, all eight waves: the accumulators go through LDS ([256 co][128 ci] fp32 = 128 KB over the three stages) and leave
     // as 16-byte stores into this split's slab.
     __syncthreads();

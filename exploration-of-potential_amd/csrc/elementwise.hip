@@ -1055,8 +1055,17 @@ __device__ __forceinline__ float ema_step(float e, float pnew, float d, float om
     return __fadd_rn(__fmul_rn(e, d), __fmul_rn(omd, pnew));
 }
 
+// Round 5: the update keeps the packed bf16 FORWARD copy of the conv weights current itself.  The flat buffer holds a conv weight
+// physically as [Cout][kh][kw][Cin] - for Cin % 8 == 0 exactly the layout of its packed copy - and segments start at multiples of
+// 64 elements, so a 4-element group of the update lies in one segment: `wf_delta[(base + i) >> 6]` is that segment's
+// (offset in wf) - (offset in the flat buffer), or INT_MIN for a group that has no such copy (BatchNorm vectors, biases, a conv with
+// a padded Cin row).  The step used to start with pack_batched_kernel re-reading all 217 MB of masters on the main lane (98 us on
+// the critical path of YOLOX-l, profiles/r04_step_timeline.csv); now the freshly written values leave as 8-byte bf16 stores from
+// the pass that has them in registers.  base = index of p[0] in the whole flat buffer (the range form passes p + first).
+constexpr int WF_NONE = -2147483647 - 1;
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float mom,
-                                                  float gscale, const int* first_flag, const float* hp, float* ema) {
+                                                  float gscale, const int* first_flag, const float* hp, float* ema,
+                                                  long base = 0, const int* wf_delta = nullptr, bf16* wf = nullptr) {
     const int first = *first_flag;
     float d = 0.f, omd = 0.f;
     if (hp) { lr = hp[0]; mom = hp[1]; gscale = hp[2]; d = hp[3]; omd = hp[4]; }
@@ -1065,6 +1074,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
             f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
             f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
             f32x4 bv = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(buf + i);
+            const int wd = wf_delta ? wf_delta[(base + i) >> 6] : WF_NONE;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float gg = gv[j] * gscale;
@@ -1073,6 +1083,12 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
             }
             *reinterpret_cast<f32x4*>(buf + i) = bv;
             *reinterpret_cast<f32x4*>(p + i) = pv;
+            if (wd != WF_NONE) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)pv[j];
+                *reinterpret_cast<bf16x4*>(wf + (base + i + wd)) = o;
+            }
             if (ema) {
                 f32x4 ev = *reinterpret_cast<const f32x4*>(ema + i);
 #pragma unroll
@@ -1086,6 +1102,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
                 buf[k] = b;
                 p[k] -= lr * (gg + mom * b);
                 if (ema) ema[k] = ema_step(ema[k], p[k], d, omd);
+                const int wd = wf_delta ? wf_delta[(base + k) >> 6] : WF_NONE;
+                if (wd != WF_NONE) wf[base + k + wd] = (bf16)p[k];
             }
         }
     }
@@ -1358,6 +1376,21 @@ extern "C" int ep24_sgd_nesterov_hp_range(float* p, const float* g, float* buf, 
                        ema ? ema + first : nullptr);
     if (last) hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
     EP24_LAUNCH_CHECK("ep24_sgd_nesterov_hp_range");
+    return EP24_OK;
+}
+
+// ... and with the packed forward copy of the conv weights written by the same pass (see sgd_kernel): wf_delta has one int32 per 64
+// elements of the WHOLE flat buffer, wf is the packed buffer's base.
+extern "C" int ep24_sgd_nesterov_hp_range_pack(float* p, const float* g, float* buf, int64_t first, int64_t n, const float* hp,
+                                               int32_t* first_flag, float* ema, int last, const int32_t* wf_delta, void* wf, void* stream) {
+    EP24_REQUIRE(p && g && buf && hp && first_flag && wf_delta && wf && n > 0 && first >= 0 && first % 4 == 0, EP24_E_ARG,
+                 "sgd_nesterov_hp_range_pack: bad arguments");
+    EP24_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf | (uintptr_t)ema) % 16 == 0 && (uintptr_t)wf % 16 == 0, EP24_E_ARG,
+                 "sgd_nesterov_hp_range_pack: 16-byte alignment");
+    hipLaunchKernelGGL(sgd_kernel, dim3(cap_grid((n + 3) / 4)), dim3(256), 0, S_, p + first, g + first, buf + first, n, 0.f, 0.f, 0.f, first_flag, hp,
+                       ema ? ema + first : nullptr, (long)first, (const int*)wf_delta, (bf16*)wf);
+    if (last) hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, S_, first_flag);
+    EP24_LAUNCH_CHECK("ep24_sgd_nesterov_hp_range_pack");
     return EP24_OK;
 }
 

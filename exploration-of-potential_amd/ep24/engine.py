@@ -225,7 +225,7 @@ class ParamHome:
         n = wf = wd = 0
         for seg in self.order:                      # execution order: backward completes the buffer from its tail
             seg.off = n
-            n += (seg.numel + 3) // 4 * 4
+            n += (seg.numel + 63) // 64 * 64        # 64-element alignment: a group of the update lies in ONE segment (wf_delta below)
         for seg in self.convs:
             seg.wf_off, seg.wd_off = wf, wd
             wf += seg.cout * seg.taps * seg.cin_pad
@@ -237,6 +237,21 @@ class ParamHome:
         self.wf = torch.zeros(max(wf, 8), dtype=BF16, device=dev)
         self.wd = torch.zeros(max(wd, 8), dtype=BF16, device=dev)
         self.first_flag = torch.ones(1, dtype=torch.int32, device=dev)
+        # Round 5: the fused update writes the packed forward copy itself (csrc/elementwise.hip sgd_kernel).  One int32 per 64 flat
+        # elements: (offset of the element's segment in wf) - (its offset in flat) for a conv weight whose Cin is a multiple of 8
+        # (its [Cout][T][Cin] master IS the packed layout), INT32_MIN otherwise (BatchNorm vectors, biases, padded-Cin convs: the
+        # Focus stem's 108 -> 112 columns).  `wf_current`: the packed copy follows the masters; anything that writes parameters
+        # other than the fused update (load_state_dict, a user's p.data.copy_) must clear it - mark_weights_changed() - and the
+        # next step packs everything once.
+        delta = torch.full((max(n // 64, 1),), -2 ** 31, dtype=torch.int32)
+        self.pack_rest = []                               # conv segments the update cannot keep current: packed every step
+        for seg in self.convs:
+            if seg.cin_pad == seg.cin:
+                delta[seg.off // 64:(seg.off + seg.numel + 63) // 64] = seg.wf_off - seg.off
+            else:
+                self.pack_rest.append(seg)
+        self.wf_delta = delta.to(dev)
+        self.wf_current = False
         # BatchNorm running statistics in one flat buffer too (module buffers become views): ModelEMA averages every
         # floating-point state_dict entry (utils/ema.py:55-60), i.e. these next to the parameters, in two launches
         paired = {id(b) for pair in self.merged_bn for b in pair}
@@ -274,6 +289,10 @@ class ParamHome:
         self.pack_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.pack_prefix = torch.tensor(pref, dtype=torch.int64, device=dev)
         self.pack_total = pref[-1]
+        for sub in model.modules():                       # load_state_dict writes parameters behind the fused update's back
+            if not getattr(sub, "_ep24_pack_hook", False):
+                sub.register_load_state_dict_post_hook(_weights_loaded)
+                sub._ep24_pack_hook = True
         self.views = {}                                   # param -> (flat view, grad view, momentum view)
         for sub in model.modules():                       # plans / homes of parts that ran on their own before are stale now
             if sub is not model:
@@ -318,6 +337,27 @@ class ParamHome:
              len(self.convs), ptr(self.wf), ptr(self.wd), self.pack_total, self.pack_tiles, ptr(self.pack_chunk_seg),
              ptr(self.pack_tile_seg), which, stream_ptr())
 
+    def mark_weights_changed(self):
+        """Parameters were written by something other than the fused update: the packed forward copy is stale until the next pack."""
+        self.wf_current = False
+
+    def pack_rest_forward(self):
+        """The forward copies the fused update does not write (padded-Cin convs: the Focus stem, a few KB): the packing kernel
+        over a descriptor table of just those segments."""
+        if not self.pack_rest:
+            return
+        if getattr(self, "_rest_tables", None) is None:
+            rows, pref, tpref = [], [0], [0]
+            for seg in self.pack_rest:
+                rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
+                pref.append(pref[-1] + seg.numel)
+                tpref.append(tpref[-1] + seg.taps * ((seg.cout + 63) // 64) * ((seg.cin + 63) // 64))
+            t = lambda v: torch.tensor(v, dtype=torch.int64, device=self.dev)
+            self._rest_tables = (t(rows), t(pref), t(tpref), len(rows), pref[-1], tpref[-1])
+        desc, pref, tpref, n, total, tiles = self._rest_tables
+        call("pack_weights_batched", ptr(self.flat), ptr(desc), ptr(pref), ptr(tpref), n, ptr(self.wf), ptr(self.wd), total, tiles,
+             None, None, 1, stream_ptr())
+
     def zero_grad(self):
         call("memset_zero", ptr(self.gflat), self.numel * 4, stream_ptr())
 
@@ -334,10 +374,19 @@ class ParamHome:
             raise _lib.Ep24Error("ep24: the EMA model's parameter layout differs from the trained model's")
         hi = self.numel if hi is None else hi
         if hi > lo:
-            call("sgd_nesterov_hp_range", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), lo, hi - lo, ptr(hp), ptr(self.first_flag),
-                 ptr(ema_home.flat) if ema_home is not None else None, 1 if last else 0, stream_ptr())
+            call("sgd_nesterov_hp_range_pack", ptr(self.flat), ptr(self.gflat), ptr(self.mflat), lo, hi - lo, ptr(hp), ptr(self.first_flag),
+                 ptr(ema_home.flat) if ema_home is not None else None, 1 if last else 0, ptr(self.wf_delta), ptr(self.wf), stream_ptr())
         if last and ema_home is not None and self.bnumel:
             call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
+
+
+def _weights_loaded(module, _incompatible_keys):
+    """load_state_dict post hook of every module of a model that lives in flat buffers (each module of the recursion calls its own
+    hooks, so a sub-module's load counts): the packed forward copy of whichever home its parameters live in is stale."""
+    for q in module.parameters(recurse=False):
+        h = getattr(q, "_ep24_home", None)
+        if h is not None:
+            h.mark_weights_changed()
 
 
 def _same_bn(a, b):
@@ -566,8 +615,8 @@ class Engine:
         """conv_fwd_bf16 / conv_dgrad_bf16 with the plan's kernel options (PlanOptions.conv_kernel_opts != 0: the _ex entry points);
         bit 8 of the options is the weight gradient's bit 0 (its loader / consumer ring form, an A/B option)."""
         ko = self.options.conv_kernel_opts
-        if ko & 0xFF and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
-            return name + "_ex", tuple(args) + (ko & 0xFF,)
+        if ko & 0x2FF and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
+            return name + "_ex", tuple(args) + (ko & 0x2FF,)
         if ko & 0x100 and name in ("conv_wgrad_slab_bf16", "side:conv_wgrad_slab_bf16"):
             return name + "_ex", tuple(args) + (1,)
         return name, tuple(args)

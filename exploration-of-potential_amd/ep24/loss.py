@@ -250,8 +250,12 @@ def _circle_lens(c_gtx, c_gty, gt_r, c_pdx, c_pdy, pd_r, pairwise):
     res = torch.zeros(n, 24, dtype=torch.float32, device=dev)
     dist = torch.zeros(n, 24, dtype=torch.float32, device=dev)
     if n:
-        call("circle_lens", ptr(f(c_gtx, G)), ptr(f(c_gty, G)), ptr(f(gt_r, G, 24)), ptr(f(c_pdx, P)), ptr(f(c_pdy, P)),
-             ptr(f(pd_r, P, 24)), ptr(res), ptr(dist), G, P, int(pairwise), stream_ptr())
+        # the converted operands stay bound until the launch is enqueued: a temporary made by f() (strided view, other dtype or
+        # device - the reference's own call passes pred[:, 0], pred[:, 1], pred[:, 2:]) would be freed as soon as ptr() returned
+        # and the caching allocator would hand the same block to the next f() of equal size
+        ops = [f(c_gtx, G), f(c_gty, G), f(gt_r, G, 24), f(c_pdx, P), f(c_pdy, P), f(pd_r, P, 24)]
+        call("circle_lens", *[ptr(o) for o in ops], ptr(res), ptr(dist), G, P, int(pairwise), stream_ptr())
+        del ops
     return res, dist
 
 

@@ -30,6 +30,7 @@ class PlanOptions:
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane
     forward_lanes: int = 2
+    fwd_order: int = 0                 # how the forward's two lanes are enqueued (ep24.train.TrainStep.step; A/B of round 5)
     bwd_cuts: Optional[Tuple[float, ...]] = None   # fractions of the backward list where its graph segments are cut (None: default)
     chunked_update: bool = True        # the optimizer update in pieces on the weight-gradient lane, each as soon as its gradients are complete
 
@@ -54,7 +55,7 @@ class PlanOptions:
             if k == "bwd_cuts":
                 kw[k] = (tuple((i + 1) / int(v[1:]) for i in range(int(v[1:]) - 1)) if v[0] == "u"
                          else tuple(float(x) for x in v.split(":")))
-            elif k in ("forward_lanes", "conv_kernel_opts"):
+            elif k in ("forward_lanes", "conv_kernel_opts", "fwd_order"):
                 kw[k] = int(v)
             else:
                 kw[k] = v.strip() not in ("0", "false", "False", "")

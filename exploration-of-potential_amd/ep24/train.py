@@ -160,7 +160,10 @@ class TrainStep:
         if not torch.cuda.is_current_stream_capturing():
             eng.draw_dropout()
         eng.zero_step_buffers()
-        self.home.pack(1)
+        # the packed forward copy of the weights is kept current by the fused update (round 5: csrc/elementwise.hip sgd_kernel;
+        # step() packs everything once when something else has written parameters); only the segments the update cannot write
+        # (padded-Cin convs: the Focus stem) are packed here - a few KB instead of 217 MB of masters at the head of the main lane
+        self.home.pack_rest_forward()
         eng.run_lane(self._fwd_split()[0])
 
     def _phase_loss(self):
@@ -350,6 +353,10 @@ class TrainStep:
             self.labels.copy_(labels, non_blocking=True)
         if self.graphs is None and self.use_graph:
             self._capture()
+        if self.use_graph and not self.home.wf_current:
+            # first step, a loaded checkpoint, parameters written from outside: the whole forward copy from the masters, once
+            self.home.pack(1)
+            self.home.wf_current = True
         self._push_hparams()
         eng.draw_dropout()                               # DenseNet backbone: this step's Dropout2d factors (device RNG)
         if not self.use_graph:
@@ -394,17 +401,41 @@ class TrainStep:
         elif isinstance(self.g_fwd, tuple):
             g1, g_main, g_side, g_loss = self.g_fwd
             main, side = torch.cuda.current_stream(), self._side
+            probe = getattr(self, "probe", None)      # tools/fwd_lanes_probe.py: timed events at the lane boundaries (outside a profiler)
+
+            def mark(name, stream):
+                if probe is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(stream)
+                    probe[name] = e
+            mark("start", main)
             g1.replay()
+            mark("fork", main)
+            order = self.eng.options.fwd_order
+            if order == 1:                            # A/B: a real dispatch between the graph and the event
+                _lib.call("memset_zero", _lib.ptr(self.hp) + 28, 4, _lib.stream_ptr())
             ev = torch.cuda.Event()
             ev.record(main)
-            g_main.replay()                           # the main lane's graph is enqueued first (see the backward loop)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                g_side.replay()
+            if order == 2:                            # A/B: the side lane's graph first
+                side.wait_event(ev)
+                mark("side_begin", side)
+                with torch.cuda.stream(side):
+                    g_side.replay()
+                g_main.replay()
+            else:
+                g_main.replay()                       # the main lane's graph is enqueued first (see the backward loop)
+                side.wait_event(ev)
+                mark("side_begin", side)
+                with torch.cuda.stream(side):
+                    g_side.replay()
+            mark("main_end", main)
+            mark("side_end", side)
             ev2 = torch.cuda.Event()
             ev2.record(side)
             main.wait_event(ev2)
+            mark("loss_begin", main)
             g_loss.replay()
+            mark("loss_end", main)
             with torch.cuda.stream(side):
                 self.g_pre_bwd.replay()                # beside the loss; backward starts behind both
             ev_pb = torch.cuda.Event()
@@ -482,4 +513,8 @@ class TrainStep:
             self.g_upd_early[1].replay()                     # the parameters below the cut; finishes the step
         else:
             self.g_upd.replay()
+        if getattr(self, "probe", None) is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            self.probe["end"] = e
         return self.ws.result

@@ -42,6 +42,28 @@ class SyntheticDataset(torch.utils.data.Dataset):
         return (img, lab, hw, ident)
 
 
+class ResumableSampler(torch.utils.data.Sampler):
+    """The epoch's index order of ``base`` (a SequentialSampler, or a DistributedSampler shard), with the first ``start`` indices
+    left out on the NEXT pass only: a run resumed inside an epoch continues with the batch it stopped in front of instead of
+    training the epoch's first batches twice and never reaching its tail.  ``len()`` stays the whole epoch's."""
+
+    def __init__(self, base):
+        self.base, self.start = base, 0
+
+    def set_epoch(self, epoch):
+        if hasattr(self.base, "set_epoch"):
+            self.base.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self.base)
+
+    def __iter__(self):
+        start, self.start = int(self.start), 0
+        for i, idx in enumerate(self.base):
+            if i >= start:
+                yield idx
+
+
 def raw_collate(items):
     """Batches of the raw source stay lists (images differ in size in a real dataset): ``DataPrefetcher`` hands them to
     ``TrainTransform.batch``."""

@@ -65,7 +65,7 @@ class Exp(BaseExp):
         the training process itself left the trainer at 0.21 of bench.py, four processes + page-locked batches bring 0.91 - and 0 for
         the raw uint8 source, whose batches are lists of cached images: 0.96, profiles/r04_trainer.json); ``pin``: page-locked batches
         (None: with loader processes and fp32 batches only)."""
-        from datasets import SyntheticDataset, raw_collate
+        from datasets import ResumableSampler, SyntheticDataset, raw_collate
         import torch
         import os
         self.dataset = SyntheticDataset(self.synthetic_len, tuple(self.input_size), self.synthetic_gts, self.num_classes, raw=raw_u8)
@@ -73,6 +73,9 @@ class Exp(BaseExp):
         sampler = None
         if world > 1:                                     # every rank walks its own shard of the epoch
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=world, rank=rank, shuffle=False)
+        else:
+            sampler = torch.utils.data.SequentialSampler(self.dataset)
+        sampler = ResumableSampler(sampler)               # .start: indices a resumed run has already trained on (train_24p.py)
         if workers is None:
             workers = 0 if raw_u8 else getattr(self, "loader_workers", 0)
         workers = int(workers)

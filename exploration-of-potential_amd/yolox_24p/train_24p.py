@@ -102,6 +102,13 @@ class Trainer:
         self.current_step = self.resumed_step(self.start_epoch, self.max_iter) if resumed_step is None else resumed_step
         # iterations of the start epoch that the checkpointed run had already done (a run cut short by --steps inside an epoch)
         skip_iters = min(max(self.current_step - self.start_epoch * self.max_iter, 0), self.max_iter)
+        # ... and the DATA position with it: the loader's first pass leaves those batches out (the epoch's first batches
+        # were trained twice and its tail never ran)
+        if skip_iters and hasattr(self.train_loader.sampler, "start"):
+            self.train_loader.sampler.start = skip_iters * args.batch_size
+        if args.throughput_json and args.steps and args.steps <= args.throughput_window:
+            print("train_24p.py: --throughput-window %d clamped to --steps %d - 1" % (args.throughput_window, args.steps))
+            args.throughput_window = max(args.steps - 1, 1)
         self.tblogger = SummaryWriter(self.file_name) if (SummaryWriter and self.rank == 0) else None
         self.lr_scheduler = exp.get_lr_scheduler(args.learn_rate, self.max_iter) if args.sched else None
         self.ema_model = None
@@ -176,6 +183,7 @@ class Trainer:
                     t_mark = now
                 if self.current_step % args.log_interval == 0:
                     self.TB_data(res, seen * self.world / (time.time() - t0))
+                    self.check_ring_guard()               # the log line has synchronised already
                 if tp_t0 is not None:
                     now = time.perf_counter()
                     host["rest"] += now - t_mark
@@ -205,11 +213,24 @@ class Trainer:
                 with open(args.throughput_json, "w") as fh:
                     json.dump(rec, fh)
                 print("throughput %s" % json.dumps(rec))
-        from ep24 import _lib
-        if _lib.lib().fn["ep24_conv_ring_timeouts"]() != 0:       # never seen; a broken hand-off would have produced wrong numbers
-            raise RuntimeError("train_24p.py: bounded waits of the loader / consumer ring kernels gave up during this run (ep24_conv_ring_timeouts)")
+        self.check_ring_guard()
         if self.world > 1:
             torch.distributed.destroy_process_group()
+
+    @staticmethod
+    def ring_timeouts():
+        from ep24 import _lib
+        return _lib.lib().fn["ep24_conv_ring_timeouts"]()
+
+    def check_ring_guard(self):
+        """A bounded wait of a loader / consumer ring kernel that gives up carries on with whatever is in LDS (by design: a protocol
+        error must never hang the GPU), so the convolutions of that launch are wrong.  Never seen outside development builds; read at
+        every log interval, BEFORE every checkpoint and at the end of the run, so that a run with a broken hand-off stops without
+        overwriting its last good checkpoint (the reference's cadence: train_24p.py:139-154)."""
+        n = self.ring_timeouts()
+        if n != 0:
+            raise RuntimeError("train_24p.py: %d bounded wait(s) of the loader / consumer ring kernels gave up (ep24_conv_ring_timeouts) at "
+                               "step %d: the run stops and no checkpoint is written over the last good one" % (n, self.current_step))
 
     @staticmethod
     def resumed_step(start_epoch, max_iter):
@@ -255,6 +276,7 @@ class Trainer:
     def save_ckpt(self, ckpt_name, update_best_ckpt=False):
         # the reference's three keys (train_24p.py:144-148) plus the global step: "start_epoch" is the first epoch that is NOT complete
         # (a run cut short by --steps inside an epoch resumes that epoch at the step it stopped, not at the next epoch's first step)
+        self.check_ring_guard()                           # raises before anything is written
         state = {"start_epoch": self.epoch + (1 if self.epoch_complete else 0), "model": self.model.state_dict(),
                  "optimizer": self.optimizer.state_dict(), "global_step": self.current_step}
         if self.ema_model is not None:

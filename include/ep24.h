@@ -36,7 +36,7 @@ const char* ep24_last_error(void);
 /* Bumped whenever an exported signature or the meaning of an argument changes.  2 (round 4): ep24_bn_act_bwd_reduce / _apply /
  * _apply_acc and ep24_pack_weights_batched took new arguments in round 3, ep24_conv_set_patch went away, the BatchNorm-backward sums
  * became 2^-36 fixed point, ep24_circle_lens is new.  A caller built against another version must not call in. */
-#define EP24_ABI_VERSION 2
+#define EP24_ABI_VERSION 3
 int ep24_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -69,7 +69,9 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * which the 256 x 128 ring does not take (bit-identical results; measured slower than the tiled kernel it would replace: an A/B
  * option); bit 7: the tiled kernel without its three-stage form (round 4: layers whose 128-wide tiles leave at most one workgroup per
  * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
- * two-stage tiles as before; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * two-stage tiles as before; bit-identical results); bit 9: the parity classes of a stride-2 input gradient dealt class by class
+ * inside their one launch (the order before round 5; default: interleaved, an XCD runs every class and N tile of an M tile back to
+ * back so that the classes share their dy rows in its L2; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
@@ -164,7 +166,7 @@ int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats
 
 /* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
  * 2^-36 fixed-point int64 (NOT the forward statistics' 2^-20: gradient sums of the head are 1e-5 .. 1e-4 per workgroup; a workgroup's
- * partial sum must stay below 2^17 in magnitude - one that does not, or is NaN, makes the channel's folded sum NaN), kept in `reps` replicas (replica r of either sum 2*C*r elements behind
+ * partial sum must stay below 2^13 in magnitude - one that does not, or is NaN, makes the channel's folded sum NaN), kept in `reps` replicas (replica r of either sum 2*C*r elements behind
  * the pointer, i.e. [reps][2][C] when dbeta = dgamma + C; a workgroup adds to replica blockIdx % reps): the memory-side atomic
  * units serialise the adds to one address, and with a single copy every workgroup of the launch hit the same 2 C addresses. */
 int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
@@ -370,6 +372,12 @@ int ep24_sgd_nesterov_hp(float* p, const float* g, float* buf, int64_t n, const 
  * first_flag); ema, if given, is the EMA copy's flat buffer (same layout). */
 int ep24_sgd_nesterov_hp_range(float* p, const float* g, float* buf, int64_t first, int64_t n, const float* hp,
                                int32_t* first_flag, float* ema, int last, void* stream);
+/* ... and the packed bf16 FORWARD copy of the conv weights kept current by the same pass (round 5; ABI 3): the flat buffer holds a
+ * conv weight as [Cout][kh][kw][Cin], which for Cin % 8 == 0 is the layout of its packed copy, and segments start at multiples of 64
+ * elements; wf_delta[e >> 6] = (offset of element e's segment in wf) - (its offset in the flat buffer), INT32_MIN for groups without
+ * such a copy (those still go through ep24_pack_weights_batched).  The step no longer re-reads the masters to pack them. */
+int ep24_sgd_nesterov_hp_range_pack(float* p, const float* g, float* buf, int64_t first, int64_t n, const float* hp,
+                                    int32_t* first_flag, float* ema, int last, const int32_t* wf_delta, void* wf, void* stream);
 /* ModelEMA.update over one flat buffer (parameters, or the BatchNorm running statistics); hp non-null overrides
  * decay / one_minus_decay with hp[3] / hp[4]. */
 int ep24_ema_update(float* ema, const float* src, int64_t n, float decay, float one_minus_decay, const float* hp,

@@ -125,6 +125,8 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # the ring without a patch (round 4; kernel_opts bit 4; an 8th value is the kernel id the shape must dispatch to with it): the 4-step 1x1 layer of the
     # 40x40 level, a 1x1 layer with M, N and K tails, a stride-2 3x3 layer with a K tail
     (20, 40, 256, 256, 1, 1, 40, 4), (13, 50, 200, 264, 1, 1, 47, 4), (20, 90, 72, 136, 3, 2, 86, 4),
+    # a stride-2 layer on an ODD image: the parity classes of its input gradient differ in M, so the class-major tile order stays (round 5)
+    (3, 27, 24, 40, 3, 2, 31, 0),
     # the NARROW ring (256 x 64 tiles, kernel_opts bit 6, an A/B option; a 9th value = the kernel_opts the id is asked under): the 20 x 20
     # level of YOLOX-l, which 256 x 128 tiles do not spread over the chip; M and N tails; a K tail over two patch buffers; N = 64 with one chunk and the widest patch
     # (W = 160: three patch pieces per loader and step); N = 64 with an M tail
@@ -181,6 +183,8 @@ def test_conv_hot_shapes(shape):
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
     # key 4: the narrow ring where it fits; key 5 (bits 0 + 7): the tiled kernel WITHOUT its three-stage form (the 20 x 20 level)
     variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((2, 0), (0, 16), (5, 128))
+    if k == 3 and s == 2:                                                  # key 6 (bit 9): the parity classes of the input gradient dealt class by class
+        variants += ((6, 512),)                                            # (the order before round 5; the default interleaves them per M tile)
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
@@ -416,6 +420,42 @@ def test_bn_silu_fwd_bwd(M, C, res):
     close(dz, zr.grad, rel=2e-2)
     close(ggrad - 1, g_.grad, rel=5e-3)
     close(bgrad - 1, b_.grad, rel=5e-3)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_bn_backward_keeps_a_diverged_gradient_visible(bad):
+    """one NaN / Inf in dy of ONE block's rows, with net-NEGATIVE sums everywhere else (the usual start of a
+    divergence): the channel's gamma / beta gradients must read NaN, not a finite value decoded from 'marker minus the rest' -
+    and every other channel stays finite and right."""
+    call, ptr, sp = _abi()
+    M, C = 32000, 256
+    z = rnd(M, C, seed=41, scale=2.0)
+    dy = -(rnd(M, C, seed=42).float().abs() + 0.5).to(BF)              # every du sum negative and large
+    dy[12345, 7] = bad
+    gamma, beta = torch.rand(C) + 0.5, torch.rand(C) - 0.5
+    zd, dyd, gd, bd = z.to(DEV), dy.to(DEV), gamma.to(DEV), beta.to(DEV)
+    R = 2
+    stats = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+    stats[0, 0] = (z.double().sum(0) * 2 ** 20).round().long().to(DEV)
+    stats[0, 1] = ((z.double() ** 2).sum(0) * 2 ** 20).round().long().to(DEV)
+    save = torch.zeros(2, C, device=DEV)
+    rmd, rvd, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    y = torch.zeros(M, C, dtype=BF, device=DEV)
+    call("bn_act_fwd", ptr(zd), C, ptr(stats), R, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), ptr(nbt), ptr(None), ptr(save), ptr(y), C,
+         ptr(None), 0, M, C, 1e-3, 0.03, 1, sp())
+    for reps in (1, 8):
+        sums = torch.zeros(reps, 2, C, dtype=torch.int64, device=DEV)
+        ggrad, bgrad = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        call("bn_act_bwd_reduce", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), M, C, 1, reps, sp())
+        dz = torch.zeros(M, C, dtype=BF, device=DEV)
+        call("bn_act_bwd_apply", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), ptr(ggrad),
+             ptr(bgrad), ptr(dz), C, M, C, 1, reps, sp())
+        g, b = ggrad.cpu(), bgrad.cpu()
+        assert torch.isnan(g[7]) and torch.isnan(b[7]), (reps, float(g[7]), float(b[7]))
+        ok = torch.ones(C, dtype=torch.bool)
+        ok[7] = False
+        assert torch.isfinite(g[ok]).all() and torch.isfinite(b[ok]).all()
+        assert float(b[ok].max()) < 0                                  # the negative rest is really there
 
 
 def test_spp_fwd_bwd():

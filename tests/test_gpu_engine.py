@@ -374,6 +374,67 @@ def test_chunked_update_equals_the_single_update():
     assert la == lb and torch.equal(wa, wb) and torch.equal(ma, mb)
 
 
+def test_update_keeps_the_packed_forward_weights_current():
+    """Round 5: the captured step no longer re-packs the fp32 masters into the bf16 forward copy at its head; the fused update
+    (chunked over the weight-gradient lane + the two-part tail) writes the copy itself.  After every step the copy must equal a
+    fresh pack of the masters BIT FOR BIT (same round-to-nearest-even conversion, every conv segment, the padded-Cin Focus stem
+    through its own small pack), and parameters written from outside (load_state_dict, also of a sub-module) must be picked up."""
+    from ep24 import loss as eloss, train as etrain
+    torch.manual_seed(0)
+    m = tiny_model()
+    m.head.initialize_biases(1e-2)
+    ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.01, momentum=0.9, batch=4, size=256)
+    ts.eng.images.copy_(synth.make_images(4, 256, seed=1).to(DEV))
+    ts.labels.copy_(synth.make_labels(4, 3, size=256, seed=1000).to(DEV))
+    home = ts.home
+    assert home.pack_rest and len(home.pack_rest) < len(home.convs)         # the stem (Cin 108 -> 112) is the exception, not the rule
+    assert all(seg.off % 64 == 0 for seg in home.order)
+
+    def fresh():
+        keep = home.wf.clone()
+        home.wf.zero_()
+        home.pack(1)
+        torch.cuda.synchronize()
+        want = home.wf.clone()
+        home.wf.copy_(keep)
+        return want
+
+    losses = []
+    for i in range(4):
+        losses.append(float(ts.step()[0]))
+        torch.cuda.synchronize()
+        want = fresh()
+        # the stem's copy is packed at the head of the NEXT step; everything else must already be current
+        for seg in home.convs:
+            a, b = home.wf[seg.wf_off:seg.wf_off + seg.cout * seg.taps * seg.cin_pad], want[seg.wf_off:seg.wf_off + seg.cout * seg.taps * seg.cin_pad]
+            if seg in home.pack_rest:
+                continue
+            assert torch.equal(a, b), (i, seg.off)
+    assert losses[0] != losses[1] and all(np.isfinite(losses))
+    # the same run with a full pack before every step: identical losses (the copy the step used was the right one, stem included)
+    torch.manual_seed(0)
+    m2 = tiny_model()
+    m2.head.initialize_biases(1e-2)
+    ts2 = etrain.TrainStep(m2, eloss.Loss_Function(80), lr=0.01, momentum=0.9, batch=4, size=256)
+    ts2.eng.images.copy_(ts.eng.images)
+    ts2.labels.copy_(ts.labels)
+    losses2 = []
+    for i in range(4):
+        ts2.home.mark_weights_changed()
+        losses2.append(float(ts2.step()[0]))
+    assert losses2 == losses
+    # parameters written from outside: load_state_dict on the model, then on a sub-module only
+    sd = {k: (v * 0.5 if v.is_floating_point() and v.dim() == 4 else v) for k, v in m.state_dict().items()}
+    assert home.wf_current
+    m.load_state_dict(sd)
+    assert not home.wf_current
+    l_half = float(ts.step()[0])
+    torch.cuda.synchronize()
+    assert home.wf_current and np.isfinite(l_half) and l_half != losses[-1]
+    m.head.load_state_dict(m.head.state_dict())
+    assert not home.wf_current
+
+
 def test_fused_bn_reduce_plan_matches_the_default_plan():
     """PlanOptions(fuse_bn_reduce=True) (off by default: slower in the step) drops the BatchNorm-backward reduce
     launch of every unit whose only consumer is a 3x3 stride-1 conv and takes the two sums in that conv's input-gradient epilogue:

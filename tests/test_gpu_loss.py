@@ -48,17 +48,28 @@ def test_circle_inter_vs_golden_g1_and_oracle(L, golden):
     """circle_inter on the product surface: the method IOUloss.circle_inter (losses.py:23-78, matched rows) against
     the reference's own output G1 - all three branches, branch by branch, and the empty input - and the module-level pairwise
     form (utils/boxes.py:102-163) against the oracle's broadcast restatement in the reference's g-major pair order.
-    dist is the sqrt of uncontracted products (the device's sqrtf and ATen's differ in the last bit on some inputs: 2 ulp).  The
-    branch a pair falls into is decided on the REFERENCE's distances; a pair within an ulp of a branch boundary would show as a
-    mismatch of the exact-valued branches below, and the vector has none.  The lens adds device acosf / sinf (a few ulp on
-    terms up to 75 times the result): 3e-5 relative plus 1e-6 of the two circles' areas."""
+    dist = sqrt(dx * dx + dy * dy) of uncontracted fp32 products on both sides; the sum under the root is bit-identical.  The
+    DEVICE's sqrtf is correctly rounded (hipcc's default expansion: v_sqrt_f32 plus the +-1 ulp residual fix-up, visible in the
+    kernel's ISA) and is required here to EQUAL the correctly rounded root bit for bit.  ATen's CPU sqrt is the one that is not:
+    torch 2.10 hands contiguous fp32 sqrt to MKL's VML in its "high accuracy" mode, which returns the value one ulp BELOW the
+    correctly rounded one on ~0.6 % of inputs (profiles/r05_sqrt_table.txt, tests/test_oracle_geometry.py::
+    test_aten_cpu_sqrt_is_not_correctly_rounded; numpy's and float64-then-round agree with each other and with the device) -
+    1 of the 96 distances of G1.  So the golden distances are matched to <= 1 ulp, and exactly wherever the golden value is the
+    correctly rounded one.  The branch a pair falls into is decided on the REFERENCE's distances; a pair within an ulp of a
+    branch boundary would show as a mismatch of the exact-valued branches below, and the vector has none.  The lens adds device
+    acosf / sinf (a few ulp on terms up to 75 times the result): 3e-5 relative plus 1e-6 of the two circles' areas."""
     from oracle import geometry
     z = golden("g1_circle_inter")
     arg = [t(z[k]).to(DEV) for k in ("gt_cx", "gt_cy", "gt_r", "pd_cx", "pd_cy", "pd_r")]
     iou = L.IOUloss("none")
     res, dist = iou.circle_inter(*arg)
     want_res, want_dist = t(z["res_inter"]), t(z["dist"])
-    torch.testing.assert_close(dist.cpu(), want_dist, rtol=2.5e-7, atol=0)                # sqrt of a rounded sum of squares: <= 2 ulp
+    # the correctly rounded root of the (bit-identical) fp32 sum: float64 sqrt of a float32, rounded once more, is exact
+    ssum = (t(z["gt_cx"]) - t(z["pd_cx"])) ** 2 + (t(z["gt_cy"]) - t(z["pd_cy"])) ** 2
+    exact = torch.sqrt(ssum.double()).float().unsqueeze(1).repeat(1, 24)
+    assert torch.equal(dist.cpu(), exact), "the device sqrtf is not the correctly rounded one"
+    ulp = (dist.cpu().view(torch.int32) - want_dist.view(torch.int32)).abs()
+    assert int(ulp.max()) <= 1 and torch.equal(ulp > 0, want_dist != exact)                # only where MKL's sqrt is a ulp low
     gt_r, pd_r = t(z["gt_r"]), t(z["pd_r"])
     contained = (gt_r - pd_r).abs() >= want_dist
     disjoint = want_dist >= gt_r + pd_r
@@ -91,13 +102,38 @@ def test_circle_inter_vs_golden_g1_and_oracle(L, golden):
     ex = lambda a, n: a.reshape(G, 1, n).expand(G, P, n).reshape(G * P, n)                # repeat_interleave(P, 0)
     ep = lambda a, n: a.reshape(1, P, n).expand(G, P, n).reshape(G * P, n)                # repeat(G, 1)
     want_res, want_dist = geometry.matched_lens(ex(gx, 1)[:, 0], ex(gy, 1)[:, 0], ex(gr, 24), ep(px, 1)[:, 0], ep(py, 1)[:, 0], ep(pr_, 24))
-    torch.testing.assert_close(dist.cpu(), want_dist, rtol=2.5e-7, atol=0)
+    exact = torch.sqrt(((ex(gx, 1) - ep(px, 1)) ** 2 + (ex(gy, 1) - ep(py, 1)) ** 2).double()).float().repeat(1, 24)
+    assert torch.equal(dist.cpu(), exact)                                                 # correctly rounded, bit for bit
+    torch.testing.assert_close(dist.cpu(), want_dist, rtol=1.2e-7, atol=0)                # the oracle's (ATen's) root: <= 1 ulp
     # The lens area is a difference of terms of the size of the circles' areas (2a r^2 - r d sin a: for barely overlapping circles 75
     # times the result), each carrying a few ulp of acosf / sinf on either side: the honest bound is in units of those terms
     term = 3.1415927 * (ex(gr, 24) ** 2 + ep(pr_, 24) ** 2)
     err = (res.cpu() - want_res).abs()
     assert bool((err <= 3e-5 * want_res.abs() + 1e-6 * term).all()), float((err / (term + 1e-9)).max())
     assert L.circle_inter(gx[:0].to(DEV), gy[:0].to(DEV), gr[:0].to(DEV), px.to(DEV), py.to(DEV), pr_.to(DEV))[0].shape == (0, 24)
+
+
+def test_circle_inter_strided_and_float64_inputs(L):
+    """the reference calls circle_inter with COLUMN SLICES (losses.py:109-122: pred[:, 0], pred[:, 1], pred[:, 2:]) -
+    every operand is then a strided view that has to be copied, and the copies of equal size must not share a block."""
+    g = torch.Generator().manual_seed(11)
+    N = 257
+    pred = (torch.rand(N, 26, generator=g) * 300 + 5).to(DEV)
+    tgt = (torch.rand(N, 50, generator=g) * 300 + 5).to(DEV)
+    iou = L.IOUloss("none")
+    cols = (tgt[:, 0], tgt[:, 1], tgt[:, 2:26], pred[:, 0], pred[:, 1], pred[:, 2:])
+    assert not any(c.is_contiguous() for c in cols)
+    want = iou.circle_inter(*[c.contiguous() for c in cols])
+    got = iou.circle_inter(*cols)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    got64 = iou.circle_inter(*[c.double() for c in cols])                                 # converted to fp32 on the way in
+    assert torch.equal(got64[0], want[0]) and torch.equal(got64[1], want[1])
+    # centre x and y must not have been read from one buffer: the distances depend on both
+    only_x = iou.circle_inter(cols[0], cols[0], cols[2], cols[3], cols[3], cols[5])
+    assert not torch.equal(only_x[1], want[1])
+    pw = L.circle_inter(tgt[:5, 0], tgt[:5, 1], tgt[:5, 2:26], pred[:, 0], pred[:, 1], pred[:, 2:])
+    pw_c = L.circle_inter(*[c.contiguous() for c in (tgt[:5, 0], tgt[:5, 1], tgt[:5, 2:26], pred[:, 0], pred[:, 1], pred[:, 2:])])
+    assert torch.equal(pw[0], pw_c[0]) and torch.equal(pw[1], pw_c[1])
 
 
 def test_matched_loss_and_grad_vs_golden(L, golden):
