@@ -38,6 +38,15 @@ def conv_shape(name, args):
     return args[6:13] if name.startswith("conv_dgrad") else args[-7:]
 
 
+def group_rows(args):
+    """The (B, H, W, Cin, Cout, k, s) of the problems of a grouped weight-gradient launch: its first argument is the address of a HOST
+    int64 table [n][17] (include/ep24.h, ep24_conv_wgrad_group_bf16), n the second."""
+    import ctypes
+    ptr, n = args[0], args[1]
+    t = (ctypes.c_int64 * (17 * n)).from_address(ptr)
+    return [tuple(int(t[17 * i + j]) for j in range(9, 16)) for i in range(n)]
+
+
 def conv_flops(args):
     B, H, W, Cin, Cout, k, s = args
     OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
@@ -114,7 +123,11 @@ def instrumented_step(ts):
             assert rc == 0, (name, _lib.lib().last_error())
             if timed:
                 e1.record()
-                rec.append((name, conv_flops(conv_shape(name, args)), e0, e1, conv_bytes(conv_shape(name, args))))
+                if name == "conv_wgrad_group_bf16":
+                    shapes = group_rows(a)
+                    rec.append((name, sum(conv_flops(sh) for sh in shapes), e0, e1, sum(conv_bytes(sh) for sh in shapes)))
+                else:
+                    rec.append((name, conv_flops(conv_shape(name, args)), e0, e1, conv_bytes(conv_shape(name, args))))
 
     ts.home.zero_grad()
     eng.zero_step_buffers()
@@ -128,6 +141,14 @@ def instrumented_step(ts):
     if os.environ.get("EP24_LAYER_TABLE"):
         rows = {}
         for (name, fl, e0, e1, _by), (_, args) in zip(rec, [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]):
+            if name == "conv_wgrad_group_bf16":          # a grouped launch: its time goes to its problems by their share of the FLOPs
+                shapes = group_rows(args)
+                for sh in shapes:
+                    r = rows.setdefault(("conv_wgrad_grouped",) + tuple(sh), [0, 0.0, 0.0])
+                    r[0] += 1
+                    r[1] += conv_flops(sh)
+                    r[2] += e0.elapsed_time(e1) * conv_flops(sh) / fl
+                continue
             key = (name,) + tuple(conv_shape(name, args))
             r = rows.setdefault(key, [0, 0.0, 0.0])
             r[0] += 1

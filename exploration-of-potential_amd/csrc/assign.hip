@@ -165,7 +165,10 @@ __global__ __launch_bounds__(COST_NT) void cost_kernel(const float* outputs, int
     __shared__ unsigned long long s_both[COST_APB];
     __shared__ int s_anchor[COST_APB];
     __shared__ int gcls[G_MAX];
-    __shared__ int s_nc;
+    __shared__ int s_nc, s_nq;
+    __shared__ float terms[24][COST_NT];                           // the 24 ray terms of the batch's pairs, ray-major
+    __shared__ float s_d[COST_NT];                                 // centre distance of the batch's pairs
+    __shared__ unsigned short queue[COST_NT * 24];                 // (pair of the batch) * 24 + ray of the items that need the lens
     const int b = blockIdx.y;
     const int ng = num_gt[b];
     // ---- compaction by the first wave: slot of an anchor among the candidates of the workgroup (anchor order is kept)
@@ -196,35 +199,88 @@ __global__ __launch_bounds__(COST_NT) void cost_kernel(const float* outputs, int
         const float* o = outputs + ((long)b * A + a) * ncols;
         for (int k = 0; k < 24; ++k) spr[k][slot] = o[2 + k];
         s_pcx[slot] = o[0]; s_pcy[slot] = o[1];
-        const float so = 1.0f / (1.0f + expf(-o[26]));
-        // sum over classes of the "target 0" BCE term: -max(log1p(-p), -100), p = sqrt(sigmoid(cls)*sigmoid(obj))
-        float s0 = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + c]))) * so);
-            s0 += -fmaxf(log1pf(-p), -100.f);
-        }
-        s_so[slot] = so; s_s0[slot] = s0; s_both[slot] = mb & mc; s_anchor[slot] = a;
+        s_so[slot] = 1.0f / (1.0f + expf(-o[26]));
+        s_both[slot] = mb & mc; s_anchor[slot] = a;
     }
     __syncthreads();
-    // ---- the (candidate, GT) pairs of the workgroup, candidate fastest: the lanes of a wave hold neighbouring anchors against
-    // ONE GT, so they agree on "far from it" and skip the lens arithmetic of ray_giou together
+    // sum over classes of the "target 0" BCE term: -max(log1p(-p), -100), p = sqrt(sigmoid(cls)*sigmoid(obj)).  Round 5: the C terms
+    // of a candidate are evaluated by four threads (the compacting wave alone used to walk all C of them while three waves
+    // waited) into LDS and then added by one thread in class order - the same terms, the same order of the sum.
+    {
+        float* ct = &terms[0][0];                                   // [COST_APB][C] while no batch is in flight (C <= 96)
+        const int sl = threadIdx.x >> 2, part = threadIdx.x & 3;
+        if (sl < nc) {
+            const float* o = outputs + ((long)b * A + s_anchor[sl]) * ncols;
+            const float so = s_so[sl];
+            for (int c = part; c < C; c += 4) {
+                const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + c]))) * so);
+                ct[sl * C + c] = -fmaxf(log1pf(-p), -100.f);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            float s0 = 0.f;
+            for (int c = 0; c < C; ++c) s0 += ct[threadIdx.x * C + c];
+            s_s0[threadIdx.x] = s0;
+        }
+        __syncthreads();
+    }
+    // ---- the (candidate, GT) pairs of the workgroup, candidate fastest, 256 at a time.
+    // Round 5: the lens of two properly intersecting circles (two divisions, two acosf, one sinf: ~9/10 of ray_giou's instructions)
+    // is needed by a few per cent of the (pair, ray) items - a candidate lies in the annulus |r1 - r2| < d < r1 + r2 of few GT rays -
+    // but the lanes of a wave hold 64 neighbouring anchors (512 px at stride 8) against one GT, so some lane nearly always needed it
+    // and the wave-uniform skip inside ray_giou rarely fired: 229 us of VALU time on the step's critical path
+    // (profiles/r04_step_timeline.csv).  Now a pass over the batch evaluates the contained / disjoint rays in place (ray_giou's
+    // lens block is skipped: no lane of the wave enters it) and queues the others in LDS; the queue is then evaluated densely, every
+    // lane a lens; each pair finally adds its 24 terms in ray order.  Same expressions per term, same order of the sum: bit-identical
+    // pw / cost.
     const int npair = nc * ng;
-    for (int pi = threadIdx.x; pi < npair; pi += COST_NT) {
-        const int g = pi / nc, c = pi - g * nc;
-        const int an = s_anchor[c];
-        const float* o = outputs + ((long)b * A + an) * ncols;
-        const float ddx = gcx[g] - s_pcx[c], ddy = gcy[g] - s_pcy[c];
-        const float d = sqrtf(ddx * ddx + ddy * ddy);
-        float acc = 0.f;
-        for (int k = 0; k < 24; ++k) acc += 1.0f - ray_giou(gr[g][k], spr[k][c], d);
-        const float v = acc / 24.0f / 2.0f;                        // boxes.py:238-241
-        const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + gcls[g]]))) * s_so[c]);
-        const float cls_cost = s_s0[c] - (-fmaxf(log1pf(-p), -100.f)) + (-fmaxf(logf(p), -100.f));
-        const bool both = (s_both[c] >> g) & 1ull;
-        const float cst = cls_cost + 3.0f * (-logf(v + 1e-8f)) + 100000.0f * (both ? 0.0f : 1.0f);   // losses.py:420-424
-        const long idx = ((long)b * G_MAX + g) * A + an;
-        pw[idx] = v;
-        cost[idx] = cst;
+    for (int base = 0; base < npair; base += COST_NT) {
+        const int pi = base + threadIdx.x;
+        const bool live = pi < npair;
+        int g = 0, c = 0;
+        float d = 0.f;
+        if (threadIdx.x == 0) s_nq = 0;
+        __syncthreads();                                           // also: the previous batch's terms have been read
+        if (live) {
+            g = pi / nc; c = pi - g * nc;
+            const float ddx = gcx[g] - s_pcx[c], ddy = gcy[g] - s_pcy[c];
+            d = sqrtf(ddx * ddx + ddy * ddy);
+            s_d[threadIdx.x] = d;
+            for (int k = 0; k < 24; ++k) {
+                const float r1 = gr[g][k], r2 = spr[k][c];
+                if (fabsf(r1 - r2) >= d || d >= r1 + r2) {          // contained or disjoint: no lens (the predicates of ray_giou)
+                    terms[k][threadIdx.x] = 1.0f - ray_giou(r1, r2, d);
+                } else {
+                    const int qi = atomicAdd(&s_nq, 1);
+                    queue[qi] = (unsigned short)(threadIdx.x * 24 + k);
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = s_nq;
+        for (int i = threadIdx.x; i < nq; i += COST_NT) {
+            const int it = queue[i];
+            const int t = it / 24, k = it - t * 24;
+            const int p2 = base + t;
+            const int g2 = p2 / nc, c2 = p2 - g2 * nc;
+            terms[k][t] = 1.0f - ray_giou(gr[g2][k], spr[k][c2], s_d[t]);
+        }
+        __syncthreads();
+        if (live) {
+            const int an = s_anchor[c];
+            const float* o = outputs + ((long)b * A + an) * ncols;
+            float acc = 0.f;
+            for (int k = 0; k < 24; ++k) acc += terms[k][threadIdx.x];
+            const float v = acc / 24.0f / 2.0f;                    // boxes.py:238-241
+            const float p = sqrtf((1.0f / (1.0f + expf(-o[27 + gcls[g]]))) * s_so[c]);
+            const float cls_cost = s_s0[c] - (-fmaxf(log1pf(-p), -100.f)) + (-fmaxf(logf(p), -100.f));
+            const bool both = (s_both[c] >> g) & 1ull;
+            const float cst = cls_cost + 3.0f * (-logf(v + 1e-8f)) + 100000.0f * (both ? 0.0f : 1.0f);   // losses.py:420-424
+            const long idx = ((long)b * G_MAX + g) * A + an;
+            pw[idx] = v;
+            cost[idx] = cst;
+        }
     }
 }
 
@@ -380,6 +436,7 @@ extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* la
                                 int num_classes, void* stream) {
     EP24_REQUIRE(outputs && labels && num_gt && in_box && in_ctr && pw && cost, EP24_E_ARG, "assign_cost: null pointer");
     EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "assign_cost: ncols=%d != 27+%d", ncols, num_classes);
+    EP24_REQUIRE(num_classes >= 1 && COST_APB * num_classes <= 24 * COST_NT, EP24_E_UNSUPPORTED, "assign_cost: at most %d classes", 24 * COST_NT / COST_APB);
     hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(A, COST_APB), B), dim3(COST_NT), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
                        (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, pw, cost, A, num_classes);
     EP24_LAUNCH_CHECK("ep24_assign_cost");

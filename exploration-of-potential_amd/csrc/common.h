@@ -76,20 +76,25 @@ __device__ __forceinline__ float from_fix(long long v) { return (float)((double)
 // workgroup's partial sum is 1e-5 .. 1e-4, i.e. 10 .. 100 units of 2^-20 - round 3 found channels whose gamma / beta gradient had
 // rounded to exactly 0 that way (0.8 % of the channels of the head's first class conv).  They use 2^-36: resolution 1.5e-11,
 // valid range |partial sum| < 2^17 (gradient sums over 2 M pixels stay many orders below that).
-// A diverged gradient must stay visible: __float2ll_rn turns NaN into 0 and 2^-36 wraps at |v| >= 2^27, so a partial
-// sum that is NaN or beyond 2^13 (no real workgroup sum comes within orders of magnitude of it) is replaced by the marker 2^50, and
-// from_fix_g answers NaN for any fold at or beyond HALF the marker in either direction: one marker plus a net-negative rest
-// (|rest| < 2^13 in real units, i.e. < 2^49 here) still reads >= 2^49, and up to 8 191 markers in one word stay below 2^63 (the
-// fused-sums path adds thousands of tile partials to a few replicas; the first form's marker 2^53 wrapped to 0 at 2 048 adds and
-// hid behind a negative rest).  Legitimate totals are many orders below 2^13.
-#define EP24_FIXG_MARK (1LL << 50)
+// A diverged gradient must stay visible: __float2ll_rn turns NaN into 0 and the scaled value wraps beyond 2^27, so
+// a partial sum that is NaN or beyond 2^20 in magnitude (sums of O(1) gradients over 2 M pixels stay below it; real ones by orders
+// of magnitude) is replaced by the marker 2^57, and a word decodes to NaN when it is at or beyond 2^56 in EITHER direction:
+//   - a legitimate word is a sum of partials below 2^56 (2^20 real) in magnitude that itself stays below it;
+//   - one marker plus ANY legitimate rest (also a net-negative one: the first form, marker 2^53 tested with v >= 2^53, decoded
+//     "marker minus rest" as a finite number) is >= 2^56;
+//   - k markers wrap the int64 only at k = 128: for k < 64 the word is >= 2^56, for 64 <= k < 128 it is <= -2^57.  A replica
+//     word collects at most grid / replicas partials (<= 64 on the standard path); the fold tests every replica word by itself
+//     before adding them (fixg_bad), so replicas cannot cancel each other's markers.
+#define EP24_FIXG_MARK (1LL << 57)
+#define EP24_FIXG_LIMIT (1LL << 56)
 __device__ __forceinline__ long long to_fix_g(float v) {
     const float a = fabsf(v);
-    if (!(a < 8192.0f)) return EP24_FIXG_MARK;                   // also NaN (the comparison is false)
+    if (!(a < 1048576.0f)) return EP24_FIXG_MARK;                // also NaN (the comparison is false)
     return (long long)__float2ll_rn(v * 68719476736.0f);
 }
+__device__ __forceinline__ bool fixg_bad(long long v) { return v >= EP24_FIXG_LIMIT || v <= -EP24_FIXG_LIMIT; }
 __device__ __forceinline__ float from_fix_g(long long v) {
-    if (v >= EP24_FIXG_MARK / 2 || v <= -(EP24_FIXG_MARK / 2)) return __builtin_nanf("");
+    if (fixg_bad(v)) return __builtin_nanf("");
     return (float)((double)v * (1.0 / 68719476736.0));
 }
 

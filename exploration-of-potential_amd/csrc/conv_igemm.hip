@@ -24,7 +24,6 @@ constexpr int KOPT_RING32 = 32;            // bit 5: the ring's consumers multip
                                            // cycles per step, a 9 % lower clock under load - slower in the step, profiles/r04_ring_ab.txt)
 constexpr int KOPT_NARROW = 64;            // bit 6: A/B option - 3x3 stride-1 layers in the ring with the NARROW tile (256 x 64; also the 20 x 20 level and N = 64)
 constexpr int KOPT_NO_DEEP = 128;          // bit 7: A/B option - no three-stage form of the tiled kernel (the 20 x 20 level runs in 64-wide two-stage tiles, as before round 4)
-constexpr int KOPT_MULTI_CLASS_MAJOR = 512; // bit 9 (bit 8 is the weight gradient's ring in the plan options): A/B option - the parity classes of a stride-2 input gradient dealt class by class (the order before round 5)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -202,36 +201,19 @@ __global__ __launch_bounds__(256) void igemm_dma_deep_kernel(const IgemmArgs p) 
 }
 
 // Up to four gather-GEMMs in ONE launch: the parity classes of a stride-2 input gradient (same M, N and K; 1, 2, 2 and 4 taps) used
-// to be four dependent launches of one-round grids.
-// Round 5: the classes are INTERLEAVED.  Every class reads the same rows of dy (the pixel (y', x') of a class reads dy[y'][x'] and its
-// +1 neighbours), 9 taps in all; dealt class by class (the round-3 form) the four classes walked dy at four different times and on
-// XCDs shifted by prefix % 8, so dy came from HBM once per class and N tile: 300 - 380 MB of traffic per launch against ~100 MB
-// algorithmic (profiles/r04_hbm_table.md), at 2.4 - 2.7 TB/s.  Now an XCD owns a contiguous run of M tiles and runs, for each of
-// them, every class and N tile back to back (heaviest class first): the 9 x tiles_n reads of a run of dy rows hit that XCD's L2
-// behind the first.  `uniform` = the classes agree on M and N (always, for even input sizes); otherwise the class-major order stays.
+// to be four dependent launches of one-round grids.  A workgroup finds its class from the tile prefix; inside a class the tile
+// order is the single launch's (the XCD label of a workgroup is its index mod 8 up to a constant shift per class).
+// (Round 5 measured two interleaved orders - an XCD running every class of one M tile, or of a chunk of 4 / 8 / 16 M tiles, back to
+// back so that the classes share their dy rows in its L2: 10 - 17 % slower for single tiles, level for chunks.  The launch is not
+// bound by re-reading dy; profiles/r05_s2_ab.txt.  Removed again.)
 struct IgemmMulti {
     IgemmArgs a[4];
     int prefix[5];
     int n;
-    int uniform;         // tiles_m per XCD (ceil(tiles_m / 8)) when the interleaved order applies, else 0
-    int order[4];        // class indices, most taps first
 };
 
 template <int BN>
 __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q) {
-    if (q.uniform) {
-        const IgemmArgs& p0 = q.a[0];
-        const int tiles_n = (p0.N + BN - 1) / BN, tiles_m = (int)((p0.M + BM - 1) / BM);
-        const int per_m = q.n * tiles_n;
-        const int xcd = (int)blockIdx.x & 7, sq = (int)blockIdx.x >> 3;
-        const int ml = sq / per_m, r = sq - ml * per_m;
-        const int tile_m = xcd * q.uniform + ml;
-        if (tile_m >= tiles_m) return;                       // the last XCDs' runs may be short (uniform per workgroup)
-        const int ci = r / tiles_n;
-        const int cls = __builtin_amdgcn_readfirstlane(q.order[ci]);
-        igemm_dma_tile<BN, false, 0>(q.a[cls], tile_m, r - ci * tiles_n);
-        return;
-    }
     int cls = 0;
 #pragma unroll
     for (int c = 1; c < 4; ++c)
@@ -565,17 +547,7 @@ int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
         q.a[i] = cls[i];
         q.prefix[i + 1] = q.prefix[i] + ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, wide ? 128 : 64);
     }
-    bool same = !(kernel_opts & KOPT_MULTI_CLASS_MAJOR);
-    for (int i = 1; i < n; ++i) same = same && cls[i].M == cls[0].M && cls[i].N == cls[0].N;
-    unsigned blocks = (unsigned)q.prefix[n];
-    if (same) {
-        const int tiles_m = ep24_cdiv(cls[0].M, BM), tiles_n = ep24_cdiv(cls[0].N, wide ? 128 : 64);
-        q.uniform = ep24_cdiv(tiles_m, 8);
-        for (int i = 0; i < n; ++i) q.order[i] = i;
-        for (int i = 0; i < n; ++i)                          // most taps first (insertion sort of <= 4 entries, stable)
-            for (int j = i; j > 0 && cls[q.order[j]].T > cls[q.order[j - 1]].T; --j) { const int t = q.order[j]; q.order[j] = q.order[j - 1]; q.order[j - 1] = t; }
-        blocks = 8u * (unsigned)q.uniform * (unsigned)(n * tiles_n);
-    }
+    const unsigned blocks = (unsigned)q.prefix[n];
     const dim3 grid(blocks);
     if (wide) hipLaunchKernelGGL((igemm_dma_multi_kernel<128>), grid, dim3(256), 2 * (BM * 128 + 128 * 128), stream, q);
     else hipLaunchKernelGGL((igemm_dma_multi_kernel<64>), grid, dim3(256), 2 * (BM * 128 + 64 * 128), stream, q);

@@ -78,7 +78,7 @@ template <int OFF_LO, int OFF_HI> __device__ __forceinline__ bf16x8 tr_pair(unsi
 // lane picks the entry of its chunk's tap.  dW leaves as [Cout][tap * 12 + channel], the layout of the im2col form it replaces
 // (which re-read 224 bytes per pixel here: 0.40 ms at B = 20).
 template <int TCO, int TCI, bool VTAP = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock) {
     constexpr int Y_BYTES = 64 * TCO * 2, X_BYTES = 64 * TCI * 2, STAGE = Y_BYTES + X_BYTES;
     constexpr int FM = TCO / 32, FN = TCI / 32;          // 16x16 fragments per wave along co / ci
     constexpr int YCH = TCO / 8, XCH = TCI / 8;          // 16-B chunks per tile row
@@ -92,16 +92,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // (split-major), so the tiles of a pixel split - which all re-read that split's dY / X rows, 9 taps x the other
     // operand's tile count - run on one XCD (two at a run boundary) and the rows cross the fabric once or twice
     // instead of once per XCD: FETCH_SIZE showed 6x the algorithmic bytes with the splits dealt round-robin.
-    int bx, by;
-    if (p.xcd_remap) {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-        const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-        bx = v % p.tiles;
-        by = v / p.tiles;
-    } else {
-        bx = blockIdx.x % p.tiles;
-        by = blockIdx.x / p.tiles;
-    }
+    // (the remap itself lives in the kernels below: vblock is this workgroup's place in the problem's (split, tile) sequence)
+    int bx = vblock % p.tiles;
+    const int by = vblock / p.tiles;
     const int tap = bx % p.T; bx /= p.T;
     const int ci0 = (bx % p.tiles_ci) * TCI;
     const int co0 = (bx / p.tiles_ci) * TCO;
@@ -308,6 +301,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             }
         }
     }
+}
+
+// place of workgroup blockIdx.x in the launch's sequence when every XCD takes one contiguous run of it
+__device__ __forceinline__ int xcd_run_index() {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+}
+
+template <int TCO, int TCI, bool VTAP = false>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    wgrad_body<TCO, TCI, VTAP>(p, p.xcd_remap ? xcd_run_index() : (int)blockIdx.x);
+}
+
+// Up to 16 weight gradients of ONE tile class in one launch (round 5, VERDICT r3 / r4: "one grouped launch per shape class").
+// A weight gradient is needed by nobody before the optimizer, every layer keeps its own dz and its input activation, so the
+// gradients of the layers of a backward segment can wait for each other - and as ONE launch they do not need to be cut into
+// pixel splits to fill the chip: 15 1x1 layers of the 40 x 40 level were 15 launches of 16 tiles x 32 splits (16 steps of 64
+// pixels per workgroup behind a prologue and a 64-KB epilogue, 32 fp32 slabs per layer for the reduce launch to fold); grouped
+// they are 240 tiles x 2 splits of 250 steps.  The workgroups walk (problem, split, tile) in order, an XCD takes a contiguous
+// run.  Same arithmetic per (tile, split): bit-reproducible as before (the split count is part of the plan).
+constexpr int WG_MAX = 16;
+struct WgradGroup {
+    WgradArgs a[WG_MAX];
+    int prefix[WG_MAX + 1];
+    int n;
+};
+static_assert(sizeof(WgradGroup) <= 4096, "kernel arguments are passed by value");
+
+template <int TCO, int TCI>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup g) {
+    const int v = xcd_run_index();
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < WG_MAX; ++k)
+        if (k < g.n && v >= g.prefix[k]) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    wgrad_body<TCO, TCI, false>(g.a[i], v - g.prefix[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -831,6 +861,57 @@ extern "C" int ep24_conv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void
                                          int64_t slab_floats, int64_t ld_dw, int cout_valid, int cin_valid, int B, int H,
                                          int W, int Cin, int Cout, int ksize, int stride, void* stream) {
     return ep24_conv_wgrad_slab_bf16_ex(x, ld_x, dy, ld_dy, slab, slab_floats, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride, 0, stream);
+}
+
+/* Grouped launch (see wgrad_group_kernel).  desc: HOST array [n][17] of int64 -
+ * x, ld_x, dy, ld_dy, slab, slab_floats, ld_dw, cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride, splits. */
+template <int TCO, int TCI>
+static int launch_group(const int64_t* desc, int n, hipStream_t stream) {
+    WgradGroup g{};
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* d = desc + 17 * i;
+        WgradArgs& a = g.a[i];
+        EP24_REQUIRE(d[0] && d[2] && d[4], EP24_E_ARG, "conv_wgrad_group: null pointer in problem %d", i);
+        if (int rc = fill_args(a, (const void*)d[0], d[1], (const void*)d[2], d[3], nullptr, d[6], (int)d[7], (int)d[8], (int)d[9], (int)d[10], (int)d[11],
+                               (int)d[12], (int)d[13], (int)d[14], (int)d[15])) return rc;
+        bool co64, ci64;
+        tile_choice(a, co64, ci64);
+        EP24_REQUIRE((co64 ? 64 : 128) == TCO && (ci64 ? 64 : 128) == TCI, EP24_E_ARG, "conv_wgrad_group: problem %d is not of the group's tile class", i);
+        a.slab = (float*)d[4];
+        a.slab_stride = (long)a.cout_valid * a.ld_dw;
+        const long splits = d[16], steps = (a.M + 63) / 64;
+        EP24_REQUIRE(splits >= 1 && splits * a.slab_stride <= d[5], EP24_E_ARG, "conv_wgrad_group: problem %d: %ld splits need %ld slab floats, %ld given", i,
+                     splits, splits * a.slab_stride, (long)d[5]);
+        a.tiles_ci = ep24_cdiv(a.Cin, TCI); a.tiles_co = ep24_cdiv(a.Cout, TCO);
+        a.tiles = a.tiles_ci * a.tiles_co * a.T;
+        a.chunk = ((steps + splits - 1) / splits) * 64;
+        a.xcd_remap = 1;
+        g.prefix[i + 1] = g.prefix[i] + (int)(a.tiles * splits);
+    }
+    hipLaunchKernelGGL((wgrad_group_kernel<TCO, TCI>), dim3((unsigned)g.prefix[n]), dim3(256), 2 * 64 * (TCO + TCI) * 2 + 512, stream, g);
+    return EP24_OK;
+}
+
+extern "C" int ep24_conv_wgrad_tile_class(int Cin, int Cout, int ksize) {
+    WgradArgs a{};
+    a.Cin = Cin; a.Cout = Cout; a.ksize = ksize;
+    bool co64, ci64;
+    tile_choice(a, co64, ci64);
+    return (co64 ? 1 : 0) | (ci64 ? 2 : 0);
+}
+
+extern "C" int ep24_conv_wgrad_group_bf16(const int64_t* desc, int n, void* stream) {
+    EP24_REQUIRE(desc && n >= 1 && n <= WG_MAX, EP24_E_ARG, "conv_wgrad_group: 1 .. %d problems per launch", WG_MAX);
+    const int cls = ep24_conv_wgrad_tile_class((int)desc[12], (int)desc[13], (int)desc[14]);
+    int rc;
+    if (cls == 3) rc = launch_group<64, 64>(desc, n, (hipStream_t)stream);
+    else if (cls == 1) rc = launch_group<64, 128>(desc, n, (hipStream_t)stream);
+    else if (cls == 2) rc = launch_group<128, 64>(desc, n, (hipStream_t)stream);
+    else rc = launch_group<128, 128>(desc, n, (hipStream_t)stream);
+    if (rc) return rc;
+    EP24_LAUNCH_CHECK("ep24_conv_wgrad_group");
+    return EP24_OK;
 }
 
 // bounded waits of the ring kernels of this translation unit that gave up (added to ep24_conv_ring_timeouts by conv_ring.hip)

@@ -249,14 +249,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
     for (int i = tid; i < 2 * C; i += 256) {
         const long long* src = i < C ? dgamma + i : dbeta + (i - C);
         long long acc = 0;
+        bool bad = false;                                       // a replica word that carries a NaN marker (common.h)
         for (int rb = 0; rb < reps; rb += 8) {
             long long a[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) a[r] = src[(long)(rb + r < reps ? rb + r : rb) * 2 * C];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc += rb + r < reps ? a[r] : 0ll;
+            for (int r = 0; r < 8; ++r) {
+                acc += rb + r < reps ? a[r] : 0ll;
+                bad = bad || fixg_bad(a[r]);
+            }
         }
-        folded[i] = from_fix_g(acc);
+        folded[i] = bad ? __builtin_nanf("") : from_fix_g(acc);
     }
     __syncthreads();
     for (int cg = tid % rm.tpr; cg < (C >> 3); cg += 256) {      // only loops when C > 2048

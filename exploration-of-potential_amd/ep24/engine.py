@@ -26,6 +26,10 @@ from .options import PlanOptions, get_options
 
 BF16 = torch.bfloat16
 WGRAD_REDUCE_GROUP = 16        # layers per weight-gradient reduce launch
+WGRAD_GROUP_MAX = 16           # problems per grouped weight-gradient launch (csrc/conv_wgrad.hip WG_MAX: the table travels as kernel arguments)
+WGRAD_GROUP_FILL = 0.88        # a class is launched once its (tile, split) grid fills this share of the chip's resident slots
+WGRAD_GROUP_TAIL = 0.93        # the last builders of backward (dark2, the stem) launch their weight gradients one by one again:
+                               # what waits in a group there is exposed behind the main lane's last kernel
 STATS_REPLICAS = 8
 STRIDES = (8, 16, 32)
 
@@ -228,7 +232,9 @@ class ParamHome:
             n += (seg.numel + 63) // 64 * 64        # 64-element alignment: a group of the update lies in ONE segment (wf_delta below)
         for seg in self.convs:
             seg.wf_off, seg.wd_off = wf, wd
-            wf += seg.cout * seg.taps * seg.cin_pad
+            # 64-element steps like the masters: the fused update converts whole 4-element groups, and the alignment padding behind
+            # a master whose size is not a multiple of 64 (zeros) lands in this copy's own padding, not in the next layer's weights
+            wf += (seg.cout * seg.taps * seg.cin_pad + 63) // 64 * 64
             wd += seg.cin * seg.taps * seg.cout_pad if seg.need_dgrad else 0
         self.numel = n
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -252,6 +258,15 @@ class ParamHome:
                 self.pack_rest.append(seg)
         self.wf_delta = delta.to(dev)
         self.wf_current = False
+        self._rest_tables = None
+        if self.pack_rest:                                # descriptor tables of the packing kernel for just those segments (built now:
+            rows, pref, tpref = [], [0], [0]              # the call sits inside captured graphs)
+            for seg in self.pack_rest:
+                rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
+                pref.append(pref[-1] + seg.numel)
+                tpref.append(tpref[-1] + seg.taps * ((seg.cout + 63) // 64) * ((seg.cin + 63) // 64))
+            t = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+            self._rest_tables = (t(rows), t(pref), t(tpref), len(rows), pref[-1], tpref[-1])
         # BatchNorm running statistics in one flat buffer too (module buffers become views): ModelEMA averages every
         # floating-point state_dict entry (utils/ema.py:55-60), i.e. these next to the parameters, in two launches
         paired = {id(b) for pair in self.merged_bn for b in pair}
@@ -346,14 +361,6 @@ class ParamHome:
         over a descriptor table of just those segments."""
         if not self.pack_rest:
             return
-        if getattr(self, "_rest_tables", None) is None:
-            rows, pref, tpref = [], [0], [0]
-            for seg in self.pack_rest:
-                rows.append([seg.off, seg.wf_off, seg.wd_off if seg.need_dgrad else -1, seg.cout, seg.taps, seg.cin, seg.cin_pad, seg.cout_pad])
-                pref.append(pref[-1] + seg.numel)
-                tpref.append(tpref[-1] + seg.taps * ((seg.cout + 63) // 64) * ((seg.cin + 63) // 64))
-            t = lambda v: torch.tensor(v, dtype=torch.int64, device=self.dev)
-            self._rest_tables = (t(rows), t(pref), t(tpref), len(rows), pref[-1], tpref[-1])
         desc, pref, tpref, n, total, tiles = self._rest_tables
         call("pack_weights_batched", ptr(self.flat), ptr(desc), ptr(pref), ptr(tpref), n, ptr(self.wf), ptr(self.wd), total, tiles,
              None, None, 1, stream_ptr())
@@ -592,6 +599,8 @@ class Engine:
         self.parallel_head = self.options.parallel_head and not self.f32
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
+        self._wg_pending = {}                    # tile class -> weight-gradient problems waiting for their grouped launch
+        self._wg_tail = False
         self._side = None
         self.use_side = not self.f32            # weight gradients on a second stream
         self.capture_side = self.options.capture_side   # also inside captured graphs (experimental)
@@ -615,8 +624,8 @@ class Engine:
         """conv_fwd_bf16 / conv_dgrad_bf16 with the plan's kernel options (PlanOptions.conv_kernel_opts != 0: the _ex entry points);
         bit 8 of the options is the weight gradient's bit 0 (its loader / consumer ring form, an A/B option)."""
         ko = self.options.conv_kernel_opts
-        if ko & 0x2FF and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
-            return name + "_ex", tuple(args) + (ko & 0x2FF,)
+        if ko & 0xFF and name in ("conv_fwd_bf16", "conv_dgrad_bf16"):
+            return name + "_ex", tuple(args) + (ko & 0xFF,)
         if ko & 0x100 and name in ("conv_wgrad_slab_bf16", "side:conv_wgrad_slab_bf16"):
             return name + "_ex", tuple(args) + (1,)
         return name, tuple(args)
@@ -757,7 +766,11 @@ class Engine:
         # weight-gradient lane, where it runs next to the level-0 chain of the main lane; the main lane joins before
         # the first trunk entry.
         in_head = False
-        for b in reversed(self._bwd_builders):
+        n_builders = len(self._bwd_builders)
+        for bi, b in enumerate(reversed(self._bwd_builders)):
+            if not self._wg_tail and bi >= WGRAD_GROUP_TAIL * n_builders:
+                self._wg_tail = True                      # from here on: one launch per layer, nothing left waiting at the end
+                self._flush_wgrad()
             tag = getattr(b, "tag", None)
             is_head = tag is not None and tag[0] == "head"
             if self.parallel_head:
@@ -815,8 +828,64 @@ class Engine:
         fn.tag = self._cur_tag                    # which part of the network registered it (head level k / trunk)
         self._bwd_builders.append(fn)
 
+    # ---- grouped weight gradients (round 5) ---------------------------------------------------------
+    def _wg_plan(self, probs, cls):
+        """Pixel splits of the problems of one grouped launch: every workgroup keeps >= WGRAD_GROUP_MIN_STEPS 64-pixel steps, and the
+        largest common split cap K is taken whose (tile, split) grid still fits the chip's resident slots (one round).
+        -> (splits per problem, workgroups, slots)"""
+        slots = 256 * (4 if cls == 3 else 2 if cls == 0 else 3)
+        kmax = [max(1, pr["steps"] // max(8, int(self.options.wgrad_group_steps))) for pr in probs]
+        best = None
+        for K in range(max(kmax), 0, -1):
+            sp = [min(K, km) for km in kmax]
+            wg = sum(pr["tiles"] * q for pr, q in zip(probs, sp))
+            if wg <= slots or K == 1:
+                best = (sp, wg)
+                break
+        return best[0], best[1], slots
+
+    def _pend_wgrad(self, pr):
+        fn = _lib.lib().fn
+        cls = fn["ep24_conv_wgrad_tile_class"](pr["cin"], pr["cout"], pr["k"])
+        tco, tci = (64 if cls & 1 else 128), (64 if cls & 2 else 128)
+        pr["tiles"] = -(-pr["cin"] // tci) * -(-pr["cout"] // tco) * pr["k"] * pr["k"]
+        OH, OW = (pr["H"] - 1) // pr["s"] + 1, (pr["W"] - 1) // pr["s"] + 1
+        pr["steps"] = -(-(pr["B"] * OH * OW) // 64)
+        lst = self._wg_pending.setdefault(cls, [])
+        lst.append(pr)
+        _sp, wg, slots = self._wg_plan(lst, cls)
+        if len(lst) >= WGRAD_GROUP_MAX or wg >= WGRAD_GROUP_FILL * slots:
+            self._flush_wgrad(cls)
+
+    def _flush_wgrad(self, only=None):
+        """Emit the grouped launch of every (or one) tile class with waiting problems, in the order the classes were first used."""
+        for cls in ([only] if only is not None else list(self._wg_pending)):
+            probs = self._wg_pending.pop(cls, None)
+            if not probs:
+                continue
+            splits, _wg, _slots = self._wg_plan(probs, cls)
+            rows = []
+            for pr, sp in zip(probs, splits):
+                seg = pr["seg"]
+                soff = self._slab_floats
+                self._slab_floats += sp * seg.numel
+                rows.append((pr, sp, soff))
+                self._pending_reduce.append((seg, sp, soff))
+            keep = self._keep
+
+            def table(rows=rows):                      # resolved with the other launch arguments in _finalize: a HOST int64 array
+                t = torch.tensor([[pr["x"](), pr["ld_x"], pr["dz"](), pr["ld_dy"], self.slab.data_ptr() + 4 * soff, sp * pr["seg"].numel,
+                                   pr["ld_dw"], pr["cout_valid"], pr["cin_valid"], pr["B"], pr["H"], pr["W"], pr["cin"], pr["cout"], pr["k"], pr["s"], sp]
+                                  for pr, sp, soff in rows], dtype=torch.int64)
+                keep.append(t)
+                return t.data_ptr()
+            self._b("@side_wait_main", ())
+            self._b("side:conv_wgrad_group_bf16", (table, len(rows)))
+            self._b("@side_record", (probs[-1]["idx"],))
+
     def _flush_reduce(self):
         """One reduce launch (side stream, behind the weight-gradient kernels it sums) for the pending layers."""
+        self._flush_wgrad()                               # the slabs it folds must have been written
         if not self._pending_reduce:
             return
         rows = [[seg.off, seg.numel, splits, soff] for seg, splits, soff in self._pending_reduce]
@@ -931,10 +1000,18 @@ class Engine:
             splits = _lib.lib().fn["ep24_stem_conv_wgrad_splits"](B, H, W, cout) if focus else \
                 self._wsplits(B, H, W, cin, cout, k_, s)
             assert splits >= 1, splits
-            soff = self._slab_floats
-            self._slab_floats += splits * seg.numel
 
             def emit_wgrad():
+                if self.options.group_wgrad and not focus and not self._wg_tail and not (self.options.conv_kernel_opts & 0x100):
+                    # grouped with the other layers of its tile class (csrc/conv_wgrad.hip wgrad_group_kernel); its slab is
+                    # allotted when the group is launched (the split count is the group's)
+                    self._pend_wgrad(dict(x=x.ptr, ld_x=x.ld, dz=dz, ld_dy=cout, ld_dw=seg.taps * seg.cin, cout_valid=cout, cin_valid=seg.cin,
+                                          B=B, H=H, W=W, cin=cin, cout=cout, k=k_, s=s, seg=seg, idx=k))
+                    if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
+                        self._flush_reduce()
+                    return
+                soff = self._slab_floats
+                self._slab_floats += splits * seg.numel
                 self._b("@side_wait_main", ())
                 slab_p = (lambda soff=soff: self.slab.data_ptr() + 4 * soff)
                 if focus:

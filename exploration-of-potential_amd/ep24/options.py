@@ -24,13 +24,15 @@ class PlanOptions:
     capture_side: bool = False         # cross-stream edges inside captured graphs (experimental; faulted on ROCm 7.2)
     fold_bn_eval: bool = True          # eval mode: BatchNorm folded into the conv (one launch per unit)
     conv_kernel_opts: int = 0          # bit 0: 3x3 stride-1 layers through the generic tiled kernel, bit 1: 8-byte epilogue stores
+    wgrad_group_steps: int = 120       # 64-pixel steps a workgroup of a grouped weight-gradient launch keeps at least
+    group_wgrad: bool = True           # weight gradients of a backward segment's layers as grouped launches per tile class (round 5)
     fuse_bn_reduce: bool = False       # a 3x3 stride-1 input gradient that is the only consumer of the unit below takes that unit's
                                        # BatchNorm-backward sums in its epilogue (no reduce launch for it).  Measured slower in the step
                                        # (899 against 912 images/s, same box): kept for A/B runs only
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane
-    forward_lanes: int = 2
-    fwd_order: int = 0                 # how the forward's two lanes are enqueued (ep24.train.TrainStep.step; A/B of round 5)
+    forward_lanes: int = 2             # 2: one more stream beside the main lane; 3: head level 1 on a stream of its own
+    head1_side: bool = True            # with two lanes: head level 1 follows head level 0 on the second lane (round 5; False: on the main lane)
     bwd_cuts: Optional[Tuple[float, ...]] = None   # fractions of the backward list where its graph segments are cut (None: default)
     chunked_update: bool = True        # the optimizer update in pieces on the weight-gradient lane, each as soon as its gradients are complete
 
@@ -55,7 +57,7 @@ class PlanOptions:
             if k == "bwd_cuts":
                 kw[k] = (tuple((i + 1) / int(v[1:]) for i in range(int(v[1:]) - 1)) if v[0] == "u"
                          else tuple(float(x) for x in v.split(":")))
-            elif k in ("forward_lanes", "conv_kernel_opts", "fwd_order"):
+            elif k in ("forward_lanes", "conv_kernel_opts", "wgrad_group_steps"):
                 kw[k] = int(v)
             else:
                 kw[k] = v.strip() not in ("0", "false", "False", "")

@@ -136,7 +136,11 @@ class TrainStep:
             return None
         lo, hi = eng.fwd_head0
         fork = eng.fwd_fork
-        if self.forward_lanes >= 3:                   # a third lane: head level 1 from the point its input is complete
+        # Head level 1 off the main lane from the point its input (pan_out1) is complete: on a third stream (forward_lanes = 3) or,
+        # the default since round 5, behind head level 0 on the second lane.  Timed events in a plain run (profiles/r05_fwd_lanes.txt)
+        # showed the main lane - rest of the neck + head levels 1, 2 - finishing 0.84 ms AFTER the level-0 head, the opposite of what
+        # the profiler's trace had suggested for two rounds.
+        if (self.forward_lanes >= 3 or self.eng.options.head1_side) and getattr(eng, "fwd_head1", None) is not None:
             f1, (lo1, hi1) = eng.fwd_fork1, eng.fwd_head1
             return eng.fwd[:fork], eng.fwd[fork:f1], eng.fwd[lo:hi], eng.fwd[f1:lo] + eng.fwd[hi1:], eng.fwd[lo1:hi1]
         return eng.fwd[:fork], eng.fwd[fork:lo] + eng.fwd[hi:], eng.fwd[lo:hi]
@@ -307,7 +311,7 @@ class TrainStep:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=eng.dev)
             if len(split) == 5 and getattr(self, "_side2", None) is None:
-                self._side2 = torch.cuda.Stream(device=eng.dev)
+                self._side2 = torch.cuda.Stream(device=eng.dev) if self.forward_lanes >= 3 else self._side
         self.g_upd = capture(self._phase_update)
         self.g_upd_early = None
         self._cuts = [0, len(eng.bwd)] if self.reducer is None else self.reducer.cuts(eng)
@@ -377,22 +381,36 @@ class TrainStep:
         if isinstance(self.g_fwd, tuple) and len(self.g_fwd) == 6:
             g1, g_main_a, g_side, g_main_b, g_side2, g_loss = self.g_fwd
             main, side, side2 = torch.cuda.current_stream(), self._side, self._side2
+            probe = getattr(self, "probe", None)      # tools/fwd_lanes_probe.py: timed events at the lane boundaries (outside a profiler)
+
+            def mark(name, stream):
+                if probe is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(stream)
+                    probe[name] = e
+            mark("start", main)
             g1.replay()
+            mark("fork", main)
             ev = torch.cuda.Event()
             ev.record(main)
-            g_main_a.replay()
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                g_side.replay()
+            g_main_a.replay()                         # the main lane's graphs first (see the backward loop)
             eva = torch.cuda.Event()
             eva.record(main)
             g_main_b.replay()
-            side2.wait_event(eva)
+            mark("main_end", main)
+            side.wait_event(ev)
+            mark("side_begin", side)
+            with torch.cuda.stream(side):
+                g_side.replay()                       # head level 0
+            side2.wait_event(eva)                     # head level 1 (side2 is the same stream unless forward_lanes = 3)
             with torch.cuda.stream(side2):
                 g_side2.replay()
+            mark("side_end", side2)
             main.wait_stream(side)
             main.wait_stream(side2)
+            mark("loss_begin", main)
             g_loss.replay()
+            mark("loss_end", main)
             with torch.cuda.stream(side):
                 self.g_pre_bwd.replay()
             ev_pb = torch.cuda.Event()
@@ -411,23 +429,17 @@ class TrainStep:
             mark("start", main)
             g1.replay()
             mark("fork", main)
-            order = self.eng.options.fwd_order
-            if order == 1:                            # A/B: a real dispatch between the graph and the event
-                _lib.call("memset_zero", _lib.ptr(self.hp) + 28, 4, _lib.stream_ptr())
             ev = torch.cuda.Event()
             ev.record(main)
-            if order == 2:                            # A/B: the side lane's graph first
-                side.wait_event(ev)
-                mark("side_begin", side)
-                with torch.cuda.stream(side):
-                    g_side.replay()
-                g_main.replay()
-            else:
-                g_main.replay()                       # the main lane's graph is enqueued first (see the backward loop)
-                side.wait_event(ev)
-                mark("side_begin", side)
-                with torch.cuda.stream(side):
-                    g_side.replay()
+            # the main lane's graph is enqueued first (see the backward loop).  Round 5, tools/fwd_lanes_probe.py: timed events in a
+            # plain run put the side lane's start 20 us behind the fork (rocprofv3's queue interception shows it 1.2 ms late - the "558
+            # us hole" of profiles/r04_stream_gaps.txt is the profiler's, not the runtime's); a plain dispatch between the graph and the
+            # event delayed it by 1.3 ms, the side lane's graph first changed nothing (profiles/r05_fwd_lanes.txt)
+            g_main.replay()
+            side.wait_event(ev)
+            mark("side_begin", side)
+            with torch.cuda.stream(side):
+                g_side.replay()
             mark("main_end", main)
             mark("side_end", side)
             ev2 = torch.cuda.Event()
@@ -450,14 +462,25 @@ class TrainStep:
             # the main lane's graph of segment i+1 is enqueued BEFORE the side lane's graph of segment i.
             pending, par_done = None, None
 
+            bprobe = getattr(self, "probe", None)
+
+            def bmark(key, stream):                          # tools/fwd_lanes_probe.py: where each lane is, segment by segment
+                if bprobe is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(stream)
+                    bprobe.setdefault(key, []).append(e)
+            bmark("bwd_main", main)
+
             def launch_side(p):
                 gs, ready, ev, par = p
                 side.wait_event(ev)
+                bmark("bwd_side_begin", side)
                 with torch.cuda.stream(side):
                     if gs is not None:
                         gs.replay()
                     if ready is not None:
                         self.reducer.bucket_ready(ready)      # recorded on the side lane: it has waited for the main one
+                bmark("bwd_side", side)
                 if par:
                     e2 = torch.cuda.Event()
                     e2.record(side)
@@ -486,10 +509,13 @@ class TrainStep:
                         pending = None
                     if par_done is not None:
                         main.wait_event(par_done)          # the head levels that ran on the side lane (not its later work)
+                if join:
+                    bmark("bwd_join", main)
                 if gm is not None:
                     gm.replay()
                 ev = torch.cuda.Event()
                 ev.record(main)
+                bmark("bwd_main", main)
                 if pending is not None:
                     par_done = launch_side_ev(pending) or par_done
                 pending = (gs, ready, ev, par)
@@ -502,6 +528,7 @@ class TrainStep:
                     early[0].replay()
                     did_early = True
             main.wait_stream(side)
+            bmark("bwd_end", main)
         else:
             for i, (lo, hi) in enumerate(zip(self._cuts[:-1], self._cuts[1:])):
                 self._phase_backward(lo, hi)

@@ -69,9 +69,7 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * which the 256 x 128 ring does not take (bit-identical results; measured slower than the tiled kernel it would replace: an A/B
  * option); bit 7: the tiled kernel without its three-stage form (round 4: layers whose 128-wide tiles leave at most one workgroup per
  * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
- * two-stage tiles as before; bit-identical results); bit 9: the parity classes of a stride-2 input gradient dealt class by class
- * inside their one launch (the order before round 5; default: interleaved, an XCD runs every class and N tile of an M tile back to
- * back so that the classes share their dy rows in its L2; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * two-stage tiles as before; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
@@ -135,6 +133,14 @@ int ep24_conv_wgrad_splits_ex(int B, int H, int W, int Cin, int Cout, int ksize,
 int ep24_conv_wgrad_slab_bf16_ex(const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats,
                                  int64_t ld_dw, int cout_valid, int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize,
                                  int stride, int kernel_opts, void* stream);
+/* Round 5: up to 16 weight gradients of ONE tile class in one launch (a weight gradient is needed by nobody before the optimizer and
+ * every layer keeps its dz and its input, so the layers of a backward segment wait for each other; grouped they fill the chip without
+ * being cut into many short pixel splits).  desc is a HOST array [n][17] of int64 - x, ld_x, dy, ld_dy, slab, slab_floats, ld_dw,
+ * cout_valid, cin_valid, B, H, W, Cin, Cout, ksize, stride, splits - read during the call; `splits` (>= 1) is the caller's: slab s
+ * of problem i receives the partial sums of its s-th run of ceil(steps / splits) 64-pixel steps, ep24_wgrad_reduce folds them.
+ * ep24_conv_wgrad_tile_class: bit 0 = 64-wide tiles over Cout (else 128), bit 1 = 64-wide tiles over Cin; one class per launch. */
+int ep24_conv_wgrad_tile_class(int Cin, int Cout, int ksize);
+int ep24_conv_wgrad_group_bf16(const int64_t* desc, int n, void* stream);
 int ep24_wgrad_reduce(const int64_t* desc, int n_layers, int64_t max_numel, float* grad, const float* slab, void* stream);
 
 /* fp32 master [Cout][T][Cin] (row stride ld_w) -> bf16 w_fwd [Cout][T][Cin_pad] and bf16 w_dgrad
@@ -166,7 +172,7 @@ int ep24_bn_act_fwd(const void* z, int64_t ld_z, const int64_t* stats, int stats
 
 /* pass 1 of the backward: dgamma[c] += sum du*zhat, dbeta[c] += sum du, du = dy * silu'(bn(z)); the sums are
  * 2^-36 fixed-point int64 (NOT the forward statistics' 2^-20: gradient sums of the head are 1e-5 .. 1e-4 per workgroup; a workgroup's
- * partial sum must stay below 2^13 in magnitude - one that does not, or is NaN, makes the channel's folded sum NaN), kept in `reps` replicas (replica r of either sum 2*C*r elements behind
+ * partial sum must stay below 2^20 in magnitude - one that does not, or is NaN, makes the channel's folded sum NaN), kept in `reps` replicas (replica r of either sum 2*C*r elements behind
  * the pointer, i.e. [reps][2][C] when dbeta = dgamma + C; a workgroup adds to replica blockIdx % reps): the memory-side atomic
  * units serialise the adds to one address, and with a single copy every workgroup of the launch hit the same 2 C addresses. */
 int ep24_bn_act_bwd_reduce(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,

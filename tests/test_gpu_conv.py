@@ -125,8 +125,6 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # the ring without a patch (round 4; kernel_opts bit 4; an 8th value is the kernel id the shape must dispatch to with it): the 4-step 1x1 layer of the
     # 40x40 level, a 1x1 layer with M, N and K tails, a stride-2 3x3 layer with a K tail
     (20, 40, 256, 256, 1, 1, 40, 4), (13, 50, 200, 264, 1, 1, 47, 4), (20, 90, 72, 136, 3, 2, 86, 4),
-    # a stride-2 layer on an ODD image: the parity classes of its input gradient differ in M, so the class-major tile order stays (round 5)
-    (3, 27, 24, 40, 3, 2, 31, 0),
     # the NARROW ring (256 x 64 tiles, kernel_opts bit 6, an A/B option; a 9th value = the kernel_opts the id is asked under): the 20 x 20
     # level of YOLOX-l, which 256 x 128 tiles do not spread over the chip; M and N tails; a K tail over two patch buffers; N = 64 with one chunk and the widest patch
     # (W = 160: three patch pieces per loader and step); N = 64 with an M tail
@@ -183,8 +181,6 @@ def test_conv_hot_shapes(shape):
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
     # key 4: the narrow ring where it fits; key 5 (bits 0 + 7): the tiled kernel WITHOUT its three-stage form (the 20 x 20 level)
     variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((2, 0), (0, 16), (5, 128))
-    if k == 3 and s == 2:                                                  # key 6 (bit 9): the parity classes of the input gradient dealt class by class
-        variants += ((6, 512),)                                            # (the order before round 5; the default interleaves them per M tile)
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
@@ -249,6 +245,73 @@ def test_conv_hot_shapes(shape):
         grads[wo] = (reps[0], splits)
     assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-5 * float(grads[1][0].abs().max()), (grads[0][1], grads[1][1])
     assert fn["ep24_conv_ring_timeouts"]() == 0
+
+
+@pytest.mark.parametrize("k,shapes,splits", [
+    (1, [(4, 40, 40, 256, 256), (4, 40, 40, 128, 256), (3, 20, 24, 256, 200), (4, 40, 40, 256, 256)], [3, 1, 2, 5]),     # 64 x 64 tiles
+    (3, [(4, 40, 40, 256, 256), (2, 24, 20, 136, 384), (4, 40, 40, 256, 256)], [2, 1, 4]),                              # 128 x 128 tiles
+    (3, [(3, 40, 40, 64, 256), (2, 32, 32, 64, 128)], [2, 3]),                                                          # 128 (co) x 64 (ci)
+])
+def test_grouped_weight_gradients(k, shapes, splits):
+    """Round 5: ep24_conv_wgrad_group_bf16 - several layers' weight gradients (one tile class, different shapes and split counts)
+    in ONE launch.  Each problem against torch fp32 on the bf16-rounded operands, bitwise reproducible, and a problem's slabs equal
+    bit for bit what the same (shape, splits) gives as a group of one (a workgroup's work does not depend on its neighbours)."""
+    call, ptr, sp = _abi()
+    from ep24 import _lib
+    fn = _lib.lib().fn
+    cls = {fn["ep24_conv_wgrad_tile_class"](cin, cout, k) for (_, _, _, cin, cout) in shapes}
+    assert len(cls) == 1
+    probs = []
+    for i, (B, H, W, cin, cout) in enumerate(shapes):
+        x = rnd(B, cin, H, W, seed=10 + i)
+        gy = rnd(B, cout, H, W, seed=20 + i)
+        xr = x.float().requires_grad_(False)
+        wr = torch.zeros(cout, cin, k, k, requires_grad=True)
+        F.conv2d(xr, wr, None, 1, (k - 1) // 2).backward(gy.float())
+        probs.append(dict(x=nhwc(x).to(DEV), gy=nhwc(gy).to(DEV), ref=wr.grad.permute(0, 2, 3, 1).reshape(-1), B=B, H=H, W=W, cin=cin, cout=cout,
+                          numel=cout * k * k * cin))
+
+    def run(sel):
+        outs = []
+        rows, slabs = [], []
+        for i in sel:
+            pr, sp_ = probs[i], splits[i]
+            slab = torch.full((sp_ * pr["numel"],), float("nan"), device=DEV)
+            slabs.append(slab)
+            rows.append([pr["x"].data_ptr(), pr["cin"], pr["gy"].data_ptr(), pr["cout"], slab.data_ptr(), sp_ * pr["numel"], k * k * pr["cin"],
+                         pr["cout"], pr["cin"], pr["B"], pr["H"], pr["W"], pr["cin"], pr["cout"], k, 1, sp_])
+        desc = torch.tensor(rows, dtype=torch.int64)                    # a HOST table
+        call("conv_wgrad_group_bf16", desc.data_ptr(), len(rows), sp())
+        for i, slab in zip(sel, slabs):
+            pr = probs[i]
+            g = torch.zeros(pr["numel"], device=DEV)
+            d = torch.tensor([[0, pr["numel"], splits[i], 0]], dtype=torch.int64, device=DEV)
+            call("wgrad_reduce", ptr(d), 1, pr["numel"], ptr(g), ptr(slab), sp())
+            outs.append((slab.clone(), g))
+        torch.cuda.synchronize()
+        return outs
+
+    whole = run(list(range(len(shapes))))
+    again = run(list(range(len(shapes))))
+    for i, ((slab, g), (slab2, g2)) in enumerate(zip(whole, again)):
+        assert not torch.isnan(slab).any(), "a slab element nobody wrote"
+        assert torch.equal(slab, slab2) and torch.equal(g, g2)
+        close(g, probs[i]["ref"], rel=5e-3)
+        alone = run([i])[0]
+        assert torch.equal(alone[0], slab), i
+    with pytest.raises(_lib.Ep24Error):                                 # another tile class in the same launch is refused
+        other = (512, 512, 1) if k == 1 else (256, 256, 1)
+        assert fn["ep24_conv_wgrad_tile_class"](*other) not in cls
+        B, H, W, cin, cout = shapes[0]
+        x2 = torch.zeros(B * H * W, other[0], dtype=BF, device=DEV)
+        g2 = torch.zeros(B * H * W, other[1], dtype=BF, device=DEV)
+        sl = torch.zeros(other[0] * other[1] * other[2] ** 2, device=DEV)
+        pr = probs[0]
+        rows = [[pr["x"].data_ptr(), pr["cin"], pr["gy"].data_ptr(), pr["cout"], whole[0][0].data_ptr(), splits[0] * pr["numel"], k * k * pr["cin"], pr["cout"],
+                 pr["cin"], pr["B"], pr["H"], pr["W"], pr["cin"], pr["cout"], k, 1, splits[0]],
+                [x2.data_ptr(), other[0], g2.data_ptr(), other[1], sl.data_ptr(), sl.numel(), other[2] ** 2 * other[0], other[1], other[0], B, H, W,
+                 other[0], other[1], other[2], 1, 1]]
+        call("conv_wgrad_group_bf16", torch.tensor(rows, dtype=torch.int64).data_ptr(), 2, sp())
 
 
 @pytest.mark.parametrize("B,IH,IW,Cout", [(2, 32, 32, 64), (3, 96, 80, 64), (1, 64, 132, 24), (2, 48, 40, 8), (5, 160, 160, 64)])

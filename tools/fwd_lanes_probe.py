@@ -31,10 +31,23 @@ for plan in plans:
         ts.step()
         torch.cuda.synchronize()
         for k, e in ts.probe.items():
-            if k != "start":
+            if isinstance(e, list):
+                for i, ei in enumerate(e):
+                    rec.setdefault("%s[%d]" % (k, i), []).append(ts.probe["start"].elapsed_time(ei))
+            elif k != "start":
                 rec.setdefault(k, []).append(ts.probe["start"].elapsed_time(e))
     ts.probe = None
     med = {k: statistics.median(v) for k, v in rec.items()}
+    if os.environ.get("EP24_PROBE_BWD"):
+        nseg = len([k for k in med if k.startswith("bwd_main[")]) - 1
+        print("#   backward, plan %r: segment i - main lane done at, side lane starts / ends its part at (ms); launches main / side" % (plan or "default"))
+        for i in range(nseg):
+            gm, gs = ts.g_bwd[i][0], ts.g_bwd[i][1]
+            lo, hi = ts._segments()[0][i]
+            nm, ns = [len(x) for x in ts.eng.lane_lists(lo, hi)]
+            print("#   seg %2d  main %7.3f   side %7.3f .. %7.3f   (%3d / %3d launches)" % (
+                i, med["bwd_main[%d]" % (i + 1)], med.get("bwd_side_begin[%d]" % i, float("nan")), med.get("bwd_side[%d]" % i, float("nan")), nm, ns))
+        print("#   join at %s, backward ends %.3f, step %.3f" % (", ".join("%.3f" % v for k, v in sorted(med.items()) if k.startswith("bwd_join")), med["bwd_end[0]"], med["end"]))
     print("%-28s %8.3f %10.3f %9.3f %9.3f %10.3f %9.3f %8.3f" % (plan or "(default)", med["fork"], med["side_begin"], med["main_end"], med["side_end"],
                                                                   med["loss_begin"], med["loss_end"], med["end"]))
     del ts, m

@@ -1,7 +1,8 @@
 """GPU box helper (round 5): the stride-2 3x3 layers of YOLOX-l (B = 20) - forward and input gradient - with a list of kernel_opts
 side by side, interleaved rounds in ONE process, launches replayed from a hipGraph, operands rotated over EP24_AB_SETS sets (default 6:
 a launch finds its operands as cold as in the step).
-usage: s2_ab.py [opts ...]     (default: 0 512 = interleaved parity classes against the class-major order of rounds 3 - 4)"""
+usage: s2_ab.py [opts ...]     (default: 0 and 4 = the one-launch input gradient against one launch per parity class; round 5 used it for the
+interleaved class orders recorded in profiles/r05_s2_ab.txt, which were removed again)"""
 import os
 import sys
 
@@ -38,7 +39,7 @@ def graph_time(run, iters=12):
 
 
 def main():
-    opts = [int(v) for v in sys.argv[1:]] or [0, 512]
+    opts = [int(v) for v in sys.argv[1:]] or [0, 4]
     print("# stride-2 3x3 layers, B = 20, %d operand sets; us per launch (best of 3 interleaved rounds), TFLOP/s of the first column" % NSET)
     print("%-6s %-20s " % ("kind", "B,H,Cin,Cout") + " ".join("%10s" % ("opts=%d" % o) for o in opts))
     for B, H, Cin, Cout in SHAPES:
