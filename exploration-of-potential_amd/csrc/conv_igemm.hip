@@ -556,6 +556,11 @@ int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
 }
 
 int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, bool dry = false, int* kernel_id = nullptr) {
+#ifndef EP24_AB_VARIANTS
+    EP24_REQUIRE(!(kernel_opts & (KOPT_GRING | KOPT_RING32 | KOPT_NARROW)), EP24_E_UNSUPPORTED,
+                 "conv: kernel_opts bits 4 - 6 select variants that were measured, lost and left the product library (round 5); "
+                 "build the A/B library with `make -C exploration-of-potential_amd/csrc variants` and load it through EP24_LIB");
+#endif
     if (!dry) { if (int rc = check_extents(a)) return rc; }
     prepare(a, kernel_opts);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;

@@ -36,7 +36,7 @@ constexpr int NCW = 4, NLW = 4;                  // consumer / loader waves
 constexpr int NS = 3;                            // weight ring stages: 9 taps = 3 x 3, so the stage of a step is its tap column
 constexpr int RBN = 128, RBM = 256;              // tile
 constexpr int B_BYTES = RBN * 128;               // one weight tile: [128 channels][64 k] bf16
-constexpr int B_INSTR = RBN / 8 / NLW;           // weight-tile DMA instructions per loader and step (4)
+[[maybe_unused]] constexpr int B_INSTR = RBN / 8 / NLW;           // weight-tile DMA instructions per loader and step (4)
 constexpr int MT = 8, NT = 4;                    // accumulator tiles per consumer: 128 rows x 64 channels
 constexpr int ZB = 128;                          // LDS bytes 0..127 stay zero
 constexpr int LA = 8;                            // groups of 4 MFMAs between the request of an A fragment and its use (a divisor of 8)
@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const Igemm
 #endif
 }
 
+#ifdef EP24_AB_VARIANTS      // measured and lost (profiles/r04_ring_generic_ab.txt): only in the A/B library (make variants)
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same ring WITHOUT a patch: any gather-GEMM of igemm.h (1x1 layers with K > 128, stride-2 3x3 layers, ...).  A step is
 // (tap t, 64-channel chunk kc), chunk outer / tap inner as the tiled kernel walks them (bit-identical sums); the loaders fetch a
@@ -1210,6 +1211,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
     if (wide) ring_epilogue<RBN, MT>(p, acc, consumer, m0, n0, tile_m, smem);
     else if (consumer) igemm_epilogue<RBN, false, MT, 0, NCW, false>(p, acc, m0, n0, tile_m, smem);
 }
+#endif   // EP24_AB_VARIANTS
 
 template <int PPS, bool M32, int TBN = RBN, bool INFER = false>
 int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, hipStream_t stream) {
@@ -1259,7 +1261,13 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
         if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return 0;
     if (a.K % 8 != 0) return 0;
     if (a.bnr_z) return 0;                                   // the fused BatchNorm-backward sums (an A/B option) stay with the 8-wave kernel
+#ifdef EP24_AB_VARIANTS
     const bool narrow = narrow_ok;
+#else
+    const bool narrow = false;                               // the narrow tile and the 32 x 32 x 16 consumers left the product library (round 5)
+    (void)narrow_ok;
+    m16 = true;
+#endif
     if (a.epi_infer && (narrow || !m16)) return 0;            // the eval-mode epilogue lives in the 256 x 128 tile's 16 x 16 form
     if (!narrow && (a.N <= 64 || (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, RBN) < 200)) return 0;
     if (narrow && (long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, 64) < 128) return 0;
@@ -1280,6 +1288,7 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
         // the 32 x 32 x 16 consumers need the 16-byte store path (bf16 rows aligned to 16 bytes) and room for the statistics fold
         const bool m32 = !narrow && !m16 && !a.narrow_epi && (a.N & 7) == 0 && (a.ld_dst & 7) == 0 && (reinterpret_cast<unsigned long long>(a.dst) & 15) == 0 &&
                          lds >= (size_t)NCW * 2 * 64 * 33 * 4;
+#ifdef EP24_AB_VARIANTS
         if (narrow)
             *rc = pps <= 1 ? launch_ring_pps<1, false, 64>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, false, 64>(a, np, halo, npb, lds, stream)
@@ -1288,7 +1297,11 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
             *rc = pps <= 1 ? launch_ring_pps<1, true>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, true>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, true>(a, np, halo, npb, lds, stream);
-        else if (a.epi_infer)
+        else
+#else
+        (void)m32;
+#endif
+        if (a.epi_infer)
             *rc = pps <= 1 ? launch_ring_pps<1, false, RBN, true>(a, np, halo, npb, lds, stream)
                 : pps == 2 ? launch_ring_pps<2, false, RBN, true>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, false, RBN, true>(a, np, halo, npb, lds, stream);
@@ -1302,6 +1315,10 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
 
 // Generic form: any gather-GEMM with bf16 output, no bias, N > 64 and enough 256 x 128 tiles to fill the chip.
 bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
+#ifndef EP24_AB_VARIANTS
+    (void)a; (void)stream; (void)dry; (void)rc;
+    return false;
+#else
     if (a.K % 8 != 0 || a.N <= 64 || a.T > 16 || a.bnr_z || a.bias || a.epi_infer) return false;
     if ((long)ep24_cdiv(a.M, RBM) * ep24_cdiv(a.N, RBN) < 200) return false;
     const size_t lds = ZB + (size_t)NS * GSTAGE + 64;
@@ -1320,6 +1337,7 @@ bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* 
         *rc = EP24_OK;
     }
     return true;
+#endif
 }
 
 }  // namespace ep24_igemm

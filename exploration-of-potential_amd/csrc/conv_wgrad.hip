@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup g) {
 // fragments requested 8 groups ahead) are conv_ring.hip's.  Products and the order of the sums inside a pixel split are those of
 // wgrad_kernel; the number of splits differs (one workgroup per CU here), so the folded gradient agrees with wgrad_kernel's to fp32
 // summation order, and with itself bit for bit from run to run (plain slab stores, ordered reduce).
+#ifdef EP24_AB_VARIANTS      // the weight gradient as a ring: only in the A/B library (make variants)
 namespace wring {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -648,6 +649,7 @@ int launch(WgradArgs& a, long splits, hipStream_t stream) {
 }
 
 }  // namespace wring
+#endif   // EP24_AB_VARIANTS
 
 // Pixel splits: fill the chip's resident-workgroup slots exactly once (LDS allows 2 / 3 / 4 workgroups per CU for
 // the 128x128 / mixed / 64x64 tiles): one slot more than a full round costs a whole extra round (576 workgroups on
@@ -723,8 +725,12 @@ constexpr int WOPT_RING = 1;               // kernel_opts of the _ex entry point
                                            // option: 10 % slower than wgrad_kernel on every layer, +0.6 ms per step - profiles/r04_wgrad_ring_ab.txt)
 
 long splits_of(const WgradArgs& a, int opts = 0) {
+#ifdef EP24_AB_VARIANTS
     long rs = 0;
     if ((opts & WOPT_RING) && wring::eligible(a, &rs)) return rs;
+#else
+    (void)opts;
+#endif
     bool co64, ci64;
     tile_choice(a, co64, ci64);
     if (co64 && ci64) return wgrad_splits<64, 64>(a);
@@ -734,8 +740,12 @@ long splits_of(const WgradArgs& a, int opts = 0) {
 }
 
 int dispatch(WgradArgs& a, hipStream_t stream, int opts = 0) {
+#ifdef EP24_AB_VARIANTS
     long rs = 0;
     if (a.slab && (opts & WOPT_RING) && wring::eligible(a, &rs)) return wring::launch(a, rs, stream);
+#else
+    EP24_REQUIRE(!(opts & WOPT_RING), EP24_E_UNSUPPORTED, "conv_wgrad: kernel_opts bit 0 (the ring form: measured, lost) lives in the A/B library: make variants");
+#endif
     bool co64, ci64;
     tile_choice(a, co64, ci64);
     if (co64 && ci64) launch_wgrad<64, 64>(a, stream);
@@ -917,9 +927,13 @@ extern "C" int ep24_conv_wgrad_group_bf16(const int64_t* desc, int n, void* stre
 // bounded waits of the ring kernels of this translation unit that gave up (added to ep24_conv_ring_timeouts by conv_ring.hip)
 namespace ep24_igemm {
 int wgrad_ring_timeouts() {
+#ifdef EP24_AB_VARIANTS
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(wring::g_timeouts), sizeof(v)) != hipSuccess) return -1;
     return (int)v;
+#else
+    return 0;
+#endif
 }
 }
 

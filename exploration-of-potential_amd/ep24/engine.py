@@ -387,6 +387,21 @@ class ParamHome:
             call("ema_update", ptr(ema_home.bflat), ptr(self.bflat), self.bnumel, 0.0, 0.0, ptr(hp), stream_ptr())
 
 
+def wgrad_group_splits(tiles, steps, cls, min_steps=120):
+    """Pixel splits of the problems of one grouped weight-gradient launch (ep24_conv_wgrad_group_bf16).  tiles[i]: (Cout, tap, Cin)
+    tiles of problem i, steps[i]: its 64-pixel steps, cls: the tile class (bit 0 / bit 1: 64-wide over Cout / Cin).  Every workgroup
+    keeps >= min_steps steps (its prologue and 64-KB epilogue cost ~12), and the largest common split cap K is taken whose
+    (tile, split) grid still fits the chip's resident workgroup slots - one round (2 / 3 / 4 workgroups per CU by the tile's LDS).
+    -> (splits per problem, workgroups, slots)"""
+    slots = 256 * (4 if cls == 3 else 2 if cls == 0 else 3)
+    kmax = [max(1, st // max(8, int(min_steps))) for st in steps]
+    for K in range(max(kmax), 0, -1):
+        sp = [min(K, km) for km in kmax]
+        wg = sum(t * q for t, q in zip(tiles, sp))
+        if wg <= slots or K == 1:
+            return sp, wg, slots
+
+
 def _weights_loaded(module, _incompatible_keys):
     """load_state_dict post hook of every module of a model that lives in flat buffers (each module of the recursion calls its own
     hooks, so a sub-module's load counts): the packed forward copy of whichever home its parameters live in is stale."""
@@ -830,19 +845,7 @@ class Engine:
 
     # ---- grouped weight gradients (round 5) ---------------------------------------------------------
     def _wg_plan(self, probs, cls):
-        """Pixel splits of the problems of one grouped launch: every workgroup keeps >= WGRAD_GROUP_MIN_STEPS 64-pixel steps, and the
-        largest common split cap K is taken whose (tile, split) grid still fits the chip's resident slots (one round).
-        -> (splits per problem, workgroups, slots)"""
-        slots = 256 * (4 if cls == 3 else 2 if cls == 0 else 3)
-        kmax = [max(1, pr["steps"] // max(8, int(self.options.wgrad_group_steps))) for pr in probs]
-        best = None
-        for K in range(max(kmax), 0, -1):
-            sp = [min(K, km) for km in kmax]
-            wg = sum(pr["tiles"] * q for pr, q in zip(probs, sp))
-            if wg <= slots or K == 1:
-                best = (sp, wg)
-                break
-        return best[0], best[1], slots
+        return wgrad_group_splits([pr["tiles"] for pr in probs], [pr["steps"] for pr in probs], cls, self.options.wgrad_group_steps)
 
     def _pend_wgrad(self, pr):
         fn = _lib.lib().fn

@@ -138,14 +138,28 @@ class DataPrefetcher:
         # the event recorded on the compute stream when batch k - 1 was handed out (everything enqueued before it - the step that
         # consumed batch k - 2 - has then run).  No allocation and no record_stream per batch.
         self._bufs, self._k, self._events = [None, None, None], 0, []
+        # host seconds of this thread inside the loader (next(): dataset + collate) and inside the upload / letterbox enqueue; the
+        # second one BLOCKS in the pageable copies until the device buffer of batch k - 2 is free, i.e. it is where a GPU-bound
+        # loop waits for the GPU (profiles/r05_trainer_8sets.json), not host work
+        self.t_loader = self.t_upload = 0.0
         self.preload()
 
     def preload(self):
+        import time
+        t0 = time.perf_counter()
         try:
             images, targets, _, _ = next(self.loader)
         except StopIteration:
             self.next_input = self.next_target = None
             return
+        t1 = time.perf_counter()
+        self.t_loader += t1 - t0
+        try:
+            self._upload(images, targets)
+        finally:
+            self.t_upload += time.perf_counter() - t1
+
+    def _upload(self, images, targets):
         self._k += 1
         with torch.cuda.stream(self.stream):
             if isinstance(images, torch.Tensor):

@@ -58,8 +58,13 @@ class Trainer:
         if not args.synthetic:
             print("note: the COCO24P loader of the reference reads hard-coded paths (datasets/coco24p.py:19-20) and is out of "
                   "scope; the synthetic source with the same label layout is used (--synthetic)")
-        if args.raw_u8 and args.no_prefetch:
-            raise SystemExit("train_24p.py: --raw-u8 batches are letterboxed by the prefetcher (drop --no-prefetch)")
+        # Round 5: the raw uint8 source is the DEFAULT (0.98 of bench.py against 0.91 for ready-made fp32 canvases from four loader
+        # processes, profiles/r04_trainer.json; one host core per rank instead of five: profiles/r05_trainer_8sets.json).
+        # --fp32-batches restores the reference's form of the source; --no-prefetch implies it (raw batches are letterboxed by the
+        # prefetcher's side stream).
+        if args.raw_u8 and (args.no_prefetch or args.fp32_batches):
+            raise SystemExit("train_24p.py: --raw-u8 batches are letterboxed by the prefetcher (drop --no-prefetch / --fp32-batches)")
+        args.raw_u8 = not (args.fp32_batches or args.no_prefetch)
         self.train_loader = exp.get_data_loader(args.batch_size, raw_u8=bool(args.raw_u8), workers=args.loader_workers,
                                                  pin=None if args.loader_pin is None else bool(args.loader_pin))
         self.loss_func = Loss_Function(exp.num_classes)
@@ -146,6 +151,8 @@ class Trainer:
                     torch.cuda.synchronize()
                     tp_t0, tp_seen = time.perf_counter(), 0
                     host = {"loader_and_upload": 0.0, "step_enqueue": 0.0, "rest": 0.0}
+                    pf0 = getattr(self, "prefetcher", None)
+                    pf_mark = (pf0.t_loader, pf0.t_upload) if pf0 is not None else None
                     t_mark = tp_t0
                 elif tp_t0 is not None:                   # host time of the window by phase: what the loop's own thread spends where
                     now = time.perf_counter()
@@ -210,6 +217,10 @@ class Trainer:
                        "captured_step": step_fn is not None, "log_interval": args.log_interval, "exp_file": args.exp_file,
                        "loader_workers": self.train_loader.num_workers, "loader_pin": bool(self.train_loader.pin_memory),
                        "host_ms_per_step": {k: round(v / max(args.throughput_window, 1) * 1e3, 3) for k, v in host.items()}}
+                pf1 = getattr(self, "prefetcher", None)
+                if pf1 is not None and pf_mark is not None:      # of loader_and_upload: the loader's own work / the (blocking) upload enqueue
+                    rec["host_ms_per_step"]["loader_only"] = round((pf1.t_loader - pf_mark[0]) / max(args.throughput_window, 1) * 1e3, 3)
+                    rec["host_ms_per_step"]["upload_enqueue_blocking"] = round((pf1.t_upload - pf_mark[1]) / max(args.throughput_window, 1) * 1e3, 3)
                 with open(args.throughput_json, "w") as fh:
                     json.dump(rec, fh)
                 print("throughput %s" % json.dumps(rec))
@@ -249,6 +260,7 @@ class Trainer:
             return
         from ep24.input import DataPrefetcher, TrainTransform
         pf = DataPrefetcher(self.train_loader, tuple(self.input_size), TrainTransform(max_labels=50))
+        self.prefetcher = pf                              # its t_loader / t_upload split the throughput record's host time
         while True:
             images, labels = pf.next()
             if images is None:
@@ -310,8 +322,10 @@ def make_parser():
     p.add_argument("--loader-workers", default=None, type=int, help="processes of the synthetic loader (default: the Exp's loader_workers)")
     p.add_argument("--loader-pin", default=None, type=int, choices=(0, 1), help="page-locked batches from the loader (default: with loader processes and fp32 batches)")
     p.add_argument("--no-prefetch", action="store_true", help="the reference's loop: upload every batch on the compute stream (train_24p.py:86-88)")
-    p.add_argument("--raw-u8", action="store_true", help="the synthetic source hands over uint8 HWC images + normalised label rows; letterbox and label "
-                   "scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")
+    p.add_argument("--raw-u8", action="store_true", help="(default since round 5; kept for old command lines) the synthetic source hands over uint8 HWC "
+                   "images + normalised label rows; letterbox and label scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")
+    p.add_argument("--fp32-batches", action="store_true", help="the reference's form of the source: ready-made fp32 canvases [B,3,S,S] + label tables from "
+                   "the loader (datasets/data_augment.py TrainTransform on the host side)")
     p.add_argument("--dp-wire", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce under torch.distributed.run")
     p.add_argument("--throughput-json", default=None, type=str, help="with --steps N: write images/s over the run's last --throughput-window steps "
                    "(synchronised at both ends) to this file")

@@ -71,6 +71,10 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
  * two-stage tiles as before; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
+/* Round 5: bits 4, 5 and 6 (and bit 0 of the weight gradient's kernel_opts) select variants that were built, measured and lost in
+ * rounds 3 - 4; they left the product library, which answers EP24_E_UNSUPPORTED for them.  `make -C csrc variants` builds
+ * libep24_variants.so with them (EP24_LIB selects it); ep24_ab_variants() says which kind of library is loaded. */
+int ep24_ab_variants(void);
 int ep24_conv_fwd_bf16_ex(const void* x, int64_t ld_x, const void* w, void* y, int64_t ld_y, int y_f32,
                           int64_t y_batch_rows, int64_t y_row0, const float* bias, int64_t* stats, int stats_replicas,
                           int B, int H, int W, int Cin, int Cout, int ksize, int stride, int kernel_opts, void* stream);

@@ -740,6 +740,103 @@ def gen_vgg(utils, models):
     save("g17_vgg", **store)
 
 
+# --------------------------------------------------------------------------- G18 training curve (round 5)
+CURVE = dict(depth=0.33, width=0.25, size=320, batch=4, n_batches=8, steps=300, lr=0.01, momentum=0.9, init_seed=11,
+             gts=[[3, 5, 2, 4], [1, 6, 0, 3], [4, 4, 2, 7], [5, 1, 3, 2], [2, 3, 6, 1], [7, 2, 4, 0], [3, 3, 5, 4], [6, 2, 1, 5]])
+
+
+def curve_data(i):
+    """Batch i of the fixed synthetic set (also what tests/test_gpu_curve.py feeds the HIP paths)."""
+    c = CURVE
+    return (synth.make_images(c["batch"], c["size"], seed=500 + i), synth.make_labels(c["batch"], c["gts"][i], size=c["size"], seed=600 + i))
+
+
+def curve_init(member):
+    """Initial state dict of ensemble member `member`: the oracle network of seed CURVE['init_seed'], every floating-point parameter
+    scaled by (1 + 1e-6 N(0,1)) drawn from seed 9000 + member (member 0: unperturbed).  SGD with lr 0.01 on SimOTA's discrete assignment
+    is chaotic - two fp32 runs that differ in the seventh digit separate within ten steps and differ by 10 - 25 % in single-step loss
+    later on - so 'does bf16 train like fp32' is a statement about ENSEMBLES of runs, and this is how their members are made."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import model as om
+    c = CURVE
+    torch.manual_seed(c["init_seed"])
+    net = om.Net(c["depth"], c["width"])
+    if member:
+        g = torch.Generator().manual_seed(9000 + member)
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.mul_(1.0 + 1e-6 * torch.randn(p_.shape, generator=g))
+    return net
+
+
+def gen_curve(utils, models):
+    """G18 (round 5).  300 SGD steps (lr 0.01, momentum 0.9, nesterov: exp/yolox_base.py:120-124) of the REFERENCE's
+    own YOLOX-24p (depth 0.33, width 0.25, 320 x 320, batch 4) with the reference's own Loss_Function on a fixed set of 8 synthetic
+    batches walked in order, fp32 on the CPU as the reference trains (train_24p.py:80-111): FOUR ensemble members (curve_init 0..3) -
+    and member 0 once more through the oracle (oracle.model.Net, LossOracle, sgd_nesterov_step).  The initial parameters are the oracle
+    network's (its construction order differs from the reference's in the head, so the state dict is loaded into the reference model -
+    same keys), which lets the GPU test rebuild them without a 9 MB fixture.  Stored: the loss curves [4, 300] + [300], member
+    0's three components and num_fg / num_gt per step."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import model as om
+    from oracle.loss import LossOracle
+    c = CURVE
+    in_ch = [256, 512, 1024]
+    data = [curve_data(i) for i in range(c["n_batches"])]
+
+    def bn_cfg(mod):
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps, m.momentum = 1e-3, 0.03                  # Exp.get_model (exp/yolox_base.py:58-62)
+
+    r_loss, r_parts = [], []
+    for member in range(4):
+        net = curve_init(member)
+        ref = models.YOLOX(models.YOLOPAFPN(c["depth"], c["width"], in_channels=in_ch, act="silu"), models.YOLOXHead(80, c["width"], in_channels=in_ch, act="silu"))
+        ref.load_state_dict(net.state_dict(), strict=True)
+        bn_cfg(ref)
+        ref.train()
+        lf = models.Loss_Function(80)
+        opt = torch.optim.SGD(ref.parameters(), lr=c["lr"], momentum=c["momentum"], nesterov=True)
+        cur = []
+        for step in range(c["steps"]):
+            imgs, labs = data[step % c["n_batches"]]
+            opt.zero_grad()
+            tup = lf.forward(ref(imgs, train=True), labs)
+            tup[0].backward()
+            opt.step()
+            cur.append(float(tup[0].detach()))
+            if member == 0:
+                r_parts.append([float(tup[1].detach().sum()), float(tup[2].detach()), float(tup[3].detach()), float(tup[5])])
+            if step % 100 == 0:
+                print("reference member %d step %3d loss %.4f" % (member, step, cur[-1]))
+        r_loss.append(cur)
+    # ---- the oracle, member 0
+    net = curve_init(0)
+    bn_cfg(net)
+    net.train()
+    ora = LossOracle(80)
+    params = list(net.parameters())
+    bufs = [None] * len(params)
+    o_loss = []
+    for step in range(c["steps"]):
+        imgs, labs = data[step % c["n_batches"]]
+        for p_ in params:
+            p_.grad = None
+        tup = ora(net(imgs, train=True), labs)
+        tup[0].backward()
+        om.sgd_nesterov_step(params, bufs, c["lr"], c["momentum"])
+        o_loss.append(float(tup[0].detach()))
+        if step % 100 == 0:
+            print("oracle    member 0 step %3d loss %.4f" % (step, o_loss[-1]))
+    save("g18_train_curve", ref_loss=np.asarray(r_loss, dtype=np.float32), ref_parts=np.asarray(r_parts, dtype=np.float32),
+         oracle_loss=np.asarray(o_loss, dtype=np.float32),
+         config=np.asarray([c["depth"], c["width"], c["size"], c["batch"], c["n_batches"], c["steps"], c["lr"], c["momentum"], c["init_seed"]], dtype=np.float64),
+         gts=np.asarray(c["gts"], dtype=np.int64))
+
+
 def write_manifest():
     """tests/golden/MANIFEST.json: shape, dtype and CRC-32 of every array of every committed fixture (tests/test_golden_manifest.py)."""
     import json
@@ -782,3 +879,5 @@ if __name__ == "__main__":
         gen_densenet(utils, models)
     if "vgg" in which:
         gen_vgg(utils, models)
+    if "curve" in which:                                       # not in the default list: two 300-step CPU trainings (~3 min)
+        gen_curve(utils, models)

@@ -161,6 +161,14 @@ def test_conv_hot_shapes(shape):
     gy = rnd(B, Cout, OH, OW, seed=3)
     y_ref, dx_ref, dw_ref = _torch_conv_ref(x, w, gy, s, pad)
     M = B * OH * OW
+    # Round 5: the variants that lost twice (ring without a patch = bit 4, 32x32x16 consumers = bit 5, narrow ring = bit 6, the weight
+    # gradient as a ring) left the product library; `make variants` + EP24_LIB=.../libep24_variants.so brings them back for this test
+    have_variants = fn["ep24_ab_variants"]() == 1
+    if len(shape) > 7 and not have_variants:
+        # the product library refuses the bits loudly (also in the dry-run query)
+        assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, shape[8] if len(shape) > 8 else 16) < 0
+        assert "make" in _lib.lib().last_error() and "variants" in _lib.lib().last_error()
+        pytest.skip("variant shape: needs the A/B library (make variants)")
     if len(shape) > 7:
         assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, shape[8] if len(shape) > 8 else 16) == shape[7]
         if shape[7] == 5:                                                  # ... which no layer takes by default
@@ -180,7 +188,9 @@ def test_conv_hot_shapes(shape):
     # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
     # key 4: the narrow ring where it fits; key 5 (bits 0 + 7): the tiled kernel WITHOUT its three-stage form (the 20 x 20 level)
-    variants = ((2, 0), (3, 32), (1, 8), (0, 1), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((2, 0), (0, 16), (5, 128))
+    variants = ((0, 1), (2, 0), (3, 32), (1, 8), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((0, 128), (2, 0), (5, 16))
+    if not have_variants:
+        variants = tuple(v for v in variants if not (v[1] & (16 | 32 | 64)))
     for patch, ko in variants:
         y = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         stats = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
@@ -203,7 +213,7 @@ def test_conv_hot_shapes(shape):
     # gradients (plain and accumulated), whichever kernel ran; the batch statistics are sums of per-tile fp32 partial sums, and the
     # tiles differ (256 rows against 128): equal to fp32 summation order
     for other in outs:
-        if other == 3 and fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 32) == 3:
+        if other == 3 and have_variants and fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 32) == 3:
             # The 32x32x16 consumers add the SAME products, the fp32 sum of a 64-channel chunk in four k-steps of 16 instead of two of
             # 32: fp32 sums agree to rounding, so after the one rounding to bf16 an element differs by at most one bf16 ulp (2^-8
             # relative; an element that is itself a cancelled sum by 1e-5 of the tensor's range), and only a few per cent do at all.
@@ -229,7 +239,7 @@ def test_conv_hot_shapes(shape):
     # order; each is bitwise reproducible.
     numel = Cout * k * k * Cin
     grads = {}
-    for wo in (0, 1):
+    for wo in ((0, 1) if have_variants else (0,)):
         splits = fn["ep24_conv_wgrad_splits_ex"](B, H, W, Cin, Cout, k, s, wo)
         reps = []
         for rep in range(2):
@@ -243,7 +253,8 @@ def test_conv_hot_shapes(shape):
         if len(reps) == 2:
             assert torch.equal(reps[0], reps[1])
         grads[wo] = (reps[0], splits)
-    assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-5 * float(grads[1][0].abs().max()), (grads[0][1], grads[1][1])
+    if have_variants:
+        assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-5 * float(grads[1][0].abs().max()), (grads[0][1], grads[1][1])
     assert fn["ep24_conv_ring_timeouts"]() == 0
 
 

@@ -82,7 +82,7 @@ def test_trainer_with_loader_processes(tmp_path):
     the prefetcher's side stream (here two processes: with pytest and the trainer that is four of the six a GPU box allows)."""
     import json
     out = str(tmp_path / "run")
-    log = _train(out, "--steps", "4", "--loader-workers", "2", "--throughput-json", str(tmp_path / "tp.json"), "--throughput-window", "2")
+    log = _train(out, "--steps", "4", "--loader-workers", "2", "--fp32-batches", "--throughput-json", str(tmp_path / "tp.json"), "--throughput-window", "2")
     steps = [ln for ln in log.splitlines() if ln.startswith("step ")]
     assert len(steps) == 4 and "captured step" in log, log[-2000:]
     losses = [float(ln.split("loss")[1].split()[0]) for ln in steps]

@@ -41,3 +41,22 @@ def test_exec_order_covers_every_parameter():
                 for c in (mod.reg_preds[k], mod.obj_preds[k], mod.cls_preds[k]):
                     seen |= {c.weight, c.bias}
     assert seen == set(m.parameters())
+
+
+def test_grouped_weight_gradient_split_plan():
+    """Round 5: pixel splits of a grouped weight-gradient launch (ep24.engine.wgrad_group_splits) - every workgroup keeps its minimum
+    number of 64-pixel steps, the (tile, split) grid fits the resident slots unless one split each already exceeds them, and the cap is
+    the largest that does."""
+    from ep24.engine import wgrad_group_splits
+    # fifteen 1x1 256 -> 256 layers of the 40 x 40 level at B = 20: 16 tiles of 64 x 64, 500 steps, 1024 slots
+    sp, wg, slots = wgrad_group_splits([16] * 15, [500] * 15, 3, 120)
+    assert slots == 1024 and sp == [4] * 15 and wg == 960
+    # seven 3x3 256 -> 256 layers: 36 tiles of 128 x 128 each -> two splits fill 504 of 512 slots; an eighth pushes it to one split
+    assert wgrad_group_splits([36] * 7, [500] * 7, 0, 120)[:2] == ([2] * 7, 504)
+    assert wgrad_group_splits([36] * 8, [500] * 8, 0, 120)[:2] == ([1] * 8, 288)
+    # mixed shapes share the cap but never drop below the minimum steps: a 125-step problem is never split at 120
+    sp, wg, _ = wgrad_group_splits([9, 36, 4], [2000, 500, 125], 0, 120)
+    assert sp[2] == 1 and all(st // q >= 120 for st, q in zip([2000, 500, 125], sp)) and wg <= 512
+    assert sp == [16, 4, 1] and wg == 292                            # the common cap K = 16 is clipped per problem by its own step count
+    # more tiles than slots: one split each, several rounds
+    assert wgrad_group_splits([300, 300], [500, 500], 0, 120) == ([1, 1], 600, 512)
