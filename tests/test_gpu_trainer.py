@@ -78,7 +78,7 @@ def test_trainer_runs_and_checkpoint_round_trips(tmp_path):
 
 
 def test_trainer_with_loader_processes(tmp_path):
-    """The default source of the entry point since round 4: ready-made fp32 batches from loader PROCESSES, page-locked, uploaded on
+    """--fp32-batches (the default source of round 4; round 5's default is the raw uint8 source): ready-made fp32 batches from loader PROCESSES, page-locked, uploaded on
     the prefetcher's side stream (here two processes: with pytest and the trainer that is four of the six a GPU box allows)."""
     import json
     out = str(tmp_path / "run")
@@ -89,4 +89,7 @@ def test_trainer_with_loader_processes(tmp_path):
     assert all(v == v and 0 < v < 1e4 for v in losses), losses
     tp = json.load(open(str(tmp_path / "tp.json")))
     assert tp["loader_workers"] == 2 and tp["loader_pin"] and tp["prefetch"] and not tp["raw_u8"] and tp["images_per_s"] > 0
-    assert set(tp["host_ms_per_step"]) == {"loader_and_upload", "step_enqueue", "rest"}
+    # host time of the training thread by phase; round 5 splits loader_and_upload into the loader's own work and the (blocking) upload enqueue
+    assert set(tp["host_ms_per_step"]) == {"loader_and_upload", "step_enqueue", "rest", "loader_only", "upload_enqueue_blocking"}
+    h = tp["host_ms_per_step"]
+    assert h["loader_only"] >= 0 and h["upload_enqueue_blocking"] >= 0 and h["loader_only"] + h["upload_enqueue_blocking"] <= h["loader_and_upload"] * 1.5 + 1.0
