@@ -855,6 +855,12 @@ class Engine:
         OH, OW = (pr["H"] - 1) // pr["s"] + 1, (pr["W"] - 1) // pr["s"] + 1
         pr["steps"] = -(-(pr["B"] * OH * OW) // 64)
         lst = self._wg_pending.setdefault(cls, [])
+        if lst and self._wg_plan(lst + [pr], cls)[1] > self._wg_plan(lst + [pr], cls)[2]:
+            # with this problem the group would not fit one round even unsplit: a second round of a few LONG workgroups costs as much
+            # as the first (the VGG backbone lost 12 % that way: four 512-channel layers as 576 workgroups of 500 steps on 512 slots,
+            # profiles/r05_configs.txt) - what waits goes out now, the new problem starts the next group
+            self._flush_wgrad(cls)
+            lst = self._wg_pending.setdefault(cls, [])
         lst.append(pr)
         _sp, wg, slots = self._wg_plan(lst, cls)
         if len(lst) >= WGRAD_GROUP_MAX or wg >= WGRAD_GROUP_FILL * slots:

@@ -12,12 +12,12 @@ run() {   # name, flags
   timeout -k 10 300 python3 train_24p.py $COMMON "$@" --throughput-json $OUT/tp_$n.json > $OUT/$n.log 2>&1
   echo "$n done"
 }
-run prefetch                                          # the default: 3 loader processes, page-locked fp32 batches, side-stream upload
-run prefetch_w0 --loader-workers 0
-run prefetch_w4 --loader-workers 4 --loader-pin 0
-run prefetch_w4_pin --loader-workers 4 --loader-pin 1
-run raw_u8 --raw-u8
-run raw_u8_w4 --raw-u8 --loader-workers 4
+run raw_u8                                            # the default since round 5: raw uint8 source, GPU letterbox, side-stream upload
+run raw_u8_w4 --loader-workers 4
+run prefetch --fp32-batches                           # round 4's default: loader processes, page-locked fp32 batches, side-stream upload
+run prefetch_w0 --fp32-batches --loader-workers 0
+run prefetch_w4 --fp32-batches --loader-workers 4 --loader-pin 0
+run prefetch_w4_pin --fp32-batches --loader-workers 4 --loader-pin 1
 run no_prefetch --no-prefetch --loader-workers 0
 rm -rf $OUT/run
 cd $R
