@@ -240,6 +240,108 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* outputs, in
     }
 }
 
+// Round 5: loss gradient AND decode backward in one pass, for the captured step.  loss_grad_kernel writes d loss / d outputs as a dense
+// fp32 [B,A,27+C] tensor (72 MB at B = 20, 99 % zeros) that head_decode_bwd then reads back to produce what the prediction convs'
+// backward really consumes: per level, bf16 rows of the reg+obj gradient [cells][32] and of the class gradient [cells][ld_cls]
+// (xy: dout * stride, radii: dout * decoded radius, obj / classes unchanged: yolo_head_24p.py:212-237 backward).  Here the block writes
+// those rows directly - the unmatched anchors' cooperatively (zeros but for the objectness column), the matched ones by a wave each -
+// with the same fp32 expressions followed by the same one rounding to bf16: bit-identical to the two-launch form
+// (tests/test_gpu_loss.py::test_fused_loss_grad_decode).  Not for the L1 branch (its extra gradient is added by head_decode_bwd).
+struct DecodeLevels {
+    int a0[4], hw[4];             // first anchor and cells per image of each level (a0[n] = A)
+    float stride[4];
+    bf16* d_ro[4];
+    bf16* d_cl[4];
+    int n, ld_cls;
+};
+
+__global__ __launch_bounds__(256) void loss_grad_decode_kernel(const float* outputs, int ncols, const float* labels,
+                                                               const int* matched_gt, const float* matched_iou, const float* result,
+                                                               const DecodeLevels lv, int A, int C) {
+    __shared__ float s_obj[256];
+    __shared__ int s_g[256];
+    __shared__ long s_cell[256];                                       // cell index inside the anchor's level
+    __shared__ int s_lv[256];
+    const int b = blockIdx.y;
+    const int a0 = blockIdx.x * 256;
+    const int a = a0 + threadIdx.x;
+    const float gs = 1.0f / result[27];
+    int g = -2;                                                        // -2: no such anchor
+    if (a < A) {
+        g = matched_gt[(long)b * A + a];
+        const float so = 1.0f / (1.0f + expf(-outputs[((long)b * A + a) * ncols + 26]));
+        s_obj[threadIdx.x] = result[53] * gs * (so - (g >= 0 ? 1.f : 0.f));
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < lv.n && a >= lv.a0[k]) l = k;
+        s_lv[threadIdx.x] = l;
+        s_cell[threadIdx.x] = (long)b * lv.hw[l] + (a - lv.a0[l]);
+    }
+    s_g[threadIdx.x] = g;
+    __syncthreads();
+    {
+        // rows of the unmatched anchors: 4 chunks of 8 reg+obj columns, then ld_cls / 8 chunks of class columns, 16 bytes each
+        const int nrows = min(256, A - a0);
+        const int chunks = 4 + (lv.ld_cls >> 3);
+        for (int f = threadIdx.x; f < nrows * chunks; f += 256) {
+            const int row = f / chunks, ch = f - row * chunks;
+            if (s_g[row] >= 0) continue;
+            const int l = s_lv[row];
+            bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ch == 3) o[2] = (bf16)s_obj[row];                      // column 26
+            if (ch < 4) *reinterpret_cast<bf16x8*>(lv.d_ro[l] + s_cell[row] * 32 + ch * 8) = o;
+            else *reinterpret_cast<bf16x8*>(lv.d_cl[l] + s_cell[row] * lv.ld_cls + (ch - 4) * 8) = o;
+        }
+    }
+    __shared__ int s_list[256];
+    __shared__ int s_wc[4];
+    const int n = compact_matched(g >= 0, s_list, s_wc);
+    const int lane = threadIdx.x & 63;
+    for (int m = threadIdx.x >> 6; m < n; m += 4) {
+        const int t = s_list[m], am = a0 + t;
+        const int l = s_lv[t];
+        const float* o = outputs + ((long)b * A + am) * ncols;
+        bf16* ro = lv.d_ro[l] + s_cell[t] * 32;
+        bf16* cl = lv.d_cl[l] + s_cell[t] * lv.ld_cls;
+        const float* lab = labels + ((long)b * G_MAX + s_g[t]) * LCOLS;
+        const float gcx = lab[1], gcy = lab[2];
+        const float ddx = gcx - o[0], ddy = gcy - o[1];
+        const float d = sqrtf(ddx * ddx + ddy * ddy);
+        float gdl = 0.f;
+        if (lane < 24) {
+            const float vx = lab[3 + 2 * lane] - gcx, vy = lab[4 + 2 * lane] - gcy;
+            float g_r, g_d;
+            ray_loss_grad(sqrtf(vx * vx + vy * vy), o[2 + lane], d, g_r, g_d);
+            const float wk = result[29 + lane] * gs;
+            const float dv = wk * g_r;                                 // what loss_grad_kernel stores in column 2 + lane
+            ro[2 + lane] = (bf16)(dv * o[2 + lane]);                   // d exp(t) * s / dt = r
+            gdl = wk * g_d;
+        } else if (lane >= 27 && lane < 32) {
+            ro[lane] = (bf16)0.f;                                      // padding columns of the 32-wide row
+        }
+        const float gd = wave_sum(gdl);
+        if (lane == 0) {
+            const float st = lv.stride[l];
+            const float d0 = gd * (-ddx / d), d1 = gd * (-ddy / d);    // d == 0 gives NaN, exactly as the reference's autograd
+            ro[0] = (bf16)(d0 * st);
+            ro[1] = (bf16)(d1 * st);
+            ro[26] = (bf16)s_obj[t];
+        }
+        const int cls = (int)lab[0];
+        const float piou = matched_iou[(long)b * A + am];
+        const float cw = result[54] * gs;
+        for (int c = lane; c < lv.ld_cls; c += 64) {
+            float v = 0.f;
+            if (c < C) {
+                const float sc = 1.0f / (1.0f + expf(-o[27 + c]));
+                v = cw * (sc - (c == cls ? piou : 0.f));
+            }
+            cl[c] = (bf16)v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ stand-alone forms
 __global__ __launch_bounds__(256) void pairwise_kernel(const float* gt50, const float* pred26, float* out, int G, int P) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -342,6 +444,30 @@ extern "C" int ep24_loss_grad(const float* outputs, int ncols, const float* labe
     hipLaunchKernelGGL(loss_grad_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
                        matched_gt, matched_iou, result, grad_scale, dout, A, num_classes, origin, xs, ys, strides, d_origin);
     EP24_LAUNCH_CHECK("ep24_loss_grad");
+    return EP24_OK;
+}
+
+extern "C" int ep24_loss_grad_decode(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt, const float* matched_iou,
+                                     const float* result, int B, int A, int num_classes, int n_levels, const int64_t* levels, void* stream) {
+    EP24_REQUIRE(outputs && labels && matched_gt && matched_iou && result && levels, EP24_E_ARG, "loss_grad_decode: null pointer");
+    EP24_REQUIRE(ncols == 27 + num_classes && n_levels >= 1 && n_levels <= 3, EP24_E_ARG, "loss_grad_decode: ncols=%d, %d levels", ncols, n_levels);
+    DecodeLevels lv{};
+    lv.n = n_levels;
+    lv.ld_cls = (num_classes + 7) & ~7;
+    int a0 = 0;
+    for (int i = 0; i < n_levels; ++i) {                              // levels: HOST rows (cells per image, stride as float bits in the low word, d_ro, d_cl)
+        const int64_t* r = levels + 4 * i;
+        lv.a0[i] = a0; lv.hw[i] = (int)r[0];
+        union { unsigned u; float f; } cv; cv.u = (unsigned)r[1]; lv.stride[i] = cv.f;
+        lv.d_ro[i] = (bf16*)r[2]; lv.d_cl[i] = (bf16*)r[3];
+        EP24_REQUIRE(lv.d_ro[i] && lv.d_cl[i] && ((r[2] | r[3]) & 15) == 0, EP24_E_ARG, "loss_grad_decode: level %d gradient rows must be 16-byte aligned", i);
+        a0 += lv.hw[i];
+    }
+    lv.a0[n_levels] = a0;
+    EP24_REQUIRE(a0 == A, EP24_E_ARG, "loss_grad_decode: the levels hold %d anchors, A = %d", a0, A);
+    hipLaunchKernelGGL(loss_grad_decode_kernel, dim3(ep24_cdiv(A, 256), B), dim3(256), 0, (hipStream_t)stream, outputs, ncols, labels,
+                       matched_gt, matched_iou, result, lv, A, num_classes);
+    EP24_LAUNCH_CHECK("ep24_loss_grad_decode");
     return EP24_OK;
 }
 

@@ -614,6 +614,8 @@ class Engine:
         self.parallel_head = self.options.parallel_head and not self.f32
         self._dz_elems = 0
         self._slab_floats, self._pending_reduce, self._keep = 0, [], []
+        self.head_grads = []                     # per head level: (cells per image, stride, d_regobj, d_cls)
+        self.skip_decode_bwd = False             # True: the loss wrote those rows itself, the head_decode_bwd entries are skipped
         self._wg_pending = {}                    # tile class -> weight-gradient problems waiting for their grouped launch
         self._wg_tail = False
         self._side = None
@@ -1448,6 +1450,7 @@ class Engine:
         ldc = _r8(C)
         d_ro = torch.zeros(M * 32, dtype=BF16, device=self.dev)
         d_cl = torch.zeros(M * ldc, dtype=BF16, device=self.dev)
+        self.head_grads.append((H * W, s, d_ro, d_cl))           # what ep24_loss_grad_decode writes directly (ep24.train)
 
         def build_bwd():
             dout = Dyn(self.dyn, "dout")
@@ -1557,6 +1560,8 @@ class Engine:
                 if lanes:
                     s = s_side
                     used_side = True
+            if name == "head_decode_bwd" and self.skip_decode_bwd:
+                continue
             rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
             if rc != 0:
                 raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
@@ -1581,9 +1586,19 @@ class Engine:
         s = stream_ptr()
         fn = _lib.lib().fn
         for name, args in lst:
+            if name == "head_decode_bwd" and self.skip_decode_bwd:
+                continue
             rc = fn["ep24_" + name](*[a.get() if isinstance(a, Dyn) else a for a in args], s)
             if rc != 0:
                 raise _lib.Ep24Error("ep24_%s failed (%d): %s" % (name, rc, _lib.lib().last_error()))
+
+    def decode_levels(self):
+        """HOST table for ep24_loss_grad_decode: per head level (cells per image, the stride's float32 bits, d_regobj, d_cls)."""
+        import struct
+        if getattr(self, "_decode_levels", None) is None:
+            rows = [[hw, struct.unpack("<I", struct.pack("<f", float(s)))[0], d_ro.data_ptr(), d_cl.data_ptr()] for hw, s, d_ro, d_cl in self.head_grads]
+            self._decode_levels = torch.tensor(rows, dtype=torch.int64)
+        return self._decode_levels
 
     def zero_step_buffers(self):
         s = stream_ptr()
@@ -1636,6 +1651,7 @@ class Engine:
         [B,A,26] the gradient of the L1 branch with respect to the raw regression outputs (or None)."""
         self.dyn["dout"] = dout.data_ptr()
         self.dyn["d_origin"] = None if d_origin is None else d_origin.data_ptr()
+        self.skip_decode_bwd = False              # the eager API hands over the dense gradient: the decode backward launches run
         self._run(self.bwd)
 
     # ---- nn.Module / autograd entry -----------------------------------------------------------------

@@ -79,6 +79,13 @@ def loss_grad(ws, outputs, labels, grad_scale=None, origin=None, grid=None):
     return ws.dout
 
 
+def loss_grad_decode(ws, outputs, labels, levels):
+    """Round 5, the captured step: d loss / d outputs with the head's decode backward applied, written as the bf16 rows the prediction
+    convs' backward consumes (``levels``: ep24.engine.Engine.decode_levels(), a host table) - no dense fp32 [B,A,27+C] gradient."""
+    call("loss_grad_decode", ptr(outputs), NCOLS_BASE + ws.C, ptr(labels), ptr(ws.matched_gt), ptr(ws.matched_iou), ptr(ws.result),
+         ws.B, ws.A, ws.C, levels.shape[0], levels.data_ptr(), stream_ptr())
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, outputs, labels, xs, ys, strides, ws, state, origin):

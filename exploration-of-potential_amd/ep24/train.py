@@ -170,13 +170,25 @@ class TrainStep:
         self.home.pack_rest_forward()
         eng.run_lane(self._fwd_split()[0])
 
+    def _loss_grad(self, origin):
+        """The loss gradient.  Default (round 5): fused with the head's decode backward - the rows the prediction convs' backward reads
+        are written directly (ep24_loss_grad_decode) and the plan's head_decode_bwd entries are skipped; with the L1 branch, or
+        PlanOptions(fuse_loss_decode=False), the dense fp32 gradient + the three head_decode_bwd launches."""
+        eng = self.eng
+        fused = bool(eng.options.fuse_loss_decode) and not self.use_l1 and len(eng.head_grads) > 0
+        eng.skip_decode_bwd = fused
+        if fused:
+            eloss.loss_grad_decode(self.ws, eng.outputs, self.labels, eng.decode_levels())
+        else:
+            eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
+        eng.dyn["dout"] = self.ws.dout.data_ptr()
+        eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
+
     def _phase_loss(self):
         eng = self.eng
         origin = eng.origin if self.use_l1 else None
         eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin, candidates_done=True)
-        eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
-        eng.dyn["dout"] = self.ws.dout.data_ptr()
-        eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
+        self._loss_grad(origin)
 
     def _phase_forward(self):
         eng = self.eng
@@ -184,9 +196,7 @@ class TrainStep:
         eng.forward()
         origin = eng.origin if self.use_l1 else None
         eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin)
-        eloss.loss_grad(self.ws, eng.outputs, self.labels, None, origin, (self.xs, self.ys, self.st))
-        eng.dyn["dout"] = self.ws.dout.data_ptr()
-        eng.dyn["d_origin"] = self.ws.d_origin.data_ptr() if self.use_l1 else None
+        self._loss_grad(origin)
 
     def _phase_backward(self, lo, hi):
         eng = self.eng

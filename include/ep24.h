@@ -350,6 +350,14 @@ int ep24_loss_grad(const float* outputs, int ncols, const float* labels, const i
                    int num_classes, const float* origin, const float* xs, const float* ys, const float* strides,
                    float* d_origin, void* stream);
 
+/* Round 5: ep24_loss_grad and ep24_head_decode_bwd of every level in ONE pass (the captured step, not the L1 branch): instead of the dense
+ * fp32 [B,A,27+C] gradient it writes, per head level, the bf16 rows the prediction convs' backward consumes - reg+obj [B*cells][32] and
+ * classes [B*cells][ld_cls = C rounded up to 8] - with the decode's chain rule applied (xy * stride, radii * decoded radius;
+ * yolo_head_24p.py:212-237).  levels: HOST array [n_levels][4] of int64 = (cells per image, the stride's float32 bits, d_regobj, d_cls)
+ * in anchor order; bit-identical to the two-launch form. */
+int ep24_loss_grad_decode(const float* outputs, int ncols, const float* labels, const int32_t* matched_gt, const float* matched_iou,
+                          const float* result, int B, int A, int num_classes, int n_levels, const int64_t* levels, void* stream);
+
 /* stand-alone forms behind utils.bboxes_iou (boxes.py:166-243) and IOUloss.forward (losses.py:80-157) */
 int ep24_circle_pairwise(const float* gt50, const float* pred26, float* out, int G, int P, void* stream);
 int ep24_circle_matched_fwd(const float* pred26, const float* target50, float* loss24, int N, void* stream);

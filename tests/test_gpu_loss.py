@@ -300,3 +300,55 @@ def test_batch_without_any_label_vs_oracle():
     torch.testing.assert_close(g[..., 26], og[..., 26], rtol=1e-4, atol=1e-9)
     for b in range(B):
         assert lf.assignment_of(labels, b)[4] == 0
+
+
+def test_fused_loss_grad_decode(L):
+    """Round 5: ep24_loss_grad_decode = ep24_loss_grad followed by ep24_head_decode_bwd of every level, bit for bit - the rows the
+    prediction convs' backward reads (bf16 reg+obj [B*cells][32], classes [B*cells][80]) written without the dense fp32 gradient."""
+    import struct
+    from ep24 import synth
+    from ep24._lib import call, ptr, stream_ptr
+    B, S, C = 3, 256, 80
+    levels = [(S // 8, 8.0), (S // 16, 16.0), (S // 32, 32.0)]
+    A = sum(h * h for h, _ in levels)
+    g = torch.Generator().manual_seed(21)
+    out = torch.randn(B, A, 27 + C, generator=g)
+    labels = synth.make_labels(B, [4, 0, 7], size=S, seed=22)
+    # decoded head outputs: centres near their cells, positive radii (what the step's outputs look like)
+    xs, ys, st = [], [], []
+    for h, s in levels:
+        yy, xx = torch.meshgrid(torch.arange(h), torch.arange(h), indexing="ij")
+        xs.append(xx.reshape(-1).float()); ys.append(yy.reshape(-1).float()); st.append(torch.full((h * h,), s))
+    xs, ys, st = torch.cat(xs), torch.cat(ys), torch.cat(st)
+    out[..., 0] = (out[..., 0] + xs) * st
+    out[..., 1] = (out[..., 1] + ys) * st
+    out[..., 2:26] = torch.exp(out[..., 2:26] * 0.3) * st[None, :, None] * 2
+    out = out.contiguous().to(DEV)
+    lab, xs, ys, st = labels.to(DEV), xs.to(DEV), ys.to(DEV), st.to(DEV)
+    lf = L.Loss_Function(C)
+    ws = lf.workspace(B, A, DEV)
+    L.assign_and_reduce(ws, out, lab, xs, ys, st, lf._state)
+    assert int(ws.result[55]) > 10                                     # matched anchors exist
+    # two-launch form
+    L.loss_grad(ws, out, lab)
+    want = []
+    a0 = 0
+    for h, s in levels:
+        d_ro = torch.full((B * h * h * 32,), 7.0, dtype=torch.bfloat16, device=DEV)
+        d_cl = torch.full((B * h * h * C,), 7.0, dtype=torch.bfloat16, device=DEV)
+        call("head_decode_bwd", ptr(ws.dout), ptr(out), ptr(d_ro), ptr(d_cl), B, A, a0, h, h, s, 27 + C, None, stream_ptr())
+        want.append((d_ro, d_cl))
+        a0 += h * h
+    # fused form
+    got, rows = [], []
+    for h, s in levels:
+        d_ro = torch.full((B * h * h * 32,), 5.0, dtype=torch.bfloat16, device=DEV)
+        d_cl = torch.full((B * h * h * C,), 5.0, dtype=torch.bfloat16, device=DEV)
+        got.append((d_ro, d_cl))
+        rows.append([h * h, struct.unpack("<I", struct.pack("<f", s))[0], d_ro.data_ptr(), d_cl.data_ptr()])
+    L.loss_grad_decode(ws, out, lab, torch.tensor(rows, dtype=torch.int64))
+    torch.cuda.synchronize()
+    for k, ((w_ro, w_cl), (g_ro, g_cl)) in enumerate(zip(want, got)):
+        assert torch.equal(w_ro.view(torch.int16), g_ro.view(torch.int16)), k       # bit for bit (NaN-safe comparison)
+        assert torch.equal(w_cl.view(torch.int16), g_cl.view(torch.int16)), k
+    assert any(float(w_ro.float().abs().max()) > 0 for w_ro, _ in want)
