@@ -1232,13 +1232,14 @@ int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, h
 
 }  // namespace
 
-namespace ep24_igemm { int wgrad_ring_timeouts(); }             // conv_wgrad.hip: the weight-gradient ring's counter
+namespace ep24_igemm { int wgrad_ring_timeouts(); int bn_barrier_timeouts(); }   // conv_wgrad.hip: the weight-gradient ring's counter; elementwise.hip: the
+                                                                                  // fused BatchNorm backward's grid-wide wait
 
 extern "C" int ep24_conv_ring_timeouts(void) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_timeouts), sizeof(v)) != hipSuccess) return -1;
-    const int w = ep24_igemm::wgrad_ring_timeouts();
-    return w < 0 ? -1 : (int)v + w;
+    const int w = ep24_igemm::wgrad_ring_timeouts(), bb = ep24_igemm::bn_barrier_timeouts();
+    return (w < 0 || bb < 0) ? -1 : (int)v + w + bb;
 }
 
 #ifdef EP24_STAMPS

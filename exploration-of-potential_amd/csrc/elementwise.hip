@@ -151,10 +151,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* z, long ld_
 // several 16-byte loads in flight.
 
 template <int UNROLL, int NT, int ACT>
-__global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
-                                                               const float* save, const float* gamma,
-                                                               const float* beta, long long* dgamma, long long* dbeta,
-                                                               long M, int C, int reps) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                   const float* save, const float* gamma,
+                                                   const float* beta, long long* dgamma, long long* dbeta,
+                                                   long M, int C, int reps, const int bid, const int nblk) {
     constexpr int act = ACT;
     // Wide blocks (NT threads) so that one batch of UNROLL rows per thread covers the tensor with few blocks: the
     // per-block cost is 2*C memory-side int64 atomics, and all of a thread's loads are in flight at once.
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
         const bool active = slot < rm.rpb && cg < (C >> 3);
         float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (active) {
-            const long step = (long)gridDim.x * rm.rpb;
-            const long m_first = (long)blockIdx.x * rm.rpb + slot;
+            const long step = (long)nblk * rm.rpb;
+            const long m_first = (long)bid * rm.rpb + slot;
             bf16x8 vdy[UNROLL], vz[UNROLL];
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {                  // first batch issued before the constants are needed
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
                 const int g = t >> 3, v = t & 7;
                 float a = 0.f;
                 for (int sl = 0; sl < rm.rpb; ++sl) a += red[sl * rm.tpr + g][v];
-                // replica blockIdx % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
+                // replica (block index) % reps of the sums ([reps][2][C]): with one copy every block of the launch added to the SAME 2 C
                 // addresses at about the same time - 256 serial adds per address at the memory-side atomic units, ~5 us of tail
-                long long* dst = (half ? dbeta : dgamma) + (long)(blockIdx.x % reps) * 2 * C + (cg0 + g) * 8 + v;
+                long long* dst = (half ? dbeta : dgamma) + (long)(bid % reps) * 2 * C + (cg0 + g) * 8 + v;
                 atomicAdd((unsigned long long*)dst, (unsigned long long)to_fix_g(a));
             }
             __syncthreads();
@@ -233,11 +233,19 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, l
     }
 }
 
-template <int UNROLL, int ACT, bool ACC = false>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
-                                                               const float* save, const float* gamma, const float* beta,
-                                                               const long long* dgamma, const long long* dbeta, float* ggrad,
-                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C, int reps) {
+template <int UNROLL, int NT, int ACT>
+__global__ __launch_bounds__(NT) void bn_act_bwd_reduce_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                               const float* save, const float* gamma,
+                                                               const float* beta, long long* dgamma, long long* dbeta,
+                                                               long M, int C, int reps) {
+    bn_bwd_reduce_body<UNROLL, NT, ACT>(dy, ld_dy, z, ld_z, save, gamma, beta, dgamma, dbeta, M, C, reps, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int UNROLL, int ACT, bool ACC, bool COH>
+__device__ __forceinline__ void bn_bwd_apply_body(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                  const float* save, const float* gamma, const float* beta,
+                                                  const long long* dgamma, const long long* dbeta, float* ggrad,
+                                                  float* bgrad, bf16* dz, long ld_dz, long M, int C, int reps, const int bid, const int nblk) {
     constexpr int act = ACT;
     const RowMap rm(C);
     const int tid = threadIdx.x;
@@ -253,7 +261,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
         for (int rb = 0; rb < reps; rb += 8) {
             long long a[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = src[(long)(rb + r < reps ? rb + r : rb) * 2 * C];
+            for (int r = 0; r < 8; ++r) {
+                const long long* q = src + (long)(rb + r < reps ? rb + r : rb) * 2 * C;
+                // COH (the one-launch form): the sums were added by THIS kernel's other workgroups - a device-scope load, past the
+                // caches that are only made coherent at kernel boundaries
+                a[r] = COH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 acc += rb + r < reps ? a[r] : 0ll;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
             k3[j] = k1[j] * inv * (sg_ * invM);
             k2[j] = k1[j] * (sb_ * invM) - k3[j] * mean;
         }
-        if (blockIdx.x == 0 && slot == 0 && ggrad) {          // publish this call's sums into the parameter gradients
+        if (bid == 0 && slot == 0 && ggrad) {          // publish this call's sums into the parameter gradients
             // as four 16-byte read-modify-writes issued together: element by element this was 16 serial round trips in block 0,
             // which every launch then waited for
             f32x4* pgg = reinterpret_cast<f32x4*>(ggrad + cg * 8);
@@ -307,8 +320,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
             }
             pgg[0] = a0; pgg[1] = a1; pbg[0] = c0; pbg[1] = c1;
         }
-        const long step = (long)gridDim.x * rm.rpb;
-        for (long m = (long)blockIdx.x * rm.rpb + slot; m < M; m += UNROLL * step) {
+        const long step = (long)nblk * rm.rpb;
+        for (long m = (long)bid * rm.rpb + slot; m < M; m += UNROLL * step) {
             bf16x8 vdy[UNROLL], vz[UNROLL];
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
@@ -338,6 +351,44 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, l
             }
         }
     }
+}
+
+template <int UNROLL, int ACT, bool ACC = false>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                               const float* save, const float* gamma, const float* beta,
+                                                               const long long* dgamma, const long long* dbeta, float* ggrad,
+                                                               float* bgrad, bf16* dz, long ld_dz, long M, int C, int reps) {
+    bn_bwd_apply_body<UNROLL, ACT, ACC, false>(dy, ld_dy, z, ld_z, save, gamma, beta, dgamma, dbeta, ggrad, bgrad, dz, ld_dz, M, C, reps,
+                                               (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Round 5: both backward passes of a unit as ONE launch - reduce, a grid-wide arrive / wait on a counter in global
+// memory, apply.  The grid is at most one workgroup per CU (256 threads, 9 KB + 2 C floats of LDS, <= 128 registers: it fits beside the
+// weight-gradient lane's two workgroups per CU, so every workgroup is resident and the wait cannot starve), every workgroup walks the
+// same rows in both passes (they come back from its XCD's L2 / the Infinity Cache), and one dependent-launch boundary per layer
+// disappears.  The wait is a bounded spin: a give-up is counted (ep24_conv_ring_timeouts adds it) and carries on - wrong numbers and a
+// failed test, never a hung GPU.  The sums are read back with device-scope loads (bn_bwd_apply_body<COH>).
+__device__ unsigned g_bn_barrier_timeouts;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(const bf16* dy, long ld_dy, const bf16* z, long ld_z,
+                                                               const float* save, const float* gamma, const float* beta,
+                                                               long long* dgamma, long long* dbeta, float* ggrad, float* bgrad,
+                                                               bf16* dz, long ld_dz, long M, int C, int reps, unsigned* bar) {
+    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    bn_bwd_reduce_body<4, 256, ACT>(dy, ld_dy, z, ld_z, save, gamma, beta, dgamma, dbeta, M, C, reps, bid, nblk);
+    __syncthreads();                                         // every wave's atomics are acknowledged (s_waitcnt vmcnt(0) in front of the barrier)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int tries = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nblk) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++tries > (1 << 16)) { atomicAdd(&g_bn_barrier_timeouts, 1u); break; }       // ~20 ms: orders beyond any real wait
+        }
+    }
+    __syncthreads();
+    bn_bwd_apply_body<4, ACT, false, true>(dy, ld_dy, z, ld_z, save, gamma, beta, dgamma, dbeta, ggrad, bgrad, dz, ld_dz, M, C, reps, bid, nblk);
 }
 
 int flat_grid(long M, int C, int per_thread) {       // flat 16-byte chunks, `per_thread` chunks per lane
@@ -1189,6 +1240,30 @@ extern "C" int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* 
                        (bf16*)dz, ld_dz, M, C, reps);
     EP24_LAUNCH_CHECK("ep24_bn_act_bwd_apply");
     return EP24_OK;
+}
+
+extern "C" int ep24_bn_act_bwd_fused(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save, const float* gamma,
+                                     const float* beta, int64_t* dgamma, int64_t* dbeta, float* gamma_grad, float* beta_grad, void* dz,
+                                     int64_t ld_dz, int64_t M, int C, int act, int reps, int32_t* barrier, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz && barrier && reps > 0, EP24_E_ARG, "bn_act_bwd_fused: null pointer / reps");
+    EP24_REQUIRE(C % 8 == 0 && C <= 2048 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0, EP24_E_ARG, "bn_act_bwd_fused: alignment / C <= 2048");
+    EP24_REQUIRE((((uintptr_t)save | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)gamma_grad | (uintptr_t)beta_grad) & 15) == 0, EP24_E_ARG,
+                 "bn_act_bwd_fused: save / gamma / beta and their gradients must be 16-byte aligned (they are read as vectors)");
+    // at most one workgroup per CU: all of them resident at once is what makes the grid-wide wait safe
+    int grid = rows_grid(M, C, 4, 256, 256);
+    auto kfn = act == 1 ? bn_act_bwd_fused_kernel<1> : act == 2 ? bn_act_bwd_fused_kernel<2> : act == 3 ? bn_act_bwd_fused_kernel<3> : bn_act_bwd_fused_kernel<0>;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), 2 * (size_t)C * sizeof(float), S_, (const bf16*)dy, ld_dy, (const bf16*)z, ld_z, save, gamma, beta,
+                       (long long*)dgamma, (long long*)dbeta, gamma_grad, beta_grad, (bf16*)dz, ld_dz, M, C, reps, (unsigned*)barrier);
+    EP24_LAUNCH_CHECK("ep24_bn_act_bwd_fused");
+    return EP24_OK;
+}
+
+namespace ep24_igemm {
+int bn_barrier_timeouts() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bn_barrier_timeouts), sizeof(v)) != hipSuccess) return -1;
+    return (int)v;
+}
 }
 
 extern "C" int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,

@@ -911,6 +911,12 @@ class Engine:
         self._stats_specs.append(STATS_REPLICAS * 2 * C)
         return lambda: self.stats.data_ptr() + 8 * off
 
+    def _bar_slot(self):
+        """One zeroed word per unit for the grid-wide wait of ep24_bn_act_bwd_fused (it lives in the sums buffer: cleared with it)."""
+        off = sum(self._sum_specs)
+        self._sum_specs.append(2)
+        return lambda: self.bnsums.data_ptr() + 8 * off
+
     def _sums_slot(self, C):
         """[STATS_REPLICAS][2][C] fixed-point sums of one BatchNorm backward (replica 0's two pointers; replica r is 2 C r further)."""
         off = sum(self._sum_specs)
@@ -987,6 +993,10 @@ class Engine:
             residual.alias_grad(out)
         self.unit_acts[mod if mod is not None else conv] = (x, z, out)
         info = dict(z=z, save=save, gam=gam, bet=bet, sum_g=sum_g, sum_b=sum_b, act=act, cout=cout, fused=0)
+        # one launch for both BatchNorm-backward passes (PlanOptions.fuse_bn_bwd): trunk units only - while the head levels' backward
+        # runs on the second lane its ring kernels hold whole CUs' LDS, and a workgroup that cannot be placed keeps the others waiting
+        one_launch = bool(self.options.fuse_bn_bwd) and not (self._cur_tag is not None and self._cur_tag[0] == "head") and cout <= 2048
+        bar = self._bar_slot() if one_launch else None
         if residual is None:                       # with a residual the incoming gradient is shared with the shortcut: not this unit's alone
             out.bn_info, out.bn_c0 = info, 0
 
@@ -998,12 +1008,17 @@ class Engine:
             self._dz_elems += M * cout
             dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
             assert info["fused"] in (0, cout), "BatchNorm-backward sums fused for a part of the channels only"
-            if not info["fused"]:                     # else: the consumer's input-gradient epilogue has produced the two sums
-                self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                              ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
-            self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                         ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                         dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet), reads=out if info["fused"] else None)
+            if one_launch and not info["fused"]:
+                self._b("bn_act_bwd_fused", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sum_g, sum_b,
+                                             ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, M, cout, act, STATS_REPLICAS, bar),
+                        writes=(gam, bet), reads=out)
+            else:
+                if not info["fused"]:                 # else: the consumer's input-gradient epilogue has produced the two sums
+                    self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                                  ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
+                self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                             ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
+                                             dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet), reads=out if info["fused"] else None)
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every

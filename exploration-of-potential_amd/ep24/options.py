@@ -29,6 +29,7 @@ class PlanOptions:
     fuse_bn_reduce: bool = False       # a 3x3 stride-1 input gradient that is the only consumer of the unit below takes that unit's
                                        # BatchNorm-backward sums in its epilogue (no reduce launch for it).  Measured slower in the step
                                        # (899 against 912 images/s, same box): kept for A/B runs only
+    fuse_bn_bwd: bool = False          # the two BatchNorm-backward passes of a trunk unit as ONE launch with a grid-wide wait (round 5, A/B)
     fuse_loss_decode: bool = True      # TrainStep: loss gradient and the head's decode backward in one pass (round 5; not with the L1 branch)
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane

@@ -525,6 +525,12 @@ int ep24_colstats(const void* x, int64_t ld, int64_t* stats, int64_t ld_stats, i
 /* dst[rep][2][C] = the first C channels of src[rep][2][ld_src]. */
 int ep24_stats_gather(const int64_t* src, int64_t ld_src, int64_t* dst, int C, int reps, void* stream);
 /* ep24_bn_act_bwd_apply with dz += instead of dz = (same arguments). */
+/* Round 5: pass 1 and pass 2 as ONE launch (at most one 256-thread workgroup per CU; a grid-wide arrive / wait on *barrier between the
+ * passes - an int32 the caller zeroes before the launch; a bounded spin whose give-ups ep24_conv_ring_timeouts counts).  Same sums,
+ * same dz, same gradient publication as the two launches. */
+int ep24_bn_act_bwd_fused(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save, const float* gamma,
+                          const float* beta, int64_t* dgamma, int64_t* dbeta, float* gamma_grad, float* beta_grad, void* dz,
+                          int64_t ld_dz, int64_t M, int C, int act, int reps, int32_t* barrier, void* stream);
 int ep24_bn_act_bwd_apply_acc(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
                               const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
                               float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act, int reps,

@@ -532,6 +532,62 @@ def test_bn_backward_keeps_a_diverged_gradient_visible(bad):
         assert float(b[ok].max()) < 0                                  # the negative rest is really there
 
 
+@pytest.mark.parametrize("M,C", [(400, 64), (32000, 256), (128000, 128), (8000, 1024), (2048000 // 8, 64)])
+def test_bn_backward_one_launch(M, C):
+    """Round 5: ep24_bn_act_bwd_fused = reduce + grid-wide wait + apply in one launch.  Against torch fp32 like the two-launch form, against the
+    two-launch form itself (its sums are folded from other per-block partials: equal to fp32 rounding, not bit for bit), reproducible run to
+    run, the wait's counter reaching the grid size, and no give-up of the bounded spin."""
+    call, ptr, sp = _abi()
+    from ep24 import _lib
+    z = rnd(M, C, seed=51, scale=2.0)
+    dy = rnd(M, C, seed=52)
+    gamma, beta = torch.rand(C) + 0.5, torch.rand(C) - 0.5
+    zr = z.float().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.silu(F.batch_norm(zr, torch.zeros(C), torch.ones(C), g_, b_, True, 0.03, 1e-3))
+    y_ref.backward(dy.float())
+    zd, dyd, gd, bd = z.to(DEV), dy.to(DEV), gamma.to(DEV), beta.to(DEV)
+    R = 8
+    stats = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+    stats[0, 0] = (z.double().sum(0) * 2 ** 20).round().long().to(DEV)
+    stats[0, 1] = ((z.double() ** 2).sum(0) * 2 ** 20).round().long().to(DEV)
+    save = torch.zeros(2, C, device=DEV)
+    y = torch.zeros(M, C, dtype=BF, device=DEV)
+    call("bn_act_fwd", ptr(zd), C, ptr(stats), R, ptr(gd), ptr(bd), ptr(torch.zeros(C, device=DEV)), ptr(torch.ones(C, device=DEV)),
+         ptr(torch.zeros((), dtype=torch.int64, device=DEV)), None, ptr(save), ptr(y), C, None, 0, M, C, 1e-3, 0.03, 1, sp())
+
+    def two():
+        sums = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+        gg, bg = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dz = torch.zeros(M, C, dtype=BF, device=DEV)
+        call("bn_act_bwd_reduce", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), M, C, 1, R, sp())
+        call("bn_act_bwd_apply", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), ptr(gg), ptr(bg), ptr(dz), C, M, C, 1, R, sp())
+        return dz, gg, bg
+
+    def one():
+        sums = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+        gg, bg = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dz = torch.zeros(M, C, dtype=BF, device=DEV)
+        bar = torch.zeros(2, dtype=torch.int32, device=DEV)
+        call("bn_act_bwd_fused", ptr(dyd), C, ptr(zd), C, ptr(save), ptr(gd), ptr(bd), ptr(sums), ptr(sums, C), ptr(gg), ptr(bg), ptr(dz), C, M, C, 1, R,
+             ptr(bar), sp())
+        torch.cuda.synchronize()
+        return dz, gg, bg, int(bar[0])
+
+    dz2, gg2, bg2 = two()
+    dz1, gg1, bg1, arrived = one()
+    assert 1 <= arrived <= 256                                        # every workgroup of the (one per CU at most) grid arrived
+    close(dz1, zr.grad, rel=2e-2)
+    close(gg1, g_.grad, rel=5e-3)
+    close(bg1, b_.grad, rel=5e-3)
+    close(gg1, gg2.cpu(), rel=1e-4)
+    close(bg1, bg2.cpu(), rel=1e-4)
+    assert float((dz1.float() - dz2.float()).abs().max()) <= 2.0 ** -7 * float(dz2.float().abs().max())      # a bf16 ulp of the tensor's range
+    again = one()
+    assert torch.equal(again[0], dz1) and torch.equal(again[1], gg1) and torch.equal(again[2], bg1)
+    assert _lib.lib().fn["ep24_conv_ring_timeouts"]() == 0
+
+
 def test_spp_fwd_bwd():
     call, ptr, sp = _abi()
     B, H, W, C = 2, 20, 20, 16
