@@ -131,7 +131,7 @@ class Trainer:
         done = False
         self.epoch = self.start_epoch
         self.epoch_complete = False
-        tp_t0 = tp_seen = None                            # --throughput-json: a synchronised window over the run's last steps
+        tp_t0 = tp_seen = tp_dt = None                    # --throughput-json: a synchronised window over the run's last steps
         for epoch in range(self.start_epoch, self.max_epoch):
             self.epoch = epoch
             model.train()
@@ -196,6 +196,9 @@ class Trainer:
                     host["rest"] += now - t_mark
                     t_mark = now
                 if args.steps and self.run_steps >= args.steps:
+                    if tp_t0 is not None:                 # the window ends HERE: the checkpoint written below is not training time
+                        torch.cuda.synchronize()          # (rounds 3-5 measured it inside the window: ~0.25 s, 1.2 ms per step of 200)
+                        tp_dt = time.perf_counter() - tp_t0
                     done = True
                     break
             else:
@@ -207,8 +210,10 @@ class Trainer:
             if done:
                 break
         if tp_t0 is not None:
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - tp_t0
+            if tp_dt is None:                             # the epochs ran out before --steps did
+                torch.cuda.synchronize()
+                tp_dt = time.perf_counter() - tp_t0
+            dt = tp_dt
             if self.rank == 0:
                 import json
                 rec = {"images_per_s": round(tp_seen * self.world / dt, 2), "ms_per_step": round(dt / max(args.throughput_window, 1) * 1e3, 3),
@@ -261,6 +266,11 @@ class Trainer:
         from ep24.input import DataPrefetcher, TrainTransform
         pf = DataPrefetcher(self.train_loader, tuple(self.input_size), TrainTransform(max_labels=50))
         self.prefetcher = pf                              # its t_loader / t_upload split the throughput record's host time
+        if self.args.resident_batch:                      # diagnostic: what the input pipeline costs the GPU (tools/trainer_timing.sh)
+            images, labels = pf.next()
+            for _ in range(len(self.train_loader)):
+                yield images, labels
+            return
         while True:
             images, labels = pf.next()
             if images is None:
@@ -326,6 +336,8 @@ def make_parser():
                    "images + normalised label rows; letterbox and label scaling run on the GPU behind the prefetcher (SURVEY 8f N1)")
     p.add_argument("--fp32-batches", action="store_true", help="the reference's form of the source: ready-made fp32 canvases [B,3,S,S] + label tables from "
                    "the loader (datasets/data_augment.py TrainTransform on the host side)")
+    p.add_argument("--resident-batch", action="store_true", help="diagnostic: the epoch's first batch stays on the device and is fed again and again "
+                   "(no upload, no letterbox after the first step): the entry point's rate without its input pipeline")
     p.add_argument("--dp-wire", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce under torch.distributed.run")
     p.add_argument("--throughput-json", default=None, type=str, help="with --steps N: write images/s over the run's last --throughput-window steps "
                    "(synchronised at both ends) to this file")
