@@ -106,3 +106,9 @@ def require_gpu():
     import torch
     if not torch.cuda.is_available():
         raise Ep24Error("ep24: no GPU visible - the hot path runs only as HIP kernels on gfx950 (no CPU fallback)")
+    q = os.environ.get("GPU_MAX_HW_QUEUES", "")
+    if q.isdigit() and int(q) > 4:
+        # measured in round 5: with 5 or more hardware queues per process the two lanes of the captured step no
+        # longer run side by side - 587 instead of 978 images/s on one box; 2, 3 and 4 (the runtime's default) are equal
+        import warnings
+        warnings.warn("ep24: GPU_MAX_HW_QUEUES=%s - the captured training step loses ~40 %% with more than 4 hardware queues" % q)
