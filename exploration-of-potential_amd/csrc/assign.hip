@@ -158,7 +158,8 @@ constexpr int COST_NT = 256;                                       // threads th
 
 __global__ __launch_bounds__(COST_NT) void cost_kernel(const float* outputs, int ncols, const float* labels,
                                                        const int* num_gt, const unsigned long long* in_box,
-                                                       const unsigned long long* in_ctr, float* pw, float* cost, int A, int C) {
+                                                       const unsigned long long* in_ctr, float* pw, float* cost, int A, int C,
+                                                       int a_base, int a_end) {
     __shared__ float gr[G_MAX][24], gcx[G_MAX], gcy[G_MAX];
     __shared__ float spr[24][COST_APB];                             // a candidate's 24 predicted radii, k-major
     __shared__ float s_pcx[COST_APB], s_pcy[COST_APB], s_so[COST_APB], s_s0[COST_APB];
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(COST_NT) void cost_kernel(const float* outputs, int
     // ---- compaction by the first wave: slot of an anchor among the candidates of the workgroup (anchor order is kept)
     int slot = -1;
     unsigned long long mb = 0ull, mc = 0ull;
-    const int a = blockIdx.x * COST_APB + threadIdx.x;
+    const int a = a_base + blockIdx.x * COST_APB + threadIdx.x;     // the launch covers anchors [a_base, a_end) of every image
     if (threadIdx.x < COST_APB) {
-        if (a < A) { mb = in_box[(long)b * A + a]; mc = in_ctr[(long)b * A + a]; }
+        if (a < a_end) { mb = in_box[(long)b * A + a]; mc = in_ctr[(long)b * A + a]; }
         const bool cand = (mb | mc) != 0ull;                        // fg_mask
         const unsigned long long bal = __ballot(cand);
         if (cand) slot = __popcll(bal & ((1ull << threadIdx.x) - 1ull));
@@ -431,16 +432,27 @@ extern "C" int ep24_assign_candidates(const float* labels, const float* xs, cons
     return EP24_OK;
 }
 
-extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
-                                const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
-                                int num_classes, void* stream) {
+// Anchors [a_lo, a_hi) of every image: a (candidate, GT) pair's pw / cost do not depend on which anchors share its workgroup, so the
+// rows of a head level can be taken as soon as that level's outputs exist (ep24.train: on the forward lane that produced them) and
+// the launches together write exactly what one launch over [0, A) writes.
+extern "C" int ep24_assign_cost_range(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
+                                      const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
+                                      int num_classes, int a_lo, int a_hi, void* stream) {
     EP24_REQUIRE(outputs && labels && num_gt && in_box && in_ctr && pw && cost, EP24_E_ARG, "assign_cost: null pointer");
     EP24_REQUIRE(ncols == 27 + num_classes, EP24_E_ARG, "assign_cost: ncols=%d != 27+%d", ncols, num_classes);
     EP24_REQUIRE(num_classes >= 1 && COST_APB * num_classes <= 24 * COST_NT, EP24_E_UNSUPPORTED, "assign_cost: at most %d classes", 24 * COST_NT / COST_APB);
-    hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(A, COST_APB), B), dim3(COST_NT), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
-                       (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, pw, cost, A, num_classes);
+    EP24_REQUIRE(B > 0 && 0 <= a_lo && a_lo <= a_hi && a_hi <= A, EP24_E_ARG, "assign_cost: anchors [%d, %d) of %d", a_lo, a_hi, A);
+    if (a_lo == a_hi) return EP24_OK;
+    hipLaunchKernelGGL(cost_kernel, dim3(ep24_cdiv(a_hi - a_lo, COST_APB), B), dim3(COST_NT), 0, (hipStream_t)stream, outputs, ncols, labels, num_gt,
+                       (const unsigned long long*)in_box, (const unsigned long long*)in_ctr, pw, cost, A, num_classes, a_lo, a_hi);
     EP24_LAUNCH_CHECK("ep24_assign_cost");
     return EP24_OK;
+}
+
+extern "C" int ep24_assign_cost(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
+                                const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
+                                int num_classes, void* stream) {
+    return ep24_assign_cost_range(outputs, ncols, labels, num_gt, in_box, in_ctr, pw, cost, B, A, num_classes, 0, A, stream);
 }
 
 extern "C" int ep24_dynamic_k(const float* pw, const float* cost, const int32_t* num_gt, const uint64_t* in_box,

@@ -49,17 +49,28 @@ def assign_candidates(ws, labels, xs, ys, strides):
          stream_ptr())
 
 
-def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin=None, candidates_done=False):
+def assign_cost_range(ws, outputs, labels, a_lo, a_hi):
+    """pw / cost rows of anchors [a_lo, a_hi) (candidate masks must be there): what ep24.train runs on the forward lane of a head
+    level as soon as that level's outputs exist."""
+    call("assign_cost_range", ptr(outputs), NCOLS_BASE + ws.C, ptr(labels), ptr(ws.num_gt), ptr(ws.masks[0]), ptr(ws.masks[1]),
+         ptr(ws.pw), ptr(ws.cost), ws.B, ws.A, ws.C, int(a_lo), int(a_hi), stream_ptr())
+
+
+def assign_and_reduce(ws, outputs, labels, xs, ys, strides, state, origin=None, candidates_done=False, cost_done=()):
     """Kernels a4..a10 forward: fills ws.matched_* and ws.result; updates `state` (device [26]).  ``origin`` [B,A,26]
-    (the head's raw regression outputs) switches the L1 branch on (losses.py:197-198, 304-309)."""
+    (the head's raw regression outputs) switches the L1 branch on (losses.py:197-198, 304-309).  ``cost_done``: anchor ranges
+    ``(lo, hi)`` whose pw / cost rows assign_cost_range has written already."""
     B, A, C = ws.B, ws.A, ws.C
     ncols = NCOLS_BASE + C
     s = stream_ptr()
     in_box, in_ctr, match = ws.masks[0], ws.masks[1], ws.masks[2]
     if not candidates_done:
         call("assign_candidates", ptr(labels), ptr(xs), ptr(ys), ptr(strides), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), B, A, s)
-    call("assign_cost", ptr(outputs), ncols, ptr(labels), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ptr(ws.pw),
-         ptr(ws.cost), B, A, C, s)
+    pos = 0
+    for lo, hi in sorted(cost_done) + [(A, A)]:               # the ranges nobody has done
+        if lo > pos:
+            assign_cost_range(ws, outputs, labels, pos, lo)
+        pos = max(pos, hi)
     call("memset_zero", ptr(match), match.numel() * 8, s)
     call("dynamic_k", ptr(ws.pw), ptr(ws.cost), ptr(ws.num_gt), ptr(in_box), ptr(in_ctr), ptr(match), ptr(ws.ks), B, A, s)
     call("assign_resolve", ptr(match), ptr(ws.pw), ptr(ws.cost), ptr(ws.num_gt), ptr(ws.matched_gt), ptr(ws.matched_iou),

@@ -35,6 +35,8 @@ class PlanOptions:
     parallel_forward: bool = True      # level-0 head chain on a second forward lane
     forward_lanes: int = 2             # 2: one more stream beside the main lane; 3: head level 1 on a stream of its own
     head1_side: bool = True            # with two lanes: head level 1 follows head level 0 on the second lane (round 5; False: on the main lane)
+    cost_on_lanes: bool = True         # SimOTA's pw / cost rows of head levels 0, 1 on the forward lane that produced them (round 5)
+    tail_cuts: bool = True             # last 4 % of backward: a graph cut in front of an input gradient that follows its layer's weight gradient (round 5)
     bwd_cuts: Optional[Tuple[float, ...]] = None   # fractions of the backward list where its graph segments are cut (None: default)
     chunked_update: bool = True        # the optimizer update in pieces on the weight-gradient lane, each as soon as its gradients are complete
 

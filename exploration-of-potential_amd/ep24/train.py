@@ -187,7 +187,8 @@ class TrainStep:
     def _phase_loss(self):
         eng = self.eng
         origin = eng.origin if self.use_l1 else None
-        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin, candidates_done=True)
+        eloss.assign_and_reduce(self.ws, eng.outputs, self.labels, self.xs, self.ys, self.st, self.state, origin, candidates_done=True,
+                                cost_done=getattr(self, "_cost_done", ()))
         self._loss_grad(origin)
 
     def _phase_forward(self):
@@ -271,6 +272,15 @@ class TrainStep:
             ready = {c: i for i, c in enumerate(rc[1:])}          # cut index -> reducer segment that ends there
         if getattr(self.eng, "bwd_tail_cut", None):            # the reduce launch in front of the last unit closes a segment:
             cuts.add(self.eng.bwd_tail_cut)                    # the side lane runs it while the main lane does that unit's BatchNorm
+        if self.eng.options.tail_cuts:
+            # At the END of backward what the side lane still holds is exposed.  A weight gradient waits for the main lane to finish the
+            # SEGMENT it is in, i.e. also for the input gradient of its own layer that follows it in the list (dark2's stride-2 conv:
+            # 0.39 ms, during which the side lane sat idle and the stem's weight gradient then queued behind this one).  In the last
+            # entries a cut goes in front of every such input gradient: the weight gradient starts when its dy is there.
+            bwd = self.eng.bwd
+            for i in range(max(int(n * 0.96), 2), n):
+                if bwd[i][0].startswith("conv_dgrad") and bwd[i - 1][0] == "@side_record" and bwd[i - 2][0].startswith("side:"):
+                    cuts.add(i)
         join = self.eng.bwd_join
         if join is not None:                                   # head levels 1, 2 run on the side lane up to here
             cuts.add(join)
@@ -314,7 +324,22 @@ class TrainStep:
         if split is None:
             self.g_fwd = capture(self._phase_forward)
         else:
-            lanes = [capture(lambda l=l: eng.run_lane(l)) for l in split[1:]]
+            # SimOTA's pw / cost rows of a head level on the lane that produced the level (round 5): the second lane has 0.3 ms to spare
+            # at the end of the forward pass and the rows of levels 0 and 1 are 95 % of the loss path's longest kernel
+            self._cost_done = []
+            lane_cost = {}
+            if eng.options.cost_on_lanes and len(eng.head_grads) == 3:
+                a1 = eng.head_grads[0][0]
+                lane_cost[2] = (0, a1)                                        # split[2]: head level 0
+                if len(split) == 5 and self.forward_lanes < 3:                # (a third stream is not ordered behind the candidate masks)
+                    lane_cost[4] = (a1, a1 + eng.head_grads[1][0])            # split[4]: head level 1, behind level 0 on the same lane
+                self._cost_done = sorted(lane_cost.values())
+
+            def lane_fn(i, l):
+                eng.run_lane(l)
+                if i in lane_cost:
+                    eloss.assign_cost_range(self.ws, eng.outputs, self.labels, *lane_cost[i])
+            lanes = [capture(lambda i=i, l=l: lane_fn(i, l)) for i, l in enumerate(split) if i >= 1]
             self.g_pre = capture(self._phase_pre_side)
             self.g_pre_bwd = capture(self._phase_pre_backward)
             self.g_fwd = (capture(self._phase_forward_head),) + tuple(lanes) + (capture(self._phase_loss),)

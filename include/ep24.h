@@ -316,6 +316,12 @@ int ep24_assign_candidates(const float* labels, const float* xs, const float* ys
 int ep24_assign_cost(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
                      const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
                      int num_classes, void* stream);
+/* The same for anchors [a_lo, a_hi) of every image (round 5).  A pair's values do not depend on the launch's extent: launches over
+ * disjoint ranges that cover [0, A) write exactly what ep24_assign_cost writes, so a head level's rows can be computed as soon as
+ * that level's outputs exist (ep24.train: on the forward lane that produced them, off the loss path). */
+int ep24_assign_cost_range(const float* outputs, int ncols, const float* labels, const int32_t* num_gt,
+                           const uint64_t* in_box, const uint64_t* in_ctr, float* pw, float* cost, int B, int A,
+                           int num_classes, int a_lo, int a_hi, void* stream);
 /* a8 part 1 (dynamic_k_matching, losses.py:449-464): per (image, gt) top-10 pw sum -> k, the k cheapest
  * candidates are OR-ed into match[B*A] (uint64 bit g).  match must be zeroed by the caller; ks[B,50] out. */
 int ep24_dynamic_k(const float* pw, const float* cost, const int32_t* num_gt, const uint64_t* in_box,

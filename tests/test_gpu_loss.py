@@ -352,3 +352,44 @@ def test_fused_loss_grad_decode(L):
         assert torch.equal(w_ro.view(torch.int16), g_ro.view(torch.int16)), k       # bit for bit (NaN-safe comparison)
         assert torch.equal(w_cl.view(torch.int16), g_cl.view(torch.int16)), k
     assert any(float(w_ro.float().abs().max()) > 0 for w_ro, _ in want)
+
+
+def test_cost_rows_by_anchor_ranges(L):
+    """Round 5: ep24_assign_cost_range over disjoint anchor ranges (a head level each - and cuts that are no multiple of the
+    kernel's 64 anchors per workgroup) writes exactly the pw / cost rows of ONE ep24_assign_cost launch, and the assignment that
+    follows is the same - what lets ep24.train take a level's rows on the forward lane that produced the level."""
+    B, S, C = 3, 416, 80                                                # 52^2 + 26^2 + 13^2 anchors: level starts 2704, 3380 (not aligned)
+    levels = [(S // 8, 8.0), (S // 16, 16.0), (S // 32, 32.0)]
+    A = sum(h * h for h, _ in levels)
+    g = torch.Generator().manual_seed(31)
+    out = torch.randn(B, A, 27 + C, generator=g)
+    labels = synth.make_labels(B, [6, 0, 9], size=S, seed=32)
+    xs, ys, st = [], [], []
+    for h, s in levels:
+        yy, xx = torch.meshgrid(torch.arange(h), torch.arange(h), indexing="ij")
+        xs.append(xx.reshape(-1).float()); ys.append(yy.reshape(-1).float()); st.append(torch.full((h * h,), s))
+    xs, ys, st = torch.cat(xs), torch.cat(ys), torch.cat(st)
+    out[..., 0] = (out[..., 0] + xs) * st
+    out[..., 1] = (out[..., 1] + ys) * st
+    out[..., 2:26] = torch.exp(out[..., 2:26] * 0.3) * st[None, :, None] * 2
+    out = out.contiguous().to(DEV)
+    lab, xs, ys, st = labels.to(DEV), xs.to(DEV), ys.to(DEV), st.to(DEV)
+    lf = L.Loss_Function(C)
+    ws = lf.workspace(B, A, DEV)
+    ws.pw.fill_(-3.0); ws.cost.fill_(-3.0)
+    L.assign_and_reduce(ws, out, lab, xs, ys, st, lf._state.clone())
+    torch.cuda.synchronize()
+    want = [x.clone() for x in (ws.pw, ws.cost, ws.matched_gt, ws.matched_iou, ws.result)]
+    assert int(ws.result[55]) > 10
+    a1, a2 = levels[0][0] ** 2, levels[0][0] ** 2 + levels[1][0] ** 2
+    for cuts in ([(0, a1), (a1, a2)], [(0, a1)], [(0, 1), (1, 77), (77, a2 + 5), (a2 + 5, A)]):
+        ws.pw.fill_(-3.0); ws.cost.fill_(-3.0)
+        L.assign_candidates(ws, lab, xs, ys, st)
+        for lo, hi in cuts:
+            L.assign_cost_range(ws, out, lab, lo, hi)
+        L.assign_and_reduce(ws, out, lab, xs, ys, st, lf._state.clone(), candidates_done=True, cost_done=cuts)
+        torch.cuda.synchronize()
+        for w, x in zip(want, (ws.pw, ws.cost, ws.matched_gt, ws.matched_iou, ws.result)):
+            assert torch.equal(w, x), cuts
+    with pytest.raises(Exception):
+        L.assign_cost_range(ws, out, lab, 10, A + 1)
