@@ -245,10 +245,28 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
 // the offset select.  The im2col form of rounds 1 - 2 wrote 224 bytes per pixel (459 MB at B = 20) and read them back twice
 // (forward and weight gradient): 0.33 + 0.14 ms at the head of every step.  The weight tile is re-indexed on its way into LDS
 // (HBM layout [Cout][tap * 12 + channel], row stride p.K).
-template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
-__global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
-    constexpr int SP = BN / 64, NTW = SP * 4, MT = 2, RG = 4 * MT * 16;       // 4 waves x 32 rows per unit
+//
+// XF (round 5): the A operand is TRANSFORMED on its way from memory to the MFMA - the BatchNorm pass that would have produced it as a
+// launch of its own happens here, in the registers the rows pass through anyway (this is the one conv kernel whose A operand does):
+//   1 / 2  A = y = silu(bn(z)) (2: + residual row), z = p.src = the producing unit's raw output; y is stored to p.xf_out as
+//          bn_act_fwd would have stored it (same expressions, same rounding: the rows the MFMAs read are the stored bf16 values)
+//   3      A = dz = bn_act_bwd_apply(dy = p.src, z = p.xf_aux); dz is stored to p.xf_out for the weight gradient
+// Per-channel constants are folded from the fixed-point sums by every workgroup into LDS behind the weight tile (as the BatchNorm
+// kernels' prologues do); block 0 also does those kernels' block-0 duties.  Host: N <= BN (one N tile: every row is made once).
+template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false, int XF = 0>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+__global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
+    // 4 waves x 32 rows per row group.  The transformed-A forms walk a wave's 32 rows as two blocks of 16 (XS = 2 sub-blocks: their
+    // second source row and the constants need the registers - with 32 rows per block the loop spilled, and a scratch access in the
+    // loop turns every counted wait into vmcnt(0)); the rows a lane owns and the order it adds them to the BatchNorm statistics are
+    // the plain kernel's, so the statistics are bit-identical as well.
+    constexpr int SP = BN / 64, NTW = SP * 4, MT = XF ? 1 : 2, XS = XF ? 2 : 1, RG = 128;
+    static_assert(XF == 0 || H == 1, "the transformed-A forms make one K pass");
     constexpr int OOB = 0x7FFFFFF0;
+    constexpr bool XAUX = XF >= 2;                                            // a second source row beside p.src
+    constexpr int XNC = XF == 3 ? 5 : 2;                                      // constants per channel: (sc, sh) / (sc, sh, k1, k2, k3)
+    constexpr int XKP = H * 128;                                              // channels the K steps touch
+    static_assert(XF == 0 || (EPI == 0 && !GATHER), "the transformed-A forms are training forms of the plain 1x1 kernel");
+    constexpr int NPAN_ = (H - 1) * 2 + (NKS + 1) / 2;                        // 64-channel weight panels in LDS (NPAN below)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     const auto drsrc = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
     const long n_groups = (p.M + RG - 1) / RG;
     const long my_groups = rb < n_groups ? (n_groups - rb + bpn - 1) / bpn : 0;
-    const long units = my_groups * H;                                      // (row group, K half) pairs
+    const long units = my_groups * H * XS;                                 // (row group, K half) pairs / (row group, 16-row half) pairs
 
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -279,11 +297,13 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
             gof[ks] = (((ty - 1) * p.GW + gdx[ks]) * 16 + (fq & 1) * 8) * 2;
         }
     }
+    [[maybe_unused]] const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(XAUX ? p.xf_aux : p.src), 0, XAUX ? p.xf_aux_bytes : 0u, 0x00020000);
+    [[maybe_unused]] const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(XF ? p.xf_out : (bf16*)p.dst, 0, XF ? p.xf_out_bytes : 0u, 0x00020000);
     // every load is issued: a row past M (also every row of a unit past the last one) and a K step past K read zeros
-    auto load = [&](bf16x8 (&A)[MT][NKS], long u) {
-        const long g = rb + (u / H) * bpn;
+    auto load = [&](bf16x8 (&A)[MT][NKS], [[maybe_unused]] bf16x8 (&X)[XAUX ? MT : 1][XAUX ? NKS : 1], long u) {
+        const long g = rb + (u / (H * XS)) * bpn;
         const int h = (int)(u % H);
-        const long r0 = g * RG + wave * (MT * 16);
+        const long r0 = g * RG + wave * 32 + (XF ? (int)(u % XS) * 16 : 0);
         if constexpr (GATHER) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -307,11 +327,17 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         for (int i = 0; i < MT; ++i) {
             const long row = r0 + i * 16 + frow;
             const int base = row < p.M ? (int)((row * p.ld_src + fq * 8 + h * 128) * 2) : OOB;
+            [[maybe_unused]] const int xbase = XAUX && row < p.M ? (int)((row * p.xf_ldaux + fq * 8 + h * 128) * 2) : OOB;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const int vo = (h * 128 + ks * 32 + fq * 8 < p.K) ? base + ks * 64 : OOB;       // a select, not a branch
                 v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
                 A[i][ks] = __builtin_bit_cast(bf16x8, t);
+                if constexpr (XAUX) {
+                    const int xo = (h * 128 + ks * 32 + fq * 8 < p.K) ? xbase + ks * 64 : OOB;
+                    v4i tx = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
+                    X[i][ks] = __builtin_bit_cast(bf16x8, tx);
+                }
             }
         }
     };
@@ -330,8 +356,52 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
         }
     }
     // HH: which K half this block is (compile time: in the two-block loop body block 0 is half 0 and block 1 half H - 1)
-    auto compute = [&](bf16x8 (&A)[MT][NKS], long u, auto hh) {
+    auto compute = [&](bf16x8 (&A)[MT][NKS], [[maybe_unused]] bf16x8 (&X)[XAUX ? MT : 1][XAUX ? NKS : 1], long u, auto hh) {
         constexpr int h = decltype(hh)::value;
+        if constexpr (XF != 0) {
+            // the BatchNorm pass on the rows in flight: constants of a lane's 8 channels per K step from LDS (the 16 lanes of a
+            // quarter read the same words: broadcast), rows >= M become zeros (they must add nothing to this unit's statistics)
+            const float* xc = reinterpret_cast<const float*>(smem + NPAN_ * (BN * 128));
+            const long g_ = rb + (u / XS) * bpn;
+            const long r0_ = g_ * RG + wave * 32 + (int)(u % XS) * 16;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int ch0 = h * 128 + ks * 32 + fq * 8;
+                bf16x8 o_[MT];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {            // four channels at a time: their constants are live, no more (registers)
+                    f32x4 c_[XNC];
+#pragma unroll
+                    for (int q = 0; q < XNC; ++q) c_[q] = *reinterpret_cast<const f32x4*>(xc + q * XKP + ch0 + hf * 4);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = hf * 4 + jj;
+                            if constexpr (XF == 3) {            // bn_bwd_apply_body's expressions
+                                const float zz = (float)X[i][ks][j];
+                                const float du = (float)A[i][ks][j] * act_grad(fmaf(zz, c_[0][jj], c_[1][jj]), 1);
+                                o_[i][j] = (bf16)fmaf(-c_[4][jj], zz, fmaf(c_[2][jj], du, -c_[3][jj]));
+                            } else {                            // bn_act_fwd_kernel's
+                                const float uu = fmaf((float)A[i][ks][j], c_[0][jj], c_[1][jj]);
+                                if constexpr (XF == 2) o_[i][j] = (bf16)(act_fwd(uu, 1) + (float)X[i][ks][j]);
+                                else o_[i][j] = (bf16)act_fwd(uu, 1);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const long row = r0_ + i * 16 + frow;
+                    const bool ok = row < p.M;
+                    const bf16x8 o = o_[i];
+                    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    A[i][ks] = ok ? o : zero8;
+                    const int so = (ok && ch0 < p.K) ? (int)((row * p.xf_ldout + ch0) * 2) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, o), orsrc, so, 0, 0);
+                }
+            }
+        }
         if constexpr (h == 0) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -359,8 +429,8 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
             }
         }
         if constexpr (h != H - 1) return;
-        const long g = rb + (u / H) * bpn;
-        const long r0 = g * RG + wave * (MT * 16);
+        const long g = rb + (u / (H * XS)) * bpn;
+        const long r0 = g * RG + wave * 32 + (XF ? (int)(u % XS) * 16 : 0);
         if constexpr (infer) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -409,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             v[q] = acc[i][sp * 4 + q][r];
-                            s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q];
+                            if constexpr (XF != 3) { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }     // (an input gradient has no statistics)
                         }
                         if constexpr (ACC) {
                             const bf16x4 o = __builtin_bit_cast(bf16x4, old[r][sp]);
@@ -427,8 +497,99 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
 
     // The first block of rows is requested BEFORE the weight tile is fetched into LDS: the two round trips overlap.
     bf16x8 A0[MT][NKS], A1[MT][NKS];
-    load(A0, 0);
+    bf16x8 X0[XAUX ? MT : 1][XAUX ? NKS : 1], X1[XAUX ? MT : 1][XAUX ? NKS : 1];
+    load(A0, X0, 0);
     constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;       // every 64-channel panel the K steps of the loop read (zeros past K)
+    static_assert(NPAN == NPAN_, "panels");
+    if constexpr (XF == 1 || XF == 2) {
+        // bn_act_fwd_kernel's prologue: the producer's fixed-point statistics -> scale / shift per channel; block 0 keeps mean and
+        // invstd for the backward and updates the running statistics
+        float* xc = reinterpret_cast<float*>(smem + NPAN * (BN * 128));
+        const int C = p.K;
+        const long long* stats = p.xf_stats;
+        const int reps = p.xf_reps;
+        for (int c = tid; c < XKP; c += 256) {
+            float s_ = 0.f, t_ = 0.f;
+            if (c < C) {
+                long long i1 = 0, i2 = 0;
+                const float gmm = p.xf_gamma[c], bta = p.xf_beta[c];
+                for (int rb_ = 0; rb_ < reps; rb_ += 8) {
+                    long long a[8], b[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int rr_ = rb_ + r < reps ? rb_ + r : rb_;
+                        a[r] = stats[(long)rr_ * 2 * C + c];
+                        b[r] = stats[(long)rr_ * 2 * C + C + c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        i1 += rb_ + r < reps ? a[r] : 0ll;
+                        i2 += rb_ + r < reps ? b[r] : 0ll;
+                    }
+                }
+                const float mean = from_fix(i1) / (float)p.M;
+                float var = from_fix(i2) / (float)p.M - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const float invstd = rsqrtf(var + p.xf_eps);
+                s_ = gmm * invstd;
+                t_ = bta - mean * s_;
+                if (blockIdx.x == 0) {
+                    p.xf_save[c] = mean;
+                    p.xf_save[C + c] = invstd;
+                    if (p.xf_rmean) {
+                        const float unb = p.M > 1 ? var * (float)p.M / (float)(p.M - 1) : var;
+                        p.xf_rmean[c] = (1.f - p.xf_momentum) * p.xf_rmean[c] + p.xf_momentum * mean;
+                        p.xf_rvar[c] = (1.f - p.xf_momentum) * p.xf_rvar[c] + p.xf_momentum * unb;
+                    }
+                }
+            }
+            xc[c] = s_;
+            xc[XKP + c] = t_;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            if (p.xf_nbt) *p.xf_nbt += 1;
+            if (p.xf_nbt2) *p.xf_nbt2 += 1;
+        }
+    }
+    if constexpr (XF == 3) {
+        // bn_bwd_apply_body's prologue: fold the replicas of the two sums (exact integers), derive the five constants per channel;
+        // block 0 publishes the sums into the parameter gradients
+        float* xc = reinterpret_cast<float*>(smem + NPAN * (BN * 128));
+        const int C = p.K;
+        const int reps = p.xf_reps;
+        const float invM = 1.f / (float)p.M;
+        for (int c = tid; c < XKP; c += 256) {
+            float v_[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (c < C) {
+                float f_[2];
+#pragma unroll
+                for (int w_ = 0; w_ < 2; ++w_) {
+                    const long long* src_ = w_ ? p.xf_dbeta + c : p.xf_dgamma + c;
+                    long long acc_ = 0;
+                    bool bad = false;
+                    for (int rb_ = 0; rb_ < reps; rb_ += 8) {
+                        long long a[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) a[r] = src_[(long)(rb_ + r < reps ? rb_ + r : rb_) * 2 * C];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            acc_ += rb_ + r < reps ? a[r] : 0ll;
+                            bad = bad || fixg_bad(a[r]);
+                        }
+                    }
+                    f_[w_] = bad ? __builtin_nanf("") : from_fix_g(acc_);
+                }
+                const float mean = p.xf_save[c], inv = p.xf_save[C + c], g = p.xf_gamma[c];
+                v_[0] = g * inv; v_[1] = p.xf_beta[c] - mean * v_[0];
+                v_[2] = g * inv;
+                v_[4] = v_[2] * inv * (f_[0] * invM);
+                v_[3] = v_[2] * (f_[1] * invM) - v_[4] * mean;
+                if (blockIdx.x == 0 && p.xf_ggrad) { p.xf_ggrad[c] += f_[0]; p.xf_bgrad[c] += f_[1]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) xc[q * XKP + c] = v_[q];
+        }
+    }
     for (int u = tid; u < BN * NPAN * 8; u += 256) {
         const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
         const int l = L & 63;
@@ -452,10 +613,10 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     // are >= M, so it loads zeros, stores nothing and adds zeros to the statistics.
 #pragma unroll 1
     for (long u = 0; u < units; u += 2) {
-        load(A1, u + 1);
-        compute(A0, u, std::integral_constant<int, 0>{});
-        load(A0, u + 2);
-        compute(A1, u + 1, std::integral_constant<int, H - 1>{});
+        load(A1, X1, u + 1);
+        compute(A0, X0, u, std::integral_constant<int, 0>{});
+        load(A0, X0, u + 2);
+        compute(A1, X1, u + 1, std::integral_constant<int, H - 1>{});
     }
 
     if (p.stats) {
@@ -484,9 +645,9 @@ __global__ __launch_bounds__(256, 2) void igemm_stream_kernel(const IgemmArgs p,
     }
 }
 
-template <int BN, int H, int NKS, bool GATHER = false>
+template <int BN, int H, int NKS, bool GATHER = false, int XF = 0>
 void launch_stream(const IgemmArgs& a, hipStream_t stream) {
-    constexpr int RG = 128;
+    constexpr int RG = 128;                                    // rows per workgroup and row group, as in the kernel
     const int n_tiles = ep24_cdiv(a.N, BN);
     const long n_groups = (a.M + RG - 1) / RG;
     // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
@@ -495,8 +656,15 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;          // as in the kernel: all panels its K steps touch
     size_t lds = (size_t)NPAN * BN * 128;
     if (lds < 4096) lds = 4096;                                // the statistics fold: [4 waves][2][BN] floats
+    if (XF) lds = (size_t)NPAN * BN * 128 + (size_t)(XF == 3 ? 5 : 2) * H * 128 * sizeof(float);      // + the per-channel constants
+    if (XF && lds < 4096) lds = 4096;
     const dim3 grid((unsigned)(bpn * n_tiles));
-    if constexpr (GATHER) {
+    if constexpr (XF == 3) {                                   // the input gradient may be a second writer of its destination
+        if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
+    } else if constexpr (XF != 0) {
+        hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
+    } else if constexpr (GATHER) {
         if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false, true>), grid, dim3(256), lds, stream, a, (int)bpn);
         else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, true>), grid, dim3(256), lds, stream, a, (int)bpn);
     } else {
@@ -505,6 +673,16 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
         else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
     }
 }
+
+// the transformed-A forms (XF): which tile the plain kernel would take, N in ONE tile (every row of A is made exactly once)
+template <int XF>
+void launch_stream_xf(const IgemmArgs& a, hipStream_t stream) {               // K <= 128 (xf_shape_ok)
+    if (a.N > 64) { if (a.K > 64) launch_stream<128, 1, 4, false, XF>(a, stream); else launch_stream<128, 1, 2, false, XF>(a, stream); }
+    else          { if (a.K > 64) launch_stream<64, 1, 4, false, XF>(a, stream); else launch_stream<64, 1, 2, false, XF>(a, stream); }
+}
+
+// Shapes the transformed-A forms take: what the plain streaming kernel takes with K <= 128 (one K pass) and N in one tile.
+bool xf_shape_ok(long M, int K, int N) { return K > 0 && K % 8 == 0 && K <= 128 && N > 0 && N % 4 == 0 && N <= 128 && M > 0; }
 
 template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
@@ -841,6 +1019,82 @@ extern "C" int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const voi
     b.bnr_z = (const bf16*)z; b.bnr_ldz = ld_z; b.bnr_mean = mean; b.bnr_invstd = invstd; b.bnr_gamma = gamma; b.bnr_beta = beta;
     b.bnr_dgamma = (long long*)dgamma; b.bnr_dbeta = (long long*)dbeta; b.bnr_rep_stride = rep_stride; b.bnr_reps = reps; b.bnr_act = act;
     return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, 0, B, H, W, Cin, Cout_k, ksize, 1, 0, stream, false, nullptr, &b);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A 1x1 stride-1 conv unit together with the BatchNorm pass in front of it (igemm_stream_kernel<XF>, round 5).
+extern "C" int ep24_conv1x1_xf_ok(int B, int H, int W, int Cin, int Cout) { return xf_shape_ok((long)B * H * W, Cin, Cout) ? 1 : 0; }
+
+// Forward: y_in = silu(bn(z_in)) (+ residual) exactly as ep24_bn_act_fwd (same statistics fold, save / running statistics / counters
+// by block 0), and z_out = conv1x1(y_in, w) with its batch statistics exactly as ep24_conv_fwd_bf16 - one launch.
+extern "C" int ep24_conv1x1_bnin_bf16(const void* z_in, int64_t ld_zin, const int64_t* stats_in, int reps_in, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                                      int64_t* num_batches2, float* save, void* y_in, int64_t ld_yin, const void* residual,
+                                      int64_t ld_res, float eps, float momentum, int act, const void* w, void* z_out, int64_t ld_zout,
+                                      int64_t* stats_out, int reps_out, int B, int H, int W, int Cin, int Cout, void* stream) {
+    EP24_REQUIRE(z_in && stats_in && gamma && beta && save && y_in && w && z_out, EP24_E_ARG, "conv1x1_bnin: null pointer");
+    EP24_REQUIRE(act == 1, EP24_E_UNSUPPORTED, "conv1x1_bnin: SiLU units only (act = %d)", act);
+    const long M = (long)B * H * W;
+    EP24_REQUIRE(xf_shape_ok(M, Cin, Cout), EP24_E_UNSUPPORTED, "conv1x1_bnin: Cin=%d Cout=%d is not a shape of the transformed-A kernel (Cin, Cout <= 128)", Cin, Cout);
+    EP24_REQUIRE(ld_zin % 8 == 0 && ld_yin % 8 == 0 && (!residual || ld_res % 8 == 0) && ld_zout % 4 == 0, EP24_E_ARG, "conv1x1_bnin: row stride alignment");
+    EP24_REQUIRE(reps_in > 0 && (!stats_out || reps_out > 0), EP24_E_ARG, "conv1x1_bnin: replicas");
+    EP24_REQUIRE(((reinterpret_cast<uintptr_t>(z_in) | reinterpret_cast<uintptr_t>(y_in) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0, EP24_E_ARG,
+                 "conv1x1_bnin: rows are moved 16 bytes at a time (16-byte aligned bases)");
+    IgemmArgs a{};
+    a.src = (const bf16*)z_in; a.ld_src = ld_zin; a.B = B; a.SH = H; a.SW = W; a.GH = H; a.GW = W; a.sy = a.sx = 1;
+    a.T = 1; a.oy[0] = a.ox[0] = 0; a.wslot[0] = 0;
+    a.wt = (const bf16*)w; a.WT = 1; a.K = Cin; a.N = Cout;
+    a.dst = z_out; a.ld_dst = ld_zout; a.DH = H; a.DW = W; a.dsy = a.dsx = 1; a.dbs = (long)H * W;
+    a.stats = (long long*)stats_out; a.stats_replicas = stats_out ? reps_out : 1;
+    a.M = M;
+    if (int rc = check_extents(a)) return rc;
+    prepare(a, 0);
+    const long dst_b = ((M - 1) * ld_zout + Cout) * 2, y_b = ((M - 1) * ld_yin + Cin) * 2, r_b = residual ? ((M - 1) * ld_res + Cin) * 2 : 0;
+    EP24_REQUIRE(dst_b < 0x7FFF0000L && y_b < 0x7FFF0000L && r_b < 0x7FFF0000L, EP24_E_UNSUPPORTED, "conv1x1_bnin: an operand beyond 2 GiB: split the batch");
+    a.dst_bytes = (unsigned)dst_b;
+    a.xf_aux = (const bf16*)residual; a.xf_ldaux = ld_res; a.xf_aux_bytes = (unsigned)r_b;
+    a.xf_out = (bf16*)y_in; a.xf_ldout = ld_yin; a.xf_out_bytes = (unsigned)y_b;
+    a.xf_stats = (const long long*)stats_in; a.xf_reps = reps_in; a.xf_gamma = gamma; a.xf_beta = beta; a.xf_eps = eps; a.xf_momentum = momentum;
+    a.xf_rmean = running_mean; a.xf_rvar = running_var; a.xf_nbt = (long*)num_batches; a.xf_nbt2 = (long*)num_batches2; a.xf_save = save;
+    if (residual) launch_stream_xf<2>(a, (hipStream_t)stream);
+    else launch_stream_xf<1>(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_conv1x1_bnin_bf16");
+    return EP24_OK;
+}
+
+// Backward: dz = ep24_bn_act_bwd_apply(dy, z, ...) (stored: the weight gradient reads it; block 0 publishes the two sums into the
+// parameter gradients) and dx (+)= dz . wt as ep24_conv_dgrad_bf16 of the unit's 1x1 conv - one launch.  Cin / Cout_k as there.
+extern "C" int ep24_conv1x1_dgrad_bnbwd_bf16(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                                             const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                                             float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int act, int reps,
+                                             const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin,
+                                             int Cout_k, void* stream) {
+    EP24_REQUIRE(dy && z && save && gamma && beta && dgamma && dbeta && dz && wt && dx && reps > 0, EP24_E_ARG, "conv1x1_dgrad_bnbwd: null pointer / reps");
+    EP24_REQUIRE(act == 1, EP24_E_UNSUPPORTED, "conv1x1_dgrad_bnbwd: SiLU units only (act = %d)", act);
+    const long M = (long)B * H * W;
+    EP24_REQUIRE(xf_shape_ok(M, Cout_k, Cin), EP24_E_UNSUPPORTED, "conv1x1_dgrad_bnbwd: Cout=%d Cin=%d is not a shape of the transformed-A kernel (both <= 128)", Cout_k, Cin);
+    EP24_REQUIRE(ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_dz % 8 == 0 && ld_dx % 4 == 0, EP24_E_ARG, "conv1x1_dgrad_bnbwd: row stride alignment");
+    EP24_REQUIRE(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0, EP24_E_ARG,
+                 "conv1x1_dgrad_bnbwd: rows are moved 16 bytes at a time (16-byte aligned bases)");
+    IgemmArgs a{};
+    a.src = (const bf16*)dy; a.ld_src = ld_dy; a.B = B; a.SH = H; a.SW = W; a.GH = H; a.GW = W; a.sy = a.sx = 1;
+    a.T = 1; a.oy[0] = a.ox[0] = 0; a.wslot[0] = 0;
+    a.wt = (const bf16*)wt; a.WT = 1; a.K = Cout_k; a.N = Cin;
+    a.dst = dx; a.ld_dst = ld_dx; a.DH = H; a.DW = W; a.dsy = a.dsx = 1; a.dbs = (long)H * W;
+    a.accumulate = accumulate; a.stats = nullptr; a.stats_replicas = 1;
+    a.M = M;
+    if (int rc = check_extents(a)) return rc;
+    prepare(a, 0);
+    const long dst_b = ((M - 1) * ld_dx + Cin) * 2, z_b = ((M - 1) * ld_z + Cout_k) * 2, dz_b = ((M - 1) * ld_dz + Cout_k) * 2;
+    EP24_REQUIRE(dst_b < 0x7FFF0000L && z_b < 0x7FFF0000L && dz_b < 0x7FFF0000L, EP24_E_UNSUPPORTED, "conv1x1_dgrad_bnbwd: an operand beyond 2 GiB: split the batch");
+    a.dst_bytes = (unsigned)dst_b;
+    a.xf_aux = (const bf16*)z; a.xf_ldaux = ld_z; a.xf_aux_bytes = (unsigned)z_b;
+    a.xf_out = (bf16*)dz; a.xf_ldout = ld_dz; a.xf_out_bytes = (unsigned)dz_b;
+    a.xf_reps = reps; a.xf_gamma = gamma; a.xf_beta = beta; a.xf_save = const_cast<float*>(save);
+    a.xf_dgamma = (const long long*)dgamma; a.xf_dbeta = (const long long*)dbeta; a.xf_ggrad = gamma_grad; a.xf_bgrad = beta_grad;
+    launch_stream_xf<3>(a, (hipStream_t)stream);
+    EP24_LAUNCH_CHECK("ep24_conv1x1_dgrad_bnbwd_bf16");
+    return EP24_OK;
 }
 
 static int kernel_for_impl(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias, int kernel_opts);

@@ -33,6 +33,19 @@ struct IgemmArgs {
     // kernel read dy and z once more for them.  [reps][..] fixed-point sums, replica stride bnr_rep_stride, as bn_act_bwd_reduce.
     const bf16* bnr_z; long bnr_ldz; const float* bnr_mean; const float* bnr_invstd; const float* bnr_gamma; const float* bnr_beta;
     long long* bnr_dgamma; long long* bnr_dbeta; long bnr_rep_stride; int bnr_reps; int bnr_act;
+    // Streaming 1x1 kernel with a TRANSFORMED A operand (igemm_stream_kernel<XF>, round 5): the rows it multiplies are not stored yet.
+    // It makes them from what the BatchNorm pass in front of it would have read, stores them where that pass would have, and multiplies
+    // them - one dependent launch and one read of the rows less, the same values bit for bit.
+    //   forward  (XF 1, 2): src = z of the producing unit, A = y = silu(bn(z)) (+ residual rows xf_aux); xf_out receives y; block 0
+    //                       does what bn_act_fwd's block 0 does (save, running statistics, num_batches)
+    //   backward (XF 3):    src = dy of this unit, xf_aux = its z, A = dz of bn_act_bwd_apply; xf_out receives dz (the weight gradient
+    //                       reads it); block 0 publishes the two sums into the parameter gradients
+    const bf16* xf_aux; long xf_ldaux; unsigned xf_aux_bytes;
+    bf16* xf_out; long xf_ldout; unsigned xf_out_bytes;
+    const long long* xf_stats; int xf_reps;                   // forward: [reps][2][K] 2^-20 sums; backward: reps of the two 2^-36 sums
+    const float* xf_gamma; const float* xf_beta; float xf_eps, xf_momentum;
+    float* xf_rmean; float* xf_rvar; long* xf_nbt; long* xf_nbt2; float* xf_save;
+    const long long* xf_dgamma; const long long* xf_dbeta; float* xf_ggrad; float* xf_bgrad;
 };
 
 constexpr int BM = 128;

@@ -924,7 +924,7 @@ class Engine:
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
-    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False):
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False, bn_in=False):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
         name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none).  ``x_single``: the
         caller states that this unit is the only consumer of ``x`` (a Bottleneck's 3x3 over its 1x1): its input gradient IS the
@@ -978,17 +978,32 @@ class Engine:
             ev_conv = ("stem_conv_fwd_bf16", (x.ptr(), wf, seg.cin_pad, z.ptr(), z.ld, None, 1, B, H, W, cout))
         else:
             ev_conv = ("conv_fwd_bf16", (x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, None, 1, B, H, W, cin, cout, k, s))
-        if focus:
+        xf_ok = (not stem and k == 1 and s == 1 and act == 1 and cout % 8 == 0 and
+                 _lib.lib().fn["ep24_conv1x1_xf_ok"](B, H, W, cin, cout) == 1)       # a shape of the transformed-A streaming kernel
+        prev = getattr(x, "_bnf", None) if bn_in and self.options.fuse_bn_stream and xf_ok else None
+        if prev is not None and prev[0] == len(self.fwd) - 1 and self.fwd[-1][0] == "bn_act_fwd" and prev[1][-1] == 1:
+            # The BatchNorm pass that produced x is the launch just before this one and this unit streams x through registers: it makes
+            # x itself (same expressions, same stored bytes) - the pass leaves the training list; the eval list keeps its own entries.
+            (pz, pldz, pstats, preps, pgam, pbet, prm, prv, pnbt, pnbt2, psave, py, pldy, pres, pldres, pM, pC, peps, pmom, _pact) = prev[1]
+            assert (py, pldy, pM, pC) == (x.ptr(), x.ld, M, cin)
+            self.fwd.pop()
+            self.fwd.append(("conv1x1_bnin_bf16", (pz, pldz, pstats, preps, pgam, pbet, prm, prv, pnbt, pnbt2, psave, py, pldy, pres, pldres,
+                                                   peps, pmom, 1, wf, z.ptr(), z.ld, stats, STATS_REPLICAS, B, H, W, cin, cout)))
+            self.fwd_eval.append(ev_conv)
+            self.n_bnin = getattr(self, "n_bnin", 0) + 1
+        elif focus:
             self._f("stem_conv_fwd_bf16", x.ptr(), wf, seg.cin_pad, z.ptr(), z.ld, stats, STATS_REPLICAS, B, H, W, cout, ev=ev_conv)
         else:
             self._f("conv_fwd_bf16", x.ptr(), x.ld, wf, z.ptr(), z.ld, 0, 0, 0, None, stats, STATS_REPLICAS, B, H, W, cin, cout, k, s, ev=ev_conv)
-        self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
-                ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
-                ptr(bn2.num_batches_tracked) if bn2 is not None else None, ptr(save), out.ptr(), out.ld,
-                res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), act,
+        bn_args = (z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off),
+                   ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                   ptr(bn2.num_batches_tracked) if bn2 is not None else None, ptr(save), out.ptr(), out.ld,
+                   res_p, res_ld, M, cout, float(bn.eps), float(bn.momentum), act)
+        self._f("bn_act_fwd", *bn_args,
                 ev=False if self.fold_bn_eval else
                 ("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
                                   ptr(bn.running_var), out.ptr(), out.ld, res_p, res_ld, M, cout, float(bn.eps), act)))
+        out._bnf = (len(self.fwd) - 1, bn_args)        # where this output's BatchNorm pass sits (a consumer with bn_in may absorb it)
         if residual is not None:
             residual.alias_grad(out)
         self.unit_acts[mod if mod is not None else conv] = (x, z, out)
@@ -1004,6 +1019,7 @@ class Engine:
             assert out.gready(), "activation without a gradient producer"
             k = self._bwd_units                       # position in backward execution order
             self._bwd_units += 1
+            dgrad_done = False
             dzoff = self._dz_elems
             self._dz_elems += M * cout
             dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
@@ -1016,9 +1032,19 @@ class Engine:
                 if not info["fused"]:                 # else: the consumer's input-gradient epilogue has produced the two sums
                     self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
                                                   ptr(flat, bet.off), sum_g, sum_b, M, cout, act, STATS_REPLICAS), reads=out)
-                self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
-                                             ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
-                                             dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet), reads=out if info["fused"] else None)
+                # The apply pass and the input gradient of a 1x1 unit of the streaming kernel as ONE launch (PlanOptions.fuse_bn_dgrad,
+                # ep24_conv1x1_dgrad_bnbwd_bf16): dz is made on the way to the MFMAs and stored for the weight gradient.
+                if xf_ok and self.options.fuse_bn_dgrad and x.needs_grad and not info["fused"] and seg.cout_pad == cout:
+                    acc = x.gwrite()
+                    self._b("conv1x1_dgrad_bnbwd_bf16", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off),
+                                                          sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off), dz, cout, act, STATS_REPLICAS,
+                                                          ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin, cout), writes=(gam, bet))
+                    self.n_bnbwd = getattr(self, "n_bnbwd", 0) + 1
+                    dgrad_done = True
+                else:
+                    self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off),
+                                                 ptr(flat, bet.off), sum_g, sum_b, ptr(gflat, gam.off), ptr(gflat, bet.off),
+                                                 dz, cout, M, cout, act, STATS_REPLICAS), writes=(gam, bet), reads=out if info["fused"] else None)
             # weight gradient on the side stream: it only needs dz and the saved input, and nothing on the main
             # stream needs its result before the optimizer, so it overlaps the dgrad and the next layer's BN passes
             # partial sums of the pixel splits go to this layer's slab slice with plain stores; a reduce launch every
@@ -1056,7 +1082,7 @@ class Engine:
                 self._deferred.append(emit_wgrad)
             else:
                 emit_wgrad()
-            if x.needs_grad:
+            if x.needs_grad and not dgrad_done:
                 acc = x.gwrite()
                 below = getattr(x, "bn_info", None) if x_single else None
                 if (below is not None and not acc and k_ == 3 and s == 1 and self.options.fuse_bn_reduce and x._alias is None and
@@ -1121,7 +1147,7 @@ class Engine:
         self.unit(mod.conv2, x, out=cat.slice(h, h))
         for i, blk in enumerate(mod.m):
             last = i == n - 1
-            u = self.unit(blk.conv1, t)
+            u = self.unit(blk.conv1, t, bn_in=i > 0)
             t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, cat, out=out)
 
@@ -1388,7 +1414,7 @@ class Engine:
 
             self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
-            u = self.unit(blk.conv1, t)
+            u = self.unit(blk.conv1, t, bn_in=i > 0)
             t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 

@@ -30,6 +30,9 @@ class PlanOptions:
                                        # BatchNorm-backward sums in its epilogue (no reduce launch for it).  Measured slower in the step
                                        # (899 against 912 images/s, same box): kept for A/B runs only
     fuse_bn_bwd: bool = False          # the two BatchNorm-backward passes of a trunk unit as ONE launch with a grid-wide wait (round 5, A/B)
+    fuse_bn_stream: bool = True        # forward: a Bottleneck's first conv, when it is a 1x1 unit of the streaming kernel (Cin, Cout <= 128), makes its
+                                       # input from the previous Bottleneck's raw output - no BatchNorm launch in front of it (round 5)
+    fuse_bn_dgrad: bool = True         # backward: the input gradient of such a 1x1 unit makes dz itself - no BatchNorm-backward apply launch (round 5)
     fuse_loss_decode: bool = True      # TrainStep: loss gradient and the head's decode backward in one pass (round 5; not with the L1 branch)
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane

@@ -192,6 +192,28 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           int reps, void* stream);
 
+/* A 1x1 stride-1 conv unit TOGETHER WITH the BatchNorm pass in front of it (round 5; csrc/conv_igemm.hip igemm_stream_kernel<XF>).
+ * The streaming 1x1 kernel is the one conv kernel whose A operand passes through registers, so the pass that would have produced
+ * that operand as a launch of its own runs on the rows in flight: one dependent launch and one read of the rows less, the same
+ * values bit for bit (the rows the MFMAs read are the bf16 values that are stored).  Shapes: Cin, Cout <= 128 (one K pass, one N
+ * tile); ep24_conv1x1_xf_ok says whether a shape is taken.  SiLU units only (act = 1).
+ *   ep24_conv1x1_bnin_bf16: y_in = silu(bn(z_in)) (+ residual) exactly as ep24_bn_act_fwd (statistics fold, save, running
+ *     statistics, counters), then z_out = conv1x1(y_in, w) with its batch statistics exactly as ep24_conv_fwd_bf16
+ *     (network_blocks.py:50-51 of the producing unit and :38-48 of this one; Bottleneck.forward :95-99).
+ *   ep24_conv1x1_dgrad_bnbwd_bf16: dz = ep24_bn_act_bwd_apply(dy, z, ...) - stored, the weight gradient reads it; the sums are
+ *     published into gamma_grad / beta_grad - then dx (+)= dz . wt exactly as ep24_conv_dgrad_bf16 of the unit's 1x1 conv
+ *     (Cin / Cout_k as there: the forward conv's input channels / its output channels padded to 8). */
+int ep24_conv1x1_xf_ok(int B, int H, int W, int Cin, int Cout);
+int ep24_conv1x1_bnin_bf16(const void* z_in, int64_t ld_zin, const int64_t* stats_in, int reps_in, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                           int64_t* num_batches2, float* save, void* y_in, int64_t ld_yin, const void* residual, int64_t ld_res,
+                           float eps, float momentum, int act, const void* w, void* z_out, int64_t ld_zout, int64_t* stats_out,
+                           int reps_out, int B, int H, int W, int Cin, int Cout, void* stream);
+int ep24_conv1x1_dgrad_bnbwd_bf16(const void* dy, int64_t ld_dy, const void* z, int64_t ld_z, const float* save,
+                                  const float* gamma, const float* beta, const int64_t* dgamma, const int64_t* dbeta,
+                                  float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int act, int reps, const void* wt,
+                                  void* dx, int64_t ld_dx, int accumulate, int B, int H, int W, int Cin, int Cout_k, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * fp32 PARITY MODE of the conv graph (csrc/f32path.hip).  The reference trains in fp32 (train_24p.py:86-104: no AMP,
  * network_blocks.py:50-51); ep24.engine.Engine(dtype=torch.float32) runs the same launch plan on fp32 activations through

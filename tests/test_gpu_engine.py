@@ -468,6 +468,40 @@ def test_fused_bn_reduce_plan_matches_the_default_plan():
     assert la2 == la and torch.equal(ga2, ga)
 
 
+def test_fuse_bn_stream_plan_is_bit_identical_to_the_unfused_plan():
+    """PlanOptions.fuse_bn_stream / fuse_bn_dgrad (default, round 5): a Bottleneck's 1x1 conv of the streaming kernel makes its input from the previous
+    Bottleneck's raw output instead of a BatchNorm launch in front of it, and its input gradient makes dz instead of an apply launch.
+    Same expressions on the same bytes: three training steps must leave every loss, parameter, momentum value and BatchNorm buffer
+    BIT-identical to the plan with the separate launches, and the eval-mode forward must not change either."""
+    from ep24 import loss as eloss, nn as enn, train as etrain
+    from ep24.options import PlanOptions, set_options
+
+    def run(plan):
+        torch.manual_seed(0)
+        m = enn.YOLOX(enn.YOLOPAFPN(0.67, 0.25), enn.YOLOXHead(80, 0.25)).to(DEV)      # two Bottlenecks per CSP layer, six in dark3 / dark4
+        m.head.initialize_biases(1e-2)
+        set_options(m, PlanOptions.parse(plan))
+        ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.01, momentum=0.9, batch=4, size=256)
+        ts.eng.images.copy_(synth.make_images(4, 256, seed=1).to(DEV))
+        ts.labels.copy_(synth.make_labels(4, 3, size=256, seed=1000).to(DEV))
+        losses = [float(ts.step()[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        fwd, bwd = [n for n, _ in ts.eng.fwd], [n for n, _ in ts.eng.bwd]
+        bufs = {k: v.clone() for k, v in m.state_dict().items()}
+        return losses, ts.home.flat.clone(), ts.home.mflat.clone(), bufs, fwd, bwd, len(ts.eng.fwd_eval)
+
+    la, wa, ma, ba, fa, bwa, ea = run("")
+    lb, wb, mb, bb, fb, bwb, eb = run("fuse_bn_stream=0,fuse_bn_dgrad=0")
+    n_f, n_b = sum(n == "conv1x1_bnin_bf16" for n in fa), sum(n.endswith("conv1x1_dgrad_bnbwd_bf16") for n in bwa)
+    assert n_f >= 8 and n_b >= 12, (n_f, n_b)                               # the default plan really took the fused launches ...
+    assert not any("conv1x1_" in n for n in fb + bwb)                       # ... and the other plan none
+    launches = lambda lst: sum(n[0] != "@" for n in lst)                    # (lane hand-offs are not launches)
+    assert len(fa) == len(fb) - n_f and launches(bwa) == launches(bwb) - n_b and ea == eb, (len(fa), len(fb), n_f, launches(bwa), launches(bwb), n_b)
+    assert la == lb and all(np.isfinite(la)) and la[0] != la[2]
+    assert torch.equal(wa, wb) and torch.equal(ma, mb)
+    assert ba.keys() == bb.keys() and all(torch.equal(ba[k], bb[k]) for k in ba), [k for k in ba if not torch.equal(ba[k], bb[k])][:5]
+
+
 def test_full_size_step_properties():
     """BASELINE config 2 itself (YOLOX-l-24p, B = 20, 640x640) through size-independent properties: (1) two training
     runs from the same state are bitwise identical - loss AND every parameter after 3 steps (fixed-point BN sums,
