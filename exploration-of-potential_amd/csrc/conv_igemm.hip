@@ -590,21 +590,47 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
             for (int q = 0; q < 5; ++q) xc[q * XKP + c] = v_[q];
         }
     }
-    for (int u = tid; u < BN * NPAN * 8; u += 256) {
-        const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
-        const int l = L & 63;
-        const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
-        const int k = pan * 64 + chunk * 8;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if constexpr (GATHER) {                     // K index tap * 16 + c of the tile <- column tap * 12 + c of the weight row
+    // The weight tile [BN][K] -> LDS.  Every 16-byte chunk of a thread is REQUESTED before the first is written: as a loop of
+    // "load, wait, ds_write" (what `for (u = tid; ...; u += 256) { v = ...; lds = v; }` compiles to) this was BN * NPAN / 32 serial round
+    // trips to L2 at the head of every launch - 8 for a 128 x 128 tile, 16 for K = 256: most of the kernel's fixed ~8 us (round 5).
+    // Buffer loads, so that a channel >= N or a chunk >= K is an out-of-range offset (zeros) instead of a branch round the load.
+    if constexpr (GATHER) {
+        for (int u = tid; u < BN * NPAN * 8; u += 256) {
+            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+            const int l = L & 63;
+            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
+            const int k = pan * 64 + chunk * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            // K index tap * 16 + c of the tile <- column tap * 12 + c of the weight row
             const int tap = k >> 4, c0 = k & 15;
             if (ch < p.N && tap < 9) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (c0 + e < 12) v[e] = p.wt[(long)ch * p.K + tap * 12 + c0 + e];
             }
-        } else if (ch < p.N && k < p.K) v = *reinterpret_cast<const bf16x8*>(p.wt + (long)ch * p.WT * p.K + k);
-        *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
+            *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
+        }
+    } else {
+        constexpr int NWT = BN * NPAN * 8 / 256;            // chunks per thread (BN * NPAN * 8 is a multiple of 256)
+        static_assert(NWT * 256 == BN * NPAN * 8, "weight tile chunks");
+        const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+        v4i wv[NWT];
+#pragma unroll
+        for (int it = 0; it < NWT; ++it) {
+            const int u = it * 256 + tid;
+            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+            const int l = L & 63;
+            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
+            const int k = pan * 64 + chunk * 8;
+            const int wo = (ch < p.N && k < p.K) ? (int)(((long)ch * p.WT * p.K + k) * 2) : OOB;
+            wv[it] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NWT; ++it) {
+            const int u = it * 256 + tid;
+            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+            *reinterpret_cast<v4i*>(smem + pan * (BN * 128) + swz(L, chunk)) = wv[it];
+        }
     }
     __syncthreads();
 
