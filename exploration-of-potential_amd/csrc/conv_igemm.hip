@@ -501,6 +501,43 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
     load(A0, X0, 0);
     constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;       // every 64-channel panel the K steps of the loop read (zeros past K)
     static_assert(NPAN == NPAN_, "panels");
+    // The weight tile [BN][K] -> LDS.  Every 16-byte chunk of a thread is REQUESTED before the first is written: as a loop of
+    // "load, wait, ds_write" (what `for (u = tid; ...; u += 256) { v = ...; lds = v; }` compiles to) this was BN * NPAN / 32 serial round
+    // trips to L2 at the head of every launch - 8 for a 128 x 128 tile, 16 for K = 256: most of the kernel's fixed ~8 us (round 5).
+    // Buffer loads, so that a channel >= N or a chunk >= K is an out-of-range offset (zeros) instead of a branch round the load.
+    // The transformed-A forms fold their per-channel constants between the request and the writes: one round trip for all of it.
+    constexpr int NWT = GATHER ? 1 : BN * NPAN * 8 / 256;   // chunks per thread (BN * NPAN * 8 is a multiple of 256)
+    static_assert(GATHER || NWT * 256 == BN * NPAN * 8, "weight tile chunks");
+    [[maybe_unused]] v4i wv[NWT];
+    if constexpr (GATHER) {
+        for (int u = tid; u < BN * NPAN * 8; u += 256) {
+            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+            const int l = L & 63;
+            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
+            const int k = pan * 64 + chunk * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            // K index tap * 16 + c of the tile <- column tap * 12 + c of the weight row
+            const int tap = k >> 4, c0 = k & 15;
+            if (ch < p.N && tap < 9) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < 12) v[e] = p.wt[(long)ch * p.K + tap * 12 + c0 + e];
+            }
+            *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
+        }
+    } else {
+        const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NWT; ++it) {
+            const int u = it * 256 + tid;
+            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
+            const int l = L & 63;
+            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
+            const int k = pan * 64 + chunk * 8;
+            const int wo = (ch < p.N && k < p.K) ? (int)(((long)ch * p.WT * p.K + k) * 2) : OOB;
+            wv[it] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
+        }
+    }
     if constexpr (XF == 1 || XF == 2) {
         // bn_act_fwd_kernel's prologue: the producer's fixed-point statistics -> scale / shift per channel; block 0 keeps mean and
         // invstd for the backward and updates the running statistics
@@ -538,8 +575,9 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
                     p.xf_save[C + c] = invstd;
                     if (p.xf_rmean) {
                         const float unb = p.M > 1 ? var * (float)p.M / (float)(p.M - 1) : var;
-                        p.xf_rmean[c] = (1.f - p.xf_momentum) * p.xf_rmean[c] + p.xf_momentum * mean;
-                        p.xf_rvar[c] = (1.f - p.xf_momentum) * p.xf_rvar[c] + p.xf_momentum * unb;
+                        const float om = p.xf_rmean[c], ov = p.xf_rvar[c];
+                        p.xf_rmean[c] = (1.f - p.xf_momentum) * om + p.xf_momentum * mean;
+                        p.xf_rvar[c] = (1.f - p.xf_momentum) * ov + p.xf_momentum * unb;
                     }
                 }
             }
@@ -562,69 +600,39 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
             float v_[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             if (c < C) {
                 float f_[2];
+                const float mean = p.xf_save[c], inv = p.xf_save[C + c], g = p.xf_gamma[c], bt_ = p.xf_beta[c];     // requested with the sums
+                long long acc_[2] = {0, 0};
+                int bad_[2] = {0, 0};                        // (no short-circuit: a branch per replica word kept the two sums' loads apart)
+                for (int rb_ = 0; rb_ < reps; rb_ += 8) {    // both sums' replica words of a batch are requested together
+                    long long a[2][8];
 #pragma unroll
-                for (int w_ = 0; w_ < 2; ++w_) {
-                    const long long* src_ = w_ ? p.xf_dbeta + c : p.xf_dgamma + c;
-                    long long acc_ = 0;
-                    bool bad = false;
-                    for (int rb_ = 0; rb_ < reps; rb_ += 8) {
-                        long long a[8];
+                    for (int w_ = 0; w_ < 2; ++w_)
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) a[r] = src_[(long)(rb_ + r < reps ? rb_ + r : rb_) * 2 * C];
+                        for (int r = 0; r < 8; ++r) a[w_][r] = (w_ ? p.xf_dbeta + c : p.xf_dgamma + c)[(long)(rb_ + r < reps ? rb_ + r : rb_) * 2 * C];
+#pragma unroll
+                    for (int w_ = 0; w_ < 2; ++w_)
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            acc_ += rb_ + r < reps ? a[r] : 0ll;
-                            bad = bad || fixg_bad(a[r]);
+                            acc_[w_] += rb_ + r < reps ? a[w_][r] : 0ll;
+                            bad_[w_] |= (int)fixg_bad(a[w_][r]);
                         }
-                    }
-                    f_[w_] = bad ? __builtin_nanf("") : from_fix_g(acc_);
                 }
-                const float mean = p.xf_save[c], inv = p.xf_save[C + c], g = p.xf_gamma[c];
-                v_[0] = g * inv; v_[1] = p.xf_beta[c] - mean * v_[0];
+#pragma unroll
+                for (int w_ = 0; w_ < 2; ++w_) f_[w_] = bad_[w_] ? __builtin_nanf("") : from_fix_g(acc_[w_]);
+                v_[0] = g * inv; v_[1] = bt_ - mean * v_[0];
                 v_[2] = g * inv;
                 v_[4] = v_[2] * inv * (f_[0] * invM);
                 v_[3] = v_[2] * (f_[1] * invM) - v_[4] * mean;
-                if (blockIdx.x == 0 && p.xf_ggrad) { p.xf_ggrad[c] += f_[0]; p.xf_bgrad[c] += f_[1]; }
+                if (blockIdx.x == 0 && p.xf_ggrad) {        // both old values requested before either is written
+                    const float og = p.xf_ggrad[c], ob = p.xf_bgrad[c];
+                    p.xf_ggrad[c] = og + f_[0]; p.xf_bgrad[c] = ob + f_[1];
+                }
             }
 #pragma unroll
             for (int q = 0; q < 5; ++q) xc[q * XKP + c] = v_[q];
         }
     }
-    // The weight tile [BN][K] -> LDS.  Every 16-byte chunk of a thread is REQUESTED before the first is written: as a loop of
-    // "load, wait, ds_write" (what `for (u = tid; ...; u += 256) { v = ...; lds = v; }` compiles to) this was BN * NPAN / 32 serial round
-    // trips to L2 at the head of every launch - 8 for a 128 x 128 tile, 16 for K = 256: most of the kernel's fixed ~8 us (round 5).
-    // Buffer loads, so that a channel >= N or a chunk >= K is an out-of-range offset (zeros) instead of a branch round the load.
-    if constexpr (GATHER) {
-        for (int u = tid; u < BN * NPAN * 8; u += 256) {
-            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
-            const int l = L & 63;
-            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
-            const int k = pan * 64 + chunk * 8;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            // K index tap * 16 + c of the tile <- column tap * 12 + c of the weight row
-            const int tap = k >> 4, c0 = k & 15;
-            if (ch < p.N && tap < 9) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e < 12) v[e] = p.wt[(long)ch * p.K + tap * 12 + c0 + e];
-            }
-            *reinterpret_cast<bf16x8*>(smem + pan * (BN * 128) + swz(L, chunk)) = v;
-        }
-    } else {
-        constexpr int NWT = BN * NPAN * 8 / 256;            // chunks per thread (BN * NPAN * 8 is a multiple of 256)
-        static_assert(NWT * 256 == BN * NPAN * 8, "weight tile chunks");
-        const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
-        v4i wv[NWT];
-#pragma unroll
-        for (int it = 0; it < NWT; ++it) {
-            const int u = it * 256 + tid;
-            const int chunk = u & 7, L = (u >> 3) % BN, pan = (u >> 3) / BN;
-            const int l = L & 63;
-            const int ch = n0 + (L & ~63) + 4 * (l & 15) + (l >> 4);          // channel relabelling of the epilogue
-            const int k = pan * 64 + chunk * 8;
-            const int wo = (ch < p.N && k < p.K) ? (int)(((long)ch * p.WT * p.K + k) * 2) : OOB;
-            wv[it] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
-        }
+    if constexpr (!GATHER) {
 #pragma unroll
         for (int it = 0; it < NWT; ++it) {
             const int u = it * 256 + tid;
