@@ -24,6 +24,8 @@ constexpr int KOPT_RING32 = 32;            // bit 5: the ring's consumers multip
                                            // cycles per step, a 9 % lower clock under load - slower in the step, profiles/r04_ring_ab.txt)
 constexpr int KOPT_NARROW = 64;            // bit 6: A/B option - 3x3 stride-1 layers in the ring with the NARROW tile (256 x 64; also the 20 x 20 level and N = 64)
 constexpr int KOPT_NO_DEEP = 128;          // bit 7: A/B option - no three-stage form of the tiled kernel (the 20 x 20 level runs in 64-wide two-stage tiles, as before round 4)
+constexpr int KOPT_TILED256 = 256;         // bit 8: A/B option - 1x1 stride-1 layers with 128 < K <= 256 and M < 100 000 in the tiled kernel, as before the streaming
+                                           // kernel's weight tile was requested in one batch (round 5: since then it wins there too, profiles/r05_xf_ab.txt)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -782,7 +784,7 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
                      a.bnr_ldz % 8 == 0 && ((reinterpret_cast<unsigned long long>(a.dst) | reinterpret_cast<unsigned long long>(a.bnr_z)) & 15) == 0 &&
                      a.bnr_reps > 0, EP24_E_ARG, "conv_dgrad_bnr: needs a plain, first-writer bf16 destination with channel counts / strides in multiples of 8");
     }
-    if (!a.bnr_z && a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && a.M >= 100000)) && !out_f32 &&
+    if (!a.bnr_z && a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && (a.M >= 100000 || !(kernel_opts & KOPT_TILED256)))) && !out_f32 &&
         (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L) {
         if (dry) { *kernel_id = 2; return EP24_OK; }
         a.dst_bytes = (unsigned)dst_b;

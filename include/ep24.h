@@ -69,7 +69,9 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * which the 256 x 128 ring does not take (bit-identical results; measured slower than the tiled kernel it would replace: an A/B
  * option); bit 7: the tiled kernel without its three-stage form (round 4: layers whose 128-wide tiles leave at most one workgroup per
  * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
- * two-stage tiles as before; bit-identical results).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * two-stage tiles as before; bit-identical results); bit 8: 1x1 stride-1 layers with 128 < K <= 256 and fewer than 100 000 pixels run
+ * in the tiled kernel, as they did before the streaming kernel's weight tile was requested in one batch (round 5: the streaming kernel
+ * is the default for every 1x1 stride-1 layer with K <= 256 now).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 /* Round 5: bits 4, 5 and 6 (and bit 0 of the weight gradient's kernel_opts) select variants that were built, measured and lost in
  * rounds 3 - 4; they left the product library, which answers EP24_E_UNSUPPORTED for them.  `make -C csrc variants` builds

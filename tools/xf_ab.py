@@ -91,4 +91,5 @@ def main():
             print("bwd  %d,%d,%d->%d acc=%d : apply %.1f + dgrad %.1f = %.1f (back to back %.1f) | fused %.1f" % (B, H, Cin, Cout, acc, t_ap, t_dg, t_ap + t_dg, t_both, t_f), flush=True)
 
 
-main()
+if __name__ == "__main__":
+    main()
