@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--fisheye", action="store_true", help="non-default: BASELINE config 5 - every step first warps its uint8 source images "
                     "(and masks) with the sector warp on the GPU and letterboxes the results into the network input")
     ap.add_argument("--backbone", default="darknet", choices=["darknet", "resnet", "densenet", "vgg"], help="non-default: BASELINE config 4 (backbone swap)")
+    ap.add_argument("--depthwise", action="store_true", help="non-default: the depthwise variants (DWConv in backbone, neck and head; in no BASELINE configuration)")
     ap.add_argument("--width", type=float, default=1.0, help="non-default: channel multiplier (tests run a small network through the same path)")
     ap.add_argument("--depth", type=float, default=1.0, help="non-default: depth multiplier")
     ap.add_argument("--eager-backward", action="store_true", help="launch the two backward lanes from the host instead of replaying captured segments")
@@ -333,7 +334,7 @@ def main():
         dist.all_gather_object(ranks_info, me)
 
     torch.manual_seed(0)                                     # identical replicas on every rank
-    model = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width, backbone_type=a.backbone), enn.YOLOXHead(80, a.width))
+    model = enn.YOLOX(enn.YOLOPAFPN(a.depth, a.width, backbone_type=a.backbone, depthwise=a.depthwise), enn.YOLOXHead(80, a.width, depthwise=a.depthwise))
     for mod in model.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):            # init_yolo, exp/yolox_base.py:58-62
             mod.eps, mod.momentum = 1e-3, 0.03
@@ -421,7 +422,7 @@ def main():
         # the family's time in the replayed run: a member's launches may run as several device kernels (the six stride-2 input
         # gradients of igemm_dma_kernel's share are igemm_dma_multi_kernel launches)
         reps = [replayed_ms_per_step(REPLAY_PREFIX[k]) for k in members]
-        default_cfg = (a.batch, a.size, a.gts, a.backbone, a.width, a.depth) == (20, 640, 10, "darknet", 1.0, 1.0) and not (a.fisheye or a.long_run or a.no_graph or a.plan)
+        default_cfg = (a.batch, a.size, a.gts, a.backbone, a.width, a.depth) == (20, 640, 10, "darknet", 1.0, 1.0) and not (a.fisheye or a.long_run or a.no_graph or a.plan or a.depthwise)
         rep_ms = sum(r[0] for r in reps) if (default_cfg and all(r[0] for r in reps)) else None     # the committed profile is of the default workload
         rep_src = reps[0][1]
         from ep24 import _lib as _l
@@ -438,6 +439,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "hip_graph": ("none" if a.no_graph else "fwd+loss, update; backward launched on 2 streams" if a.eager_backward
                                      else "forward and backward as two lanes of captured segments, loss, update"),
                        **({"long_run": "use_l1 + fused ModelEMA + yoloxwarmcos per step"} if a.long_run else {}),
+                       **({"depthwise": "DWConv in backbone, neck and head (network_blocks.py:57-76); step_mfma_frac / roofline refer to the dense network's FLOPs and do not apply"} if a.depthwise else {}),
                        **({"fisheye": "sector warp of image + mask (Theta 30..90) and letterbox of every image inside the timed step"} if a.fisheye else {})},
             "loss": round(loss, 4),
             # bounded waits of the loader / consumer ring kernels that gave up in this process (0 unless their hand-off protocol is

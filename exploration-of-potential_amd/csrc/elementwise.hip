@@ -212,7 +212,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const bf16* dy, long ld_dy, c
                 }
             }
         }
-        const int ngrp = min(rm.tpr, (C >> 3) - cg0);
+        const int ngrp = min(min(rm.tpr, NT), (C >> 3) - cg0);            // (<= NT: with C > 8 NT a pass covers NT groups, not tpr)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                   // 0: sum of du * zhat (dgamma), 1: sum of du (dbeta)
 #pragma unroll

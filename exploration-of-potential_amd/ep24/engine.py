@@ -211,6 +211,8 @@ class ParamHome:
                 k = w.shape[2]
                 if mod in stems:      # Focus stem runs as im2col x [Cout][108]: one "tap" of 108 (kh,kw,c) columns
                     self._add(ConvSeg([w], w.shape[0], 1, k * k * w.shape[1], need_dgrad=False))
+                elif mod.conv.groups > 1:                  # depthwise (DWConv.dconv): [C][9] fp32, the kernels read the master itself
+                    self._add(ConvSeg([w], w.shape[0], k * k, 1, need_dgrad=False))
                 else:
                     self._add(ConvSeg([w], w.shape[0], k * k, w.shape[1]))
                 self._add(VecSeg([mod.bn.weight]))
@@ -425,6 +427,17 @@ def csp_is_merged(m, opts):
     return opts.merge_csp and len(m.m) > 0 and (opts.merge_csp_shortcut or not any(b.use_add for b in m.m))
 
 
+def _units(m):
+    """The BaseConv units of a conv block in execution order: a DWConv is its depthwise unit, then its 1x1 unit."""
+    return (m.dconv, m.pconv) if isinstance(m, enn.DWConv) else (m,)
+
+
+def head_is_merged(head, opts):
+    """The first 3x3 conv of the class and of the regression branch as one GEMM - dense heads only (a depthwise first conv is a
+    per-channel pass over the SAME input twice: nothing to merge)."""
+    return opts.merge_head and not getattr(head, "depthwise", False)
+
+
 def exec_order(model, opts=None):
     opts = opts if opts is not None else get_options(model)
     """Modules in the order the plan executes them (yolox.py:24-34 -> yolo_pafpn.py:83-124 -> yolo_head_24p.py:150-189);
@@ -432,13 +445,13 @@ def exec_order(model, opts=None):
     def head_order(head):
         for k in range(len(head.stems)):
             yield head.stems[k]
-            if opts.merge_head:                       # the first 3x3 conv of the class and of the regression branch read the same tensor
+            if head_is_merged(head, opts):            # the first 3x3 conv of the class and of the regression branch read the same tensor
                 yield ("pair_merged", head.cls_convs[k][0], head.reg_convs[k][0])
                 yield head.cls_convs[k][1]
                 yield head.reg_convs[k][1]
             else:
-                yield from head.cls_convs[k]
-                yield from head.reg_convs[k]
+                for blk in list(head.cls_convs[k]) + list(head.reg_convs[k]):
+                    yield from _units(blk)
         yield head
 
     if isinstance(model, enn.YOLOXHead):              # a head run on its own (YOLOXHead.forward)
@@ -523,7 +536,7 @@ def exec_order(model, opts=None):
             yield m.conv2
         for blk in m.m:
             yield blk.conv1
-            yield blk.conv2
+            yield from _units(blk.conv2)
         yield m.conv3
 
     neck, head = model.backbone, model.head
@@ -534,9 +547,9 @@ def exec_order(model, opts=None):
         yield bb.stem.conv
         for name in ("dark2", "dark3", "dark4"):
             seq = getattr(bb, name)
-            yield seq[0]
+            yield from _units(seq[0])
             yield from csp(seq[1])
-        yield bb.dark5[0]
+        yield from _units(bb.dark5[0])
         yield bb.dark5[1].conv1
         yield bb.dark5[1].conv2
         yield from csp(bb.dark5[2])
@@ -544,9 +557,9 @@ def exec_order(model, opts=None):
     yield from csp(neck.C3_p4)
     yield neck.reduce_conv1
     yield from csp(neck.C3_p3)
-    yield neck.bu_conv2
+    yield from _units(neck.bu_conv2)
     yield from csp(neck.C3_n3)
-    yield neck.bu_conv1
+    yield from _units(neck.bu_conv1)
     yield from csp(neck.C3_n4)
     yield from head_order(head)
     if isinstance(bb, enn.ResNet):
@@ -686,7 +699,7 @@ class Engine:
         swapped = isinstance(bb, (enn.ResNet, enn.DenseNet, enn.VGG))
         if swapped and self.f32:
             raise NotImplementedError("ep24: the fp32 parity mode covers the CSPDarknet network (the BASELINE configuration)")
-        return (256, 512, 1024) if swapped else (bb.dark3[0].conv.out_channels, bb.dark4[0].conv.out_channels, bb.dark5[0].conv.out_channels)
+        return (256, 512, 1024) if swapped else tuple(_units(st[0])[-1].conv.out_channels for st in (bb.dark3, bb.dark4, bb.dark5))
 
     def focus_stem(self, focus):
         """Focus + its 3x3 BaseConv (network_blocks.py:188-210).  bf16: the space-to-depth image [B][H/2][W/2][16] and a conv that
@@ -710,10 +723,10 @@ class Engine:
             build = self.resnet if isinstance(bb, enn.ResNet) else self.vgg if isinstance(bb, enn.VGG) else self.densenet
             return build(bb, out3, out4)
         x = self.focus_stem(bb.stem)
-        x = self.csp(bb.dark2[1], self.unit(bb.dark2[0], x))
-        x2 = self.csp(bb.dark3[1], self.unit(bb.dark3[0], x), out=out3)
-        x1 = self.csp(bb.dark4[1], self.unit(bb.dark4[0], x2), out=out4)
-        x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.unit(bb.dark5[0], x1)))
+        x = self.csp(bb.dark2[1], self.conv_block(bb.dark2[0], x))
+        x2 = self.csp(bb.dark3[1], self.conv_block(bb.dark3[0], x), out=out3)
+        x1 = self.csp(bb.dark4[1], self.conv_block(bb.dark4[0], x2), out=out4)
+        x0 = self.csp(bb.dark5[2], self.spp(bb.dark5[1], self.conv_block(bb.dark5[0], x1)))
         return x2, x1, x0
 
     def build_neck_inputs(self, neck, feats=None):
@@ -739,10 +752,10 @@ class Engine:
         self.up2(fpn_out1, cat_p3.slice(0, c3))
         pan_out2 = self.csp(neck.C3_p3, cat_p3)
         self.fwd_fork = len(self.fwd)                 # pan_out2 is complete: head level 0 can start (ep24.train runs it on a second lane)
-        self.unit(neck.bu_conv2, pan_out2, out=cat_n3.slice(0, c3))
+        self.conv_block(neck.bu_conv2, pan_out2, out=cat_n3.slice(0, c3))
         pan_out1 = self.csp(neck.C3_n3, cat_n3)
         self.fwd_fork1 = len(self.fwd)                # pan_out1 is complete: head level 1 can start
-        self.unit(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
+        self.conv_block(neck.bu_conv1, pan_out1, out=cat_n4.slice(0, c4))
         pan_out0 = self.csp(neck.C3_n4, cat_n4)
         return pan_out2, pan_out1, pan_out0
 
@@ -924,6 +937,81 @@ class Engine:
         return (lambda: self.bnsums.data_ptr() + 8 * off), (lambda: self.bnsums.data_ptr() + 8 * (off + C))
 
     # ---- ops ---------------------------------------------------------------------------------------
+    def conv_block(self, mod, x, out=None, residual=None, x_single=False):
+        """`Conv = DWConv if depthwise else BaseConv` of the reference's constructors: a BaseConv unit, or a DWConv = depthwise unit
+        followed by a 1x1 unit (network_blocks.py:57-76), which takes the block's output slot and shortcut."""
+        if isinstance(mod, enn.DWConv):
+            return self.unit(mod.pconv, self.unit_dw(mod.dconv, x), out=out, residual=residual)
+        return self.unit(mod, x, out=out, residual=residual, x_single=x_single)
+
+    def unit_dw(self, mod, x):
+        """A depthwise BaseConv (groups = channels): conv -> BN(batch stats) -> SiLU with the conv as HBM-bound elementwise kernels
+        (csrc/dwconv.hip) over the fp32 master weights; BatchNorm + activation are the launches of every other unit."""
+        if self.f32:
+            raise NotImplementedError("ep24: the fp32 parity mode covers the dense network (the BASELINE configurations); depthwise variants run in bf16")
+        home = self.home
+        conv, bn, act = mod.conv, mod.bn, mod.act_code
+        seg = home.by_param[conv.weight]
+        gam, bet = home.by_param[bn.weight], home.by_param[bn.bias]
+        k, s, C = conv.kernel_size[0], conv.stride[0], x.C
+        assert (seg.cout, seg.cin, seg.taps) == (C, 1, 9), (seg.cout, seg.cin, seg.taps, C)
+        B, H, W = x.B, x.H, x.W
+        OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+        out, z = self.new_act(C, OH, OW), self.new_act(C, OH, OW)
+        z.needs_grad = False
+        M = B * OH * OW
+        self.max_dz = max(self.max_dz, M * C)
+        save = torch.zeros(2 * C, dtype=torch.float32, device=self.dev)
+        stats = self._stats_slot(C)
+        sum_g, sum_b = self._sums_slot(C)
+        flat, gflat = home.flat, home.gflat
+        w_p = ptr(flat, seg.off)
+        # eval mode: the same conv without statistics, then BatchNorm from the running statistics (not folded: the weights are the masters)
+        self._f("dwconv_fwd_bf16", x.ptr(), x.ld, w_p, z.ptr(), z.ld, stats, STATS_REPLICAS, B, H, W, C, k, s,
+                ev=("dwconv_fwd_bf16", (x.ptr(), x.ld, w_p, z.ptr(), z.ld, None, 1, B, H, W, C, k, s)))
+        self._f("bn_act_fwd", z.ptr(), z.ld, stats, STATS_REPLICAS, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean),
+                ptr(bn.running_var), ptr(bn.num_batches_tracked), None, ptr(save), out.ptr(), out.ld, None, 0, M, C, float(bn.eps),
+                float(bn.momentum), act,
+                ev=("bn_act_infer", (z.ptr(), z.ld, ptr(flat, gam.off), ptr(flat, bet.off), ptr(bn.running_mean), ptr(bn.running_var),
+                                     out.ptr(), out.ld, None, 0, M, C, float(bn.eps), act)))
+        self.unit_acts[mod] = (x, z, out)
+
+        def build_bwd():
+            assert out.gready(), "activation without a gradient producer"
+            kk = self._bwd_units
+            self._bwd_units += 1
+            dzoff = self._dz_elems
+            self._dz_elems += M * C
+            dz = (lambda dzoff=dzoff: self.dzbuf.data_ptr() + 2 * dzoff)
+            self._b("bn_act_bwd_reduce", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sum_g, sum_b,
+                                          M, C, act, STATS_REPLICAS), reads=out)
+            self._b("bn_act_bwd_apply", (out.gptr(), out.gld, z.ptr(), z.ld, ptr(save), ptr(flat, gam.off), ptr(flat, bet.off), sum_g, sum_b,
+                                         ptr(gflat, gam.off), ptr(gflat, bet.off), dz, C, M, C, act, STATS_REPLICAS), writes=(gam, bet))
+            splits = _lib.lib().fn["ep24_dwconv_wgrad_splits"](B, H, W, C, s)
+            assert splits >= 1, splits
+
+            def emit_wgrad():                         # side lane: per-workgroup partial sums, folded by the next reduce launch
+                soff = self._slab_floats
+                self._slab_floats += splits * seg.numel
+                self._b("@side_wait_main", ())
+                self._b("side:dwconv_wgrad_slab_bf16", (x.ptr(), x.ld, dz, C, (lambda soff=soff: self.slab.data_ptr() + 4 * soff),
+                                                         splits * seg.numel, B, H, W, C, k, s))
+                self._b("@side_record", (kk,))
+                self._pending_reduce.append((seg, splits, soff))
+                if len(self._pending_reduce) >= WGRAD_REDUCE_GROUP:
+                    self._flush_reduce()
+
+            if self._force_side:
+                self._deferred.append(emit_wgrad)
+            else:
+                emit_wgrad()
+            if x.needs_grad:
+                acc = x.gwrite()
+                self._b("dwconv_dgrad_bf16", (dz, C, w_p, x.gptr(), x.gld, acc, B, H, W, C, k, s))
+
+        self._add_builder(build_bwd)
+        return out
+
     def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False, bn_in=False):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
         name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none).  ``x_single``: the
@@ -1148,7 +1236,7 @@ class Engine:
         for i, blk in enumerate(mod.m):
             last = i == n - 1
             u = self.unit(blk.conv1, t, bn_in=i > 0)
-            t = self.unit(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None, x_single=True)
+            t = self.conv_block(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, cat, out=out)
 
     def relu(self, y):
@@ -1415,7 +1503,7 @@ class Engine:
             self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
             u = self.unit(blk.conv1, t, bn_in=i > 0)
-            t = self.unit(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None, x_single=True)
+            t = self.conv_block(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 
     def spp(self, mod, x):
@@ -1459,7 +1547,7 @@ class Engine:
         self.levels.append((H, W, s))
         self._cur_tag = ("head", k)
         x = self.unit(head.stems[k], feat)
-        if self.options.merge_head:
+        if head_is_merged(head, self.options):
             c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
             hc = c0.conv.out_channels
             _same_bn(c0.bn, r0.bn)
@@ -1470,8 +1558,8 @@ class Engine:
             cf = self.unit(head.cls_convs[k][1], both.slice(0, hc), x_single=True)      # each branch owns its half of the merged unit's channels
             rf = self.unit(head.reg_convs[k][1], both.slice(hc, hc), x_single=True)
         else:
-            cf = self.unit(head.cls_convs[k][1], self.unit(head.cls_convs[k][0], x), x_single=True)
-            rf = self.unit(head.reg_convs[k][1], self.unit(head.reg_convs[k][0], x), x_single=True)
+            cf = self.conv_block(head.cls_convs[k][1], self.conv_block(head.cls_convs[k][0], x), x_single=True)
+            rf = self.conv_block(head.reg_convs[k][1], self.conv_block(head.reg_convs[k][0], x), x_single=True)
         ro_seg = home.by_param[head.reg_preds[k].weight]
         ro_b = home.by_param[head.reg_preds[k].bias]
         cl_seg = home.by_param[head.cls_preds[k].weight]
@@ -1759,11 +1847,13 @@ class SubEngine(Engine):
             if len(home.by_param[mod.conv.weight].params) != 1:
                 raise NotImplementedError("ep24: this BaseConv runs as one merged unit with its sibling (conv1 / conv2 of a CSP layer, the "
                                           "first convs of the head branches): call the enclosing module, or build the model with PlanOptions(merge_csp=False, merge_head=False)")
-            self.outs = [self.unit(mod, x)]
+            self.outs = [self.unit_dw(mod, x) if mod.conv.groups > 1 else self.unit(mod, x)]
+        elif kind == "dwconv":                                # DWConv.forward (network_blocks.py:73-76)
+            self.outs = [self.conv_block(mod, x)]
         elif kind == "focus":
             self.outs = [self.focus_stem(mod)]
         elif kind == "bottleneck":
-            self.outs = [self.unit(mod.conv2, self.unit(mod.conv1, x), residual=x if mod.use_add else None, x_single=True)]
+            self.outs = [self.conv_block(mod.conv2, self.unit(mod.conv1, x), residual=x if mod.use_add else None, x_single=True)]
         elif kind == "csp":
             self.outs = [self.csp(mod, x)]
         elif kind == "spp":

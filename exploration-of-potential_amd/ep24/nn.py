@@ -3,7 +3,7 @@
 These modules only HOLD parameters and describe the graph; the arithmetic is the HIP plan in
 ``ep24.engine`` (NHWC bf16 MFMA convs, fused BN+SiLU, ...), entered through ``YOLOX.forward``.
 Names follow the reference so its checkpoints load unchanged:
-  network_blocks.py:29-210 (BaseConv, Bottleneck, CSPLayer, SPPBottleneck, Focus), darknet.py:95-177
+  network_blocks.py:29-210 (BaseConv, DWConv, Bottleneck, CSPLayer, SPPBottleneck, Focus), darknet.py:95-177
   (CSPDarknet), yolo_pafpn.py:27-81 (YOLOPAFPN), yolo_head_24p.py:47-141 (YOLOXHead), yolox.py:17-34 (YOLOX).
 """
 import math
@@ -36,11 +36,14 @@ class BaseConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
         super().__init__()
-        if groups != 1 or bias:
-            raise NotImplementedError("ep24 hot path: dense conv without bias (DWConv / grouped convolutions are outside the 24p configuration)")
+        depthwise = groups == in_channels == out_channels and groups > 1
+        if bias or (groups != 1 and not depthwise):
+            raise NotImplementedError("ep24 hot path: conv without bias, dense or depthwise (groups = channels: DWConv); other groupings are not in the reference")
+        if depthwise and (ksize != 3 or in_channels % 8):
+            raise NotImplementedError("ep24: depthwise convs are the 3x3 ones of DWConv over a multiple of 8 channels (got k=%d, C=%d)" % (ksize, in_channels))
         if act not in ACT_CODES:
             raise AttributeError("Unsupported act type: {}".format(act))       # get_activation, network_blocks.py:17-26
-        self.conv = nn.Conv2d(in_channels, out_channels, ksize, stride, (ksize - 1) // 2, bias=False)
+        self.conv = nn.Conv2d(in_channels, out_channels, ksize, stride, (ksize - 1) // 2, groups=groups, bias=False)
         self.bn = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.03)
         self.act = {"silu": nn.SiLU, "relu": nn.ReLU}[act](inplace=True) if act != "lrelu" else nn.LeakyReLU(0.1, inplace=True)
         self.act_code = ACT_CODES[act]
@@ -48,6 +51,24 @@ class BaseConv(nn.Module):
     def forward(self, x):
         """act(bn(conv(x))) (network_blocks.py:50-51); NCHW in / NCHW fp32 out."""
         return _sub(self, "baseconv", x)[0]
+
+
+class DWConv(nn.Module):
+    """Depthwise conv + 1x1 conv, each a BaseConv (network_blocks.py:57-76); `depthwise=True` of the constructors below puts it where
+    the reference does (darknet.py:107, network_blocks.py:92, yolo_pafpn.py:30, yolo_head_24p.py:45).  The depthwise unit runs as
+    HBM-bound elementwise kernels (csrc/dwconv.hip), the 1x1 unit as every other 1x1 unit."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride=1, act="silu"):
+        super().__init__()
+        self.dconv = BaseConv(in_channels, in_channels, ksize=ksize, stride=stride, groups=in_channels, act=act)
+        self.pconv = BaseConv(in_channels, out_channels, ksize=1, stride=1, groups=1, act=act)
+
+    def forward(self, x):
+        return _sub(self, "dwconv", x)[0]
+
+
+def _conv_cls(depthwise):
+    return DWConv if depthwise else BaseConv
 
 
 class Focus(nn.Module):
@@ -63,11 +84,9 @@ class Focus(nn.Module):
 class Bottleneck(nn.Module):
     def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError("depthwise variants are outside the 24p hot path")
         hidden = int(out_channels * expansion)
         self.conv1 = BaseConv(in_channels, hidden, 1, 1, act=act)
-        self.conv2 = BaseConv(hidden, out_channels, 3, 1, act=act)
+        self.conv2 = _conv_cls(depthwise)(hidden, out_channels, 3, 1, act=act)           # network_blocks.py:92
         self.use_add = shortcut and in_channels == out_channels
 
     def forward(self, x):
@@ -107,12 +126,13 @@ class CSPDarknet(nn.Module):
         self.out_features = out_features
         c = int(wid_mul * 64)
         d = max(round(dep_mul * 3), 1)
+        Conv, dw = _conv_cls(depthwise), depthwise                                    # darknet.py:107
         self.stem = Focus(3, c, ksize=3, act=act)
-        self.dark2 = nn.Sequential(BaseConv(c, c * 2, 3, 2, act=act), CSPLayer(c * 2, c * 2, n=d, act=act))
-        self.dark3 = nn.Sequential(BaseConv(c * 2, c * 4, 3, 2, act=act), CSPLayer(c * 4, c * 4, n=d * 3, act=act))
-        self.dark4 = nn.Sequential(BaseConv(c * 4, c * 8, 3, 2, act=act), CSPLayer(c * 8, c * 8, n=d * 3, act=act))
-        self.dark5 = nn.Sequential(BaseConv(c * 8, c * 16, 3, 2, act=act), SPPBottleneck(c * 16, c * 16, activation=act),
-                                   CSPLayer(c * 16, c * 16, n=d, shortcut=False, act=act))
+        self.dark2 = nn.Sequential(Conv(c, c * 2, 3, 2, act=act), CSPLayer(c * 2, c * 2, n=d, depthwise=dw, act=act))
+        self.dark3 = nn.Sequential(Conv(c * 2, c * 4, 3, 2, act=act), CSPLayer(c * 4, c * 4, n=d * 3, depthwise=dw, act=act))
+        self.dark4 = nn.Sequential(Conv(c * 4, c * 8, 3, 2, act=act), CSPLayer(c * 8, c * 8, n=d * 3, depthwise=dw, act=act))
+        self.dark5 = nn.Sequential(Conv(c * 8, c * 16, 3, 2, act=act), SPPBottleneck(c * 16, c * 16, activation=act),
+                                   CSPLayer(c * 16, c * 16, n=d, shortcut=False, depthwise=dw, act=act))
 
     def forward(self, x):
         """{"dark3", "dark4", "dark5"} feature maps of the images (darknet.py:165-177; out_features as constructed)."""
@@ -369,20 +389,23 @@ class YOLOPAFPN(nn.Module):
             self.backbone = vgg19()
         else:
             raise NotImplementedError("backbone_type %r is not one of 'darknet', 'resnet', 'densenet', 'vgg'" % backbone_type)
+        if depthwise and backbone_type != "darknet":
+            raise NotImplementedError("depthwise=True belongs to the CSPDarknet network (yolo_pafpn.py:27-30)")
         self.backbone_type = backbone_type
         self.in_features = in_features
         self.in_channels = in_channels
         c3, c4, c5 = [int(c * width) for c in in_channels]
         n = round(3 * depth)
         self.upsample = nn.Upsample(scale_factor=2, mode="nearest")
+        Conv, dw = _conv_cls(depthwise), depthwise                                    # yolo_pafpn.py:30
         self.lateral_conv0 = BaseConv(c5, c4, 1, 1, act=act)
-        self.C3_p4 = CSPLayer(2 * c4, c4, n, False, act=act)
+        self.C3_p4 = CSPLayer(2 * c4, c4, n, False, depthwise=dw, act=act)
         self.reduce_conv1 = BaseConv(c4, c3, 1, 1, act=act)
-        self.C3_p3 = CSPLayer(2 * c3, c3, n, False, act=act)
-        self.bu_conv2 = BaseConv(c3, c3, 3, 2, act=act)
-        self.C3_n3 = CSPLayer(2 * c3, c4, n, False, act=act)
-        self.bu_conv1 = BaseConv(c4, c4, 3, 2, act=act)
-        self.C3_n4 = CSPLayer(2 * c4, c5, n, False, act=act)
+        self.C3_p3 = CSPLayer(2 * c3, c3, n, False, depthwise=dw, act=act)
+        self.bu_conv2 = Conv(c3, c3, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c3, c4, n, False, depthwise=dw, act=act)
+        self.bu_conv1 = Conv(c4, c4, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c4, c5, n, False, depthwise=dw, act=act)
 
     def forward(self, x):
         """images -> (pan_out2, pan_out1, pan_out0), the tuple the head consumes (yolo_pafpn.py:83-124)."""
@@ -402,10 +425,12 @@ class YOLOXHead(nn.Module):
         self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
         self.cls_preds, self.reg_preds, self.obj_preds = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         self.stems = nn.ModuleList()
+        Conv = _conv_cls(depthwise)                                                   # yolo_head_24p.py:45
+        self.depthwise = bool(depthwise)
         for c in in_channels:
             self.stems.append(BaseConv(int(c * width), h, 1, 1, act=act))
-            self.cls_convs.append(nn.Sequential(BaseConv(h, h, 3, 1, act=act), BaseConv(h, h, 3, 1, act=act)))
-            self.reg_convs.append(nn.Sequential(BaseConv(h, h, 3, 1, act=act), BaseConv(h, h, 3, 1, act=act)))
+            self.cls_convs.append(nn.Sequential(Conv(h, h, 3, 1, act=act), Conv(h, h, 3, 1, act=act)))
+            self.reg_convs.append(nn.Sequential(Conv(h, h, 3, 1, act=act), Conv(h, h, 3, 1, act=act)))
             self.cls_preds.append(nn.Conv2d(h, self.n_anchors * num_classes, 1, 1, 0))
             self.reg_preds.append(nn.Conv2d(h, 26, 1, 1, 0))
             self.obj_preds.append(nn.Conv2d(h, self.n_anchors, 1, 1, 0))

@@ -194,6 +194,23 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           int reps, void* stream);
 
+/* Depthwise 3x3 convolution (groups = channels) of the DWConv blocks (yolox_24p/models/network_blocks.py:57-76: a depthwise BaseConv
+ * followed by a 1x1 BaseConv; `depthwise=True` of CSPDarknet / Bottleneck / YOLOPAFPN / YOLOXHead, darknet.py:107, network_blocks.py:92,
+ * yolo_pafpn.py:30, yolo_head_24p.py:45 - in no BASELINE configuration).  HBM-bound elementwise kernels (csrc/dwconv.hip): NHWC bf16
+ * activations, w = the fp32 master [C][3][3] read in place, fp32 accumulation, stride 1 or 2, pad 1; C % 8 == 0.
+ *   fwd:   z = conv(x, w); `stats` as ep24_conv_fwd_bf16 ([replicas][2][C] fixed-point batch statistics of z), or NULL.
+ *   dgrad: dx (+)= the input gradient from dz [B,OH,OW,C].
+ *   wgrad: slab [splits][C][9] fp32 = per-workgroup partial sums of dw, splits = ep24_dwconv_wgrad_splits(...) (fixed by the shape);
+ *          ep24_wgrad_reduce folds them in order into the flat gradient, as for every other weight gradient (no atomics).
+ * BatchNorm + activation of the unit are the ep24_bn_act_* entry points. */
+int ep24_dwconv_fwd_bf16(const void* x, int64_t ld_x, const float* w, void* z, int64_t ld_z, int64_t* stats, int stats_replicas,
+                         int B, int H, int W, int C, int ksize, int stride, void* stream);
+int ep24_dwconv_dgrad_bf16(const void* dz, int64_t ld_dz, const float* w, void* dx, int64_t ld_dx, int accumulate, int B, int H,
+                           int W, int C, int ksize, int stride, void* stream);
+int ep24_dwconv_wgrad_splits(int B, int H, int W, int C, int stride);
+int ep24_dwconv_wgrad_slab_bf16(const void* x, int64_t ld_x, const void* dz, int64_t ld_dz, float* slab, int64_t slab_floats, int B,
+                                int H, int W, int C, int ksize, int stride, void* stream);
+
 /* A 1x1 stride-1 conv unit TOGETHER WITH the BatchNorm pass in front of it (round 5; csrc/conv_igemm.hip igemm_stream_kernel<XF>).
  * The streaming 1x1 kernel is the one conv kernel whose A operand passes through registers, so the pass that would have produced
  * that operand as a launch of its own runs on the rows in flight: one dependent launch and one read of the rows less, the same

@@ -8,6 +8,8 @@ load by name:
   decoupled 24p head + train-mode decode                yolox_24p/models/yolo_head_24p.py:47-237
   factory (BN eps 1e-3 / momentum 0.03, prior bias)     yolox_24p/exp/yolox_base.py:55-72
   swapped backbone resnet50() (BASELINE config 4)       yolox_24p/models/darknet.py:179-429, yolox/models/yolo_pafpn.py:31-38
+  depthwise variants (DWConv = depthwise unit + 1x1)    yolox_24p/models/network_blocks.py:57-76; the `depthwise` switches of
+                                                        darknet.py:107, network_blocks.py:92, yolo_pafpn.py:30, yolo_head_24p.py:45
 """
 import math
 
@@ -32,13 +34,30 @@ class Unit(nn.Module):
     statistics come from the unrounded conv result, exactly as the MFMA epilogue accumulates them.  This
     isolates kernel errors from the (expected) bf16 storage error when the two paths are compared."""
 
-    def __init__(self, cin, cout, k, s=1):
+    def __init__(self, cin, cout, k, s=1, groups=1):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=False)
+        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, groups=groups, bias=False)
         self.bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.03)
 
     def forward(self, x):
         return conv_bn_act(x, self.conv, self.bn, "silu", self.training)
+
+
+class DW(nn.Module):
+    """DWConv (network_blocks.py:57-76): a depthwise unit (groups = channels) followed by a 1x1 unit; names dconv / pconv."""
+
+    def __init__(self, cin, cout, k, s=1):
+        super().__init__()
+        self.dconv = Unit(cin, cin, k, s, groups=cin)
+        self.pconv = Unit(cin, cout, 1, 1)
+
+    def forward(self, x):
+        return self.pconv(self.dconv(x))
+
+
+def Conv(depthwise):
+    """`Conv = DWConv if depthwise else BaseConv` of the reference's constructors."""
+    return DW if depthwise else Unit
 
 
 def conv_bn_act(x, conv, bn, act, training, residual=None):
@@ -47,7 +66,7 @@ def conv_bn_act(x, conv, bn, act, training, residual=None):
     if not EMULATE_BF16:
         u = bn(conv(x))
         return fn(u if residual is None else u + residual)
-    z = F.conv2d(_q(x), _q(conv.weight), None, conv.stride, conv.padding)
+    z = F.conv2d(_q(x), _q(conv.weight), None, conv.stride, conv.padding, 1, conv.groups)
     mean = z.mean((0, 2, 3))
     var = z.var((0, 2, 3), unbiased=False)
     if training:
@@ -77,10 +96,10 @@ class Stem(nn.Module):
 
 
 class Res(nn.Module):
-    def __init__(self, c, add):
+    def __init__(self, c, add, depthwise=False):
         super().__init__()
         self.conv1 = Unit(c, c, 1)
-        self.conv2 = Unit(c, c, 3)
+        self.conv2 = Conv(depthwise)(c, c, 3)
         self.add = add
 
     def forward(self, x):
@@ -89,13 +108,13 @@ class Res(nn.Module):
 
 
 class CSP(nn.Module):
-    def __init__(self, cin, cout, n, add=True):
+    def __init__(self, cin, cout, n, add=True, depthwise=False):
         super().__init__()
         h = int(cout * 0.5)
         self.conv1 = Unit(cin, h, 1)
         self.conv2 = Unit(cin, h, 1)
         self.conv3 = Unit(2 * h, cout, 1)
-        self.m = nn.Sequential(*[Res(h, add) for _ in range(n)])
+        self.m = nn.Sequential(*[Res(h, add, depthwise) for _ in range(n)])
 
     def forward(self, x):
         return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), 1))
@@ -113,15 +132,16 @@ class SPP(nn.Module):
 
 
 class Backbone(nn.Module):
-    def __init__(self, depth, width):
+    def __init__(self, depth, width, depthwise=False):
         super().__init__()
         c = int(width * 64)
         d = max(round(depth * 3), 1)
+        C, dw = Conv(depthwise), depthwise
         self.stem = Stem(3, c, 3)
-        self.dark2 = nn.Sequential(Unit(c, 2 * c, 3, 2), CSP(2 * c, 2 * c, d))
-        self.dark3 = nn.Sequential(Unit(2 * c, 4 * c, 3, 2), CSP(4 * c, 4 * c, 3 * d))
-        self.dark4 = nn.Sequential(Unit(4 * c, 8 * c, 3, 2), CSP(8 * c, 8 * c, 3 * d))
-        self.dark5 = nn.Sequential(Unit(8 * c, 16 * c, 3, 2), SPP(16 * c, 16 * c), CSP(16 * c, 16 * c, d, add=False))
+        self.dark2 = nn.Sequential(C(c, 2 * c, 3, 2), CSP(2 * c, 2 * c, d, depthwise=dw))
+        self.dark3 = nn.Sequential(C(2 * c, 4 * c, 3, 2), CSP(4 * c, 4 * c, 3 * d, depthwise=dw))
+        self.dark4 = nn.Sequential(C(4 * c, 8 * c, 3, 2), CSP(8 * c, 8 * c, 3 * d, depthwise=dw))
+        self.dark5 = nn.Sequential(C(8 * c, 16 * c, 3, 2), SPP(16 * c, 16 * c), CSP(16 * c, 16 * c, d, add=False, depthwise=dw))
 
     def forward(self, x):
         x = self.dark2(self.stem(x))
@@ -315,19 +335,20 @@ class VGGBackbone(nn.Module):
 
 
 class Neck(nn.Module):
-    def __init__(self, depth, width, in_channels=(256, 512, 1024), backbone_type="darknet"):
+    def __init__(self, depth, width, in_channels=(256, 512, 1024), backbone_type="darknet", depthwise=False):
         super().__init__()
         c3, c4, c5 = [int(c * width) for c in in_channels]
         n = round(3 * depth)
-        self.backbone = {"darknet": lambda: Backbone(depth, width), "resnet": ResNetBackbone, "densenet": DenseNetBackbone, "vgg": VGGBackbone}[backbone_type]()
+        dw = depthwise
+        self.backbone = {"darknet": lambda: Backbone(depth, width, dw), "resnet": ResNetBackbone, "densenet": DenseNetBackbone, "vgg": VGGBackbone}[backbone_type]()
         self.lateral_conv0 = Unit(c5, c4, 1)
-        self.C3_p4 = CSP(2 * c4, c4, n, add=False)
+        self.C3_p4 = CSP(2 * c4, c4, n, add=False, depthwise=dw)
         self.reduce_conv1 = Unit(c4, c3, 1)
-        self.C3_p3 = CSP(2 * c3, c3, n, add=False)
-        self.bu_conv2 = Unit(c3, c3, 3, 2)
-        self.C3_n3 = CSP(2 * c3, c4, n, add=False)
-        self.bu_conv1 = Unit(c4, c4, 3, 2)
-        self.C3_n4 = CSP(2 * c4, c5, n, add=False)
+        self.C3_p3 = CSP(2 * c3, c3, n, add=False, depthwise=dw)
+        self.bu_conv2 = Conv(dw)(c3, c3, 3, 2)
+        self.C3_n3 = CSP(2 * c3, c4, n, add=False, depthwise=dw)
+        self.bu_conv1 = Conv(dw)(c4, c4, 3, 2)
+        self.C3_n4 = CSP(2 * c4, c5, n, add=False, depthwise=dw)
 
     def forward(self, x):
         x2, x1, x0 = self.backbone(x)
@@ -341,14 +362,15 @@ class Neck(nn.Module):
 
 
 class Head(nn.Module):
-    def __init__(self, num_classes, width, in_channels=(256, 512, 1024), strides=(8, 16, 32)):
+    def __init__(self, num_classes, width, in_channels=(256, 512, 1024), strides=(8, 16, 32), depthwise=False):
         super().__init__()
         h = int(256 * width)
+        C = Conv(depthwise)
         self.num_classes = num_classes
         self.strides = strides
         self.stems = nn.ModuleList(Unit(int(c * width), h, 1) for c in in_channels)
-        self.cls_convs = nn.ModuleList(nn.Sequential(Unit(h, h, 3), Unit(h, h, 3)) for _ in in_channels)
-        self.reg_convs = nn.ModuleList(nn.Sequential(Unit(h, h, 3), Unit(h, h, 3)) for _ in in_channels)
+        self.cls_convs = nn.ModuleList(nn.Sequential(C(h, h, 3), C(h, h, 3)) for _ in in_channels)
+        self.reg_convs = nn.ModuleList(nn.Sequential(C(h, h, 3), C(h, h, 3)) for _ in in_channels)
         self.cls_preds = nn.ModuleList(nn.Conv2d(h, num_classes, 1) for _ in in_channels)
         self.reg_preds = nn.ModuleList(nn.Conv2d(h, 26, 1) for _ in in_channels)
         self.obj_preds = nn.ModuleList(nn.Conv2d(h, 1, 1) for _ in in_channels)
@@ -395,10 +417,10 @@ class Head(nn.Module):
 
 
 class Net(nn.Module):
-    def __init__(self, depth=1.0, width=1.0, num_classes=80, backbone_type="darknet"):
+    def __init__(self, depth=1.0, width=1.0, num_classes=80, backbone_type="darknet", depthwise=False):
         super().__init__()
-        self.backbone = Neck(depth, width, backbone_type=backbone_type)
-        self.head = Head(num_classes, width)
+        self.backbone = Neck(depth, width, backbone_type=backbone_type, depthwise=depthwise)
+        self.head = Head(num_classes, width, depthwise=depthwise)
         for m in self.modules():                         # init_yolo (yolox_base.py:58-62) reaches every BatchNorm2d
             if isinstance(m, nn.BatchNorm2d):
                 m.eps, m.momentum = 1e-3, 0.03

@@ -333,6 +333,77 @@ def gen_model(utils, models):
          n_params=sum(p.numel() for p in big.parameters()))
 
 
+# --------------------------------------------------------------------------- G19 depthwise variants (DWConv, network_blocks.py:57-76)
+def gen_depthwise(utils, models):
+    """The reference's own DWConv block (depthwise BaseConv + 1x1 BaseConv), a Bottleneck built from it, and the whole network with
+    depthwise=True in backbone, neck and head (darknet.py:107, network_blocks.py:92, yolo_pafpn.py:30, yolo_head_24p.py:45)."""
+    nb = importlib.import_module("models.network_blocks")
+    torch.manual_seed(190)
+
+    def bn_patch(m):
+        for x in m.modules():
+            if isinstance(x, torch.nn.BatchNorm2d):
+                x.eps, x.momentum = 1e-3, 0.03
+                with torch.no_grad():
+                    x.weight.uniform_(0.5, 1.5)
+                    x.bias.uniform_(-0.3, 0.3)
+
+    def run_block(name, mod, x):
+        bn_patch(mod)
+        mod.train()
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        x = x.clone().requires_grad_(True)
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(197))
+        y.backward(gy)
+        store = {"x": x.detach(), "y": y, "gy": gy, "gx": x.grad}
+        for k, v in sd.items():
+            store["w:" + k] = v
+        for k, v in mod.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                store["after:" + k] = v
+        for k, p in mod.named_parameters():
+            store["g:" + k] = p.grad
+        mod.eval()
+        with torch.no_grad():
+            store["y_eval"] = mod(x.detach())
+        save("g19_" + name, **store)
+
+    g = torch.Generator().manual_seed(191)
+    run_block("dwconv3", nb.DWConv(16, 24, 3, 1), torch.randn(2, 16, 12, 12, generator=g))
+    run_block("dwconv3s2", nb.DWConv(16, 32, 3, 2), torch.randn(2, 16, 12, 12, generator=g))
+    run_block("bottleneck_dw", nb.Bottleneck(16, 16, True, 1.0, depthwise=True), torch.randn(2, 16, 10, 10, generator=g))
+    run_block("csp_dw", nb.CSPLayer(16, 16, n=2, depthwise=True), torch.randn(2, 16, 10, 10, generator=g))
+
+    torch.manual_seed(192)
+    in_ch = [256, 512, 1024]
+    model = models.YOLOX(models.YOLOPAFPN(0.33, 0.125, in_channels=in_ch, depthwise=True, act="silu"),
+                         models.YOLOXHead(80, 0.125, in_channels=in_ch, act="silu", depthwise=True))
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    model.head.initialize_biases(1e-2)
+    model.train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(193)) * 255.0
+    xs, ys, st, out, orig = model(x, train=True)
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(194)) * 1e-3
+    out.backward(gy)
+    store = {"x": x, "out": out, "gy": gy, "n_params": sum(p.numel() for p in model.parameters()),
+             "keys": np.array(list(sd.keys())), "shapes": np.array([str(tuple(v.shape)) for v in sd.values()])}
+    for k, v in sd.items():
+        store["w:" + k] = v
+    named = dict(model.named_parameters())
+    for k in ("backbone.backbone.dark3.0.dconv.conv.weight", "backbone.backbone.dark3.0.pconv.conv.weight",
+              "backbone.backbone.dark4.1.m.0.conv2.dconv.conv.weight", "backbone.bu_conv2.dconv.conv.weight",
+              "head.cls_convs.0.0.dconv.conv.weight", "head.reg_convs.1.1.pconv.bn.weight", "backbone.backbone.stem.conv.conv.weight"):
+        store["g:" + k] = named[k].grad
+    model.eval()
+    with torch.no_grad():
+        store["out_eval"] = model(x, train=False)
+    save("g19_model_dw_tiny", **store)
+
+
 # --------------------------------------------------------------------------- G8 sector warp
 def gen_sector():
     sys.path.insert(0, REF)
@@ -855,7 +926,7 @@ if __name__ == "__main__":
         write_manifest()
         sys.exit(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["geometry", "assign", "model", "sector", "post", "n2", "labels", "input", "resnet", "densenet", "vgg"]
+    which = sys.argv[1:] or ["geometry", "assign", "model", "depthwise", "sector", "post", "n2", "labels", "input", "resnet", "densenet", "vgg"]
     utils, models = load_reference()
     if "geometry" in which:
         gen_geometry(utils, models)
@@ -863,6 +934,8 @@ if __name__ == "__main__":
         gen_assign(utils, models)
     if "model" in which:
         gen_model(utils, models)
+    if "depthwise" in which:
+        gen_depthwise(utils, models)
     if "sector" in which:
         gen_sector()
     if "post" in which:

@@ -1,0 +1,223 @@
+"""The depthwise variants (DWConv, /root/reference/yolox_24p/models/network_blocks.py:57-76; `depthwise=True` of CSPDarknet /
+Bottleneck / YOLOPAFPN / YOLOXHead: darknet.py:107, network_blocks.py:92, yolo_pafpn.py:30, yolo_head_24p.py:45) on the GPU: the
+three depthwise kernels through the C ABI against torch fp32 on the same bf16 operands, the modules against the reference's own
+vectors (G19, tests/golden/make_golden.py gen_depthwise), the whole depthwise network's forward / backward / eval against G19, and
+a training step's properties.  Tolerances: bf16 storage of every activation (2^-8 relative per stored tensor)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import t
+from ep24 import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("B,H,W,C,s", [(2, 12, 12, 16, 1), (2, 12, 12, 16, 2), (3, 20, 28, 64, 1), (3, 20, 28, 64, 2), (1, 9, 7, 8, 1),
+                                        (2, 16, 16, 200, 2), (20, 40, 40, 256, 1), (4, 80, 80, 128, 2), (1, 6, 6, 2304, 1)])
+def test_dwconv_kernels_vs_torch(B, H, W, C, s):
+    from ep24._lib import call, lib, ptr, stream_ptr as sp
+    x = rnd(B, C, H, W, seed=1)
+    w = torch.randn(C, 1, 3, 3, generator=torch.Generator().manual_seed(2)) * 0.3
+    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, 1, 1, C)
+    OH, OW = y_ref.shape[2:]
+    gy = rnd(B, C, OH, OW, seed=3)
+    y_ref.backward(gy.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.reshape(C, 9).contiguous().to(DEV)                      # the master layout [C][kh][kw]
+    R = 8
+    stats = torch.zeros(R, 2, C, dtype=torch.int64, device=DEV)
+    z = torch.zeros(B, OH, OW, C, dtype=BF, device=DEV)
+    call("dwconv_fwd_bf16", ptr(xd), C, ptr(wd), ptr(z), C, ptr(stats), R, B, H, W, C, 3, s, sp())
+    want = y_ref.detach().permute(0, 2, 3, 1)
+    assert rel_err(z, want) < 1e-2
+    st = stats.sum(0).double().cpu() / 2 ** 20
+    assert rel_err(st[0], want.double().sum((0, 1, 2))) < 2e-3 + 1e-3 and rel_err(st[1], (want.double() ** 2).sum((0, 1, 2))) < 1e-2
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = torch.full((B, H, W, C), 9.0, dtype=BF, device=DEV)
+    call("dwconv_dgrad_bf16", ptr(gyd), C, ptr(wd), ptr(dx), C, 0, B, H, W, C, 3, s, sp())
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-2
+    base = rnd(B, H, W, C, seed=4).to(DEV)
+    dx2 = base.clone()
+    call("dwconv_dgrad_bf16", ptr(gyd), C, ptr(wd), ptr(dx2), C, 1, B, H, W, C, 3, s, sp())
+    assert rel_err(dx2, xr.grad.permute(0, 2, 3, 1) + base.float().cpu()) < 1.5e-2
+    splits = lib().fn["ep24_dwconv_wgrad_splits"](B, H, W, C, s)
+    assert 1 <= splits <= 256
+    slab = torch.full((splits, C, 9), 7.0, device=DEV)
+    call("dwconv_wgrad_slab_bf16", ptr(xd), C, ptr(gyd), C, ptr(slab), slab.numel(), B, H, W, C, 3, s, sp())
+    assert rel_err(slab.sum(0), wr.grad.reshape(C, 9)) < 2e-3
+    slab2 = torch.zeros_like(slab)                                   # partial sums in a fixed order: bitwise reproducible
+    call("dwconv_wgrad_slab_bf16", ptr(xd), C, ptr(gyd), C, ptr(slab2), slab2.numel(), B, H, W, C, 3, s, sp())
+    assert torch.equal(slab, slab2)
+
+
+def test_dwconv_refuses_what_it_does_not_take():
+    from ep24._lib import lib, ptr, stream_ptr as sp
+    fn = lib().fn
+    a = torch.zeros(4096, dtype=BF, device=DEV)
+    f = torch.zeros(4096, device=DEV)
+    assert fn["ep24_dwconv_fwd_bf16"](ptr(a), 16, ptr(f), ptr(a), 16, None, 1, 1, 4, 4, 16, 5, 1, sp()) != 0 and "3x3" in lib().last_error()
+    assert fn["ep24_dwconv_fwd_bf16"](ptr(a), 12, ptr(f), ptr(a), 12, None, 1, 1, 4, 4, 12, 3, 1, sp()) != 0
+    assert fn["ep24_dwconv_wgrad_slab_bf16"](ptr(a), 16, ptr(a), 16, ptr(f), 8, 1, 4, 4, 16, 3, 1, sp()) != 0 and "slab" in lib().last_error()
+
+
+def _block(name):
+    from ep24 import nn as enn
+    return {"dwconv3": lambda: enn.DWConv(16, 24, 3, 1), "dwconv3s2": lambda: enn.DWConv(16, 32, 3, 2),
+            "bottleneck_dw": lambda: enn.Bottleneck(16, 16, True, 1.0, depthwise=True),
+            "csp_dw": lambda: enn.CSPLayer(16, 16, n=2, depthwise=True)}[name]()
+
+
+@pytest.mark.parametrize("name", ["dwconv3", "dwconv3s2", "bottleneck_dw", "csp_dw"])
+def test_depthwise_block_vs_reference_golden(golden, name):
+    """module(x), autograd through it, the BatchNorm buffers it leaves and its eval-mode forward against the reference's own module (G19)."""
+    z = golden("g19_" + name)
+    mod = _block(name)
+    mod.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    mod.to(DEV)
+    x = t(z["x"]).to(DEV).requires_grad_(True)
+    y = mod(x)
+    assert y.shape == z["y"].shape and rel_err(y, t(z["y"])) < 2.5e-2, rel_err(y, t(z["y"]))
+    y.backward(t(z["gy"]).to(DEV))
+    assert rel_err(x.grad, t(z["gx"])) < 4e-2, rel_err(x.grad, t(z["gx"]))
+    from test_gpu_engine import cos
+    for k, p in mod.named_parameters():
+        # (the two-Bottleneck CSP layer normalises 200 values per channel six times over: a gradient's bf16 noise grows with the
+        # BatchNorm layers behind it - direction and size are asserted there, the single blocks to 5 %)
+        e, c = rel_err(p.grad, t(z["g:" + k])), cos(p.grad, t(z["g:" + k]))
+        assert (e < 5e-2) if name != "csp_dw" else (e < 0.2 and c > 0.995), (k, e, c)
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            assert rel_err(v, t(z["after:" + k])) < 1e-2, k
+        if "num_batches" in k:
+            assert int(v) == int(z["after:" + k])
+
+
+def _model(z=None):
+    from ep24 import nn as enn
+    m = enn.YOLOX(enn.YOLOPAFPN(0.33, 0.125, depthwise=True), enn.YOLOXHead(80, 0.125, depthwise=True))
+    if z is not None:
+        m.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    return m.to(DEV)
+
+
+def test_depthwise_model_vs_reference_golden(golden):
+    """The whole network with depthwise=True in backbone, neck and head: the reference's state-dict keys and shapes, its train-mode
+    outputs, gradients of depthwise and pointwise weights at every depth, and its eval-mode outputs (G19; width 0.125 at 64 x 64: the
+    last level normalises over 8 values, so bf16 storage noise is amplified - direction-level agreement, as for the dense tiny model)."""
+    from test_gpu_engine import cos
+    z = golden("g19_model_dw_tiny")
+    m = _model(z)
+    ref = {str(k): str(s) for k, s in zip(z["keys"], z["shapes"])}
+    assert {k: str(tuple(v.shape)) for k, v in m.state_dict().items()} == ref
+    assert sum(p.numel() for p in m.parameters()) == int(z["n_params"])
+    x = t(z["x"]).to(DEV)
+    m.train()
+    out = m(x, train=True)[3]
+    want = t(z["out"])
+    assert out.shape == want.shape
+    # (twice the BatchNorm layers of the dense tiny model in front of the same 8-value last level: 0.98 where that test asks 0.99)
+    assert cos(out[..., :2], want[..., :2]) > 0.98 and cos(out[..., 26:], want[..., 26:]) > 0.98
+    assert cos(torch.log(out[..., 2:26]), torch.log(want[..., 2:26])) > 0.9
+    out.backward(t(z["gy"]).to(DEV))
+    named = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith("g:"):
+            g, w = named[k[2:]].grad, t(z[k])
+            assert g.shape == w.shape and torch.isfinite(g).all() and float(g.abs().max()) > 0, k
+    m.eval()
+    with torch.no_grad():
+        ev = m(x, train=False)
+    we = t(z["out_eval"])
+    assert ev.shape == we.shape and cos(ev[..., :2], we[..., :2]) > 0.99 and cos(ev[..., 26:], we[..., 26:]) > 0.98
+
+
+def _act(a):
+    return a.buf.t.view(a.buf.rows, a.buf.ld)[:, a.c0:a.c0 + a.C].reshape(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).float().cpu()
+
+
+def test_every_depthwise_and_pointwise_unit_vs_oracle_on_the_plans_own_inputs():
+    """As tests/test_gpu_engine.py does for the dense network: whole-net closeness of a random-init deep BatchNorm net says little, so
+    every conv unit of the depthwise plan - the depthwise ones and the 1x1 ones behind them included - is checked in isolation: the
+    oracle unit (pinned to the reference by G19; bf16-storage emulation) gets the plan's OWN input activation and must reproduce the
+    plan's output to bf16 rounding."""
+    from oracle import model as om
+    from ep24 import nn as enn
+    torch.manual_seed(3)
+    ref = om.Net(0.33, 0.25, depthwise=True)
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
+            torch.nn.init.uniform_(mod.bias, -0.2, 0.2)
+    m = enn.YOLOX(enn.YOLOPAFPN(0.33, 0.25, depthwise=True), enn.YOLOXHead(80, 0.25, depthwise=True))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m.to(DEV)
+    B, S = 4, 256
+    out = m(synth.make_images(B, S, seed=9).to(DEV), train=True)[3]
+    assert torch.isfinite(out).all()
+    eng = m.engine(B, S)
+    rmods, mmods = dict(ref.named_modules()), dict(m.named_modules())
+    names = {mod: n for n, mod in m.named_modules()}
+    ref.train()
+    om.EMULATE_BF16 = True
+    n_dw = 0
+    try:
+        with torch.no_grad():
+            for mod, (xin, z, y) in eng.unit_acts.items():
+                n = names[mod]
+                if n.endswith("stem.conv"):
+                    continue                                  # the Focus stem: covered by its block test
+                want = rmods[n](_act(xin))
+                if n.endswith(".conv2.pconv"):                # a Bottleneck's DWConv: the shortcut is added behind its 1x1 unit
+                    blk = n[:-len(".conv2.pconv")]
+                    if isinstance(rmods.get(blk), om.Res) and rmods[blk].add:
+                        want = want + _act(eng.unit_acts[mmods[blk].conv1][0])
+                n_dw += n.endswith("dconv")
+                e = rel_err(_act(y), want)
+                assert e < 1.2e-2, (n, e)
+    finally:
+        om.EMULATE_BF16 = False
+    assert n_dw >= 20, n_dw
+
+
+def test_depthwise_training_step_properties():
+    """A depthwise YOLOX-s sized network (depth 0.33, width 0.5) through the captured training step at 320 x 320: finite loss that
+    falls on a repeated batch, gradients that reach every parameter (depthwise weights included), and two runs from the same state
+    bit-identical - loss and every parameter (slab-ordered depthwise weight gradients, fixed-point statistics)."""
+    from ep24 import loss as eloss, nn as enn, train as etrain
+
+    def run():
+        torch.manual_seed(0)
+        m = enn.YOLOX(enn.YOLOPAFPN(0.33, 0.5, depthwise=True), enn.YOLOXHead(80, 0.5, depthwise=True)).to(DEV)
+        m.head.initialize_biases(1e-2)
+        ts = etrain.TrainStep(m, eloss.Loss_Function(80), lr=0.01, momentum=0.9, batch=4, size=320)
+        ts.eng.images.copy_(synth.make_images(4, 320, seed=1).to(DEV))
+        ts.labels.copy_(synth.make_labels(4, 3, size=320, seed=1000).to(DEV))
+        losses = [float(ts.step()[0]) for _ in range(6)]
+        torch.cuda.synchronize()
+        names = [n for n, _ in ts.eng.fwd] + [n for n, _ in ts.eng.bwd]
+        return losses, ts.home.flat.clone(), ts.home.gflat.clone(), m, names
+
+    la, wa, ga, m, names = run()
+    assert sum(n == "dwconv_fwd_bf16" for n in names) >= 20 and sum(n.endswith("dwconv_wgrad_slab_bf16") for n in names) >= 20
+    assert all(np.isfinite(la)) and la[-1] < la[0], la
+    home = m.__dict__["_ep24_home"]
+    for p in m.parameters():
+        seg = home.by_param[p]
+        assert float(ga[seg.off:seg.off + seg.numel].abs().max()) > 0
+    lb, wb, gb, _, _ = run()
+    assert la == lb and torch.equal(wa, wb) and torch.equal(ga, gb)
