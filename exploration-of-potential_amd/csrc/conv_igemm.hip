@@ -687,7 +687,10 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     const int n_tiles = ep24_cdiv(a.N, BN);
     const long n_groups = (a.M + RG - 1) / RG;
     // ~2 workgroups per CU in total, a multiple of 8 per N tile (XCD mapping), never more than there are row groups
-    long bpn = (512 / n_tiles + 7) / 8 * 8;
+#ifndef EP24_STREAM_WGS
+#define EP24_STREAM_WGS 512
+#endif
+    long bpn = (EP24_STREAM_WGS / n_tiles + 7) / 8 * 8;
     if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
     constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;          // as in the kernel: all panels its K steps touch
     size_t lds = (size_t)NPAN * BN * 128;
