@@ -28,6 +28,15 @@ for line in open(sys.argv[1]):
             byts += 0  # slab stores / reads are the split scheme's, not the algorithm's
         c = conv[("1x1" if k == 1 else "3x3 s%d" % s)]
         c[0] += n; c[1] += ms; c[2] += byts; c[3] += flops
+    elif f[0].startswith("conv1x1_"):
+        # a 1x1 unit together with the BatchNorm pass in front of it (round 5): forward reads z (+ shortcut, not counted), stores y and
+        # the conv output; backward reads dy and z, stores dz and the input gradient
+        B, H, W, Ci, Co = map(int, f[1:6])
+        M = B * H * W
+        K, N = (Ci, Co) if "bnin" in f[0] else (Co, Ci)
+        byts = 2.0 * ((2 if "bnin" in f[0] else 3) * M * K + M * N + N * K) * n
+        c = conv["1x1 + BN pass"]
+        c[0] += n; c[1] += ms; c[2] += byts; c[3] += 2.0 * M * N * K * n
     elif sec == 1:
         name, a = f[0], [int(v) for v in f[1:]]
         o = other[name]
@@ -43,10 +52,13 @@ for line in open(sys.argv[1]):
 print("| class | launches | serial ms | algorithmic GB | HBM bound ms (6.3 TB/s) | MFMA bound ms (2 500 TF) | serial / larger bound | (MFMA ms at 900 TF) |")
 print("|---|---|---|---|---|---|---|---|")
 tot = [0, 0.0, 0.0]
-for k in ("1x1", "3x3 s1", "3x3 s2"):
+for k in ("1x1", "1x1 + BN pass", "3x3 s1", "3x3 s2"):
     n, ms, by, fl = conv[k]
+    if not n:
+        continue
     hb, mb = by / HBM * 1e3, fl / MFMA * 1e3
-    print("| conv %s (fwd + dgrad + wgrad) | %d | %.2f | %.2f | %.2f | %.2f | %.2fx | %.2f |" % (k, n, ms, by / 1e9, hb, mb, ms / max(hb, mb), fl / MFMA_OLD * 1e3))
+    print("| conv %s (%s) | %d | %.2f | %.2f | %.2f | %.2f | %.2fx | %.2f |" % (k, "fwd / dgrad with the BatchNorm fwd / bwd-apply pass in the launch" if "BN" in k else "fwd + dgrad + wgrad",
+                                                                            n, ms, by / 1e9, hb, mb, ms / max(hb, mb), fl / MFMA_OLD * 1e3))
     tot[0] += n; tot[1] += ms; tot[2] += max(hb, mb)
 bn = [0, 0.0, 0.0]
 for k in ("bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"):
