@@ -69,6 +69,7 @@ __device__ __forceinline__ void igemm_dma_tile(const IgemmArgs& p, const int til
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wt), 0, p.wt_bytes, 0x00020000);
     int rowoff[A_INSTR];
     unsigned vmask[A_INSTR];
+    int iy0v[A_INSTR], ix0v[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const long m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
@@ -79,14 +80,21 @@ __device__ __forceinline__ void igemm_dma_tile(const IgemmArgs& p, const int til
         const int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
         const int iy0 = gy * p.sy, ix0 = gx * p.sx;
         rowoff[i] = (int)((((long)n * p.SH * p.SW + (long)iy0 * p.SW + ix0) * p.ld_src + lchunk * 8) * 2);
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {         // static trip count: the tap tables arrive with the kernel arguments
-            const int iy = iy0 + p.oy[t], ix = ix0 + p.ox[t];
-            if (t < p.T && rv && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) mk |= 1u << t;
-        }
-        vmask[i] = mk;
+        iy0v[i] = rv ? iy0 : -(1 << 20);       // a row past M fails every tap's test
+        ix0v[i] = ix0;
+        vmask[i] = 0u;
     }
+    // taps outer (their offsets come out of the packed tables with scalar shifts: no load), rows inner; T iterations, not 16
+    const unsigned long long tdy = p.tap_dy, tdx = p.tap_dx, tsl = p.tap_slot;
+    for (int t = 0; t < p.T; ++t) {
+        const int dy = (int)((tdy >> (4 * t)) & 15ull) - 8, dx = (int)((tdx >> (4 * t)) & 15ull) - 8;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int iy = iy0v[i] + dy, ix = ix0v[i] + dx;
+            if (iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW) vmask[i] |= 1u << t;
+        }
+    }
+    const int ld2 = (int)p.ld_src * 2;
     int wvoff[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
@@ -106,8 +114,9 @@ __device__ __forceinline__ void igemm_dma_tile(const IgemmArgs& p, const int til
         if (++is_t == p.T) { is_t = 0; ++is_kc; }
         const bool tail = kc >= ktail;                       // wave-uniform, false for every layer of the YOLOX-l path
         const int ktm = tail ? -(int)(kc < kmax) : -1;
-        const int a_s = p.toff[t] + kc * (BK * 2);
-        const unsigned b_s = (unsigned)((p.wslot[t] * p.K + kc * BK) * 2);
+        const int dy = (int)((tdy >> (4 * t)) & 15ull) - 8, dx = (int)((tdx >> (4 * t)) & 15ull) - 8;
+        const int a_s = (dy * p.SW + dx) * ld2 + kc * (BK * 2);                   // = p.toff[t] + ...: scalar arithmetic, no table load
+        const unsigned b_s = (unsigned)(((int)((tsl >> (4 * t)) & 15ull) * p.K + kc * BK) * 2);
         char* stage = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
@@ -733,6 +742,9 @@ void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
 // The kernels address their operands with 32-bit byte offsets through buffer descriptors (out-of-range = zero fill is how
 // padding and tails work), so every operand extent must stay below 2 GiB and the pixel count below 2^31.
 int check_extents(const IgemmArgs& a) {
+    for (int t = 0; t < a.T; ++t)
+        EP24_REQUIRE(a.T <= 16 && a.oy[t] >= -8 && a.oy[t] <= 7 && a.ox[t] >= -8 && a.ox[t] <= 7 && a.wslot[t] >= 0 && a.wslot[t] <= 15, EP24_E_UNSUPPORTED,
+                     "conv: tap %d (offset %d, %d, weight slot %d) does not fit the packed tap tables (offsets -8 .. 7, slots 0 .. 15)", t, a.oy[t], a.ox[t], a.wslot[t]);
     const long src_b = (((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2;
     const long wt_b = (long)a.N * a.WT * a.K * 2;
     EP24_REQUIRE(src_b < 0x7FFF0000L && wt_b < 0x7FFF0000L && a.M < (1L << 31) && (long)a.B * a.SH * a.SW < (1L << 31), EP24_E_UNSUPPORTED,
@@ -747,7 +759,14 @@ void prepare(IgemmArgs& a, int kernel_opts) {
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
     a.wt_bytes = (unsigned)((long)a.N * a.WT * a.K * 2);
     a.d_plane = make_fastdiv((unsigned)(a.GH * a.GW)); a.d_gw = make_fastdiv((unsigned)a.GW);
-    for (int t = 0; t < a.T; ++t) a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
+    a.tap_dy = a.tap_dx = a.tap_slot = 0ull;
+    for (int t = 0; t < a.T; ++t) {
+        a.toff[t] = (int)(((long)a.oy[t] * a.SW + a.ox[t]) * a.ld_src * 2);
+        // (tap offsets of every conv of the path are -1 .. 1, a weight slot 0 .. 8; check_extents refuses what four bits cannot hold)
+        a.tap_dy |= (unsigned long long)((a.oy[t] + 8) & 15) << (4 * t);
+        a.tap_dx |= (unsigned long long)((a.ox[t] + 8) & 15) << (4 * t);
+        a.tap_slot |= (unsigned long long)(a.wslot[t] & 15) << (4 * t);
+    }
 }
 
 // the classes of a stride-2 input gradient as one launch of the tiled kernel (bf16 output, no bias / statistics)

@@ -23,6 +23,11 @@ struct IgemmArgs {
     // inference epilogue (BatchNorm folded into weights and bias): y = act(acc + bias) + residual
     int epi_act; const bf16* epi_res; long epi_ldres; int epi_infer;
     int toff[16];               // byte offset of tap t relative to the row's (iy0, ix0) pixel
+    // the same tap tables packed four bits per tap (dy + 8, dx + 8, weight slot; prepare()): the tiled kernel takes a tap's offsets
+    // out of these with scalar shifts - indexing oy[] / ox[] / toff[] / wslot[] by a run-time tap is a scalar LOAD from the kernel
+    // arguments, one round trip through the scalar cache per use: 32 of them, one after the other, in its prologue and two between
+    // the barrier and the DMA issue of every K step (round 5)
+    unsigned long long tap_dy, tap_dx, tap_slot;
     unsigned src_bytes, wt_bytes;   // extents for the buffer descriptors of the DMA kernels
     unsigned dst_bytes;             // extent of the destination (streaming kernel: buffer stores)
     FastDiv d_plane, d_gw;          // row index -> (n, gy, gx)
