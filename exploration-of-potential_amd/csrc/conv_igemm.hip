@@ -217,8 +217,15 @@ __global__ __launch_bounds__(256) void igemm_dma_deep_kernel(const IgemmArgs p) 
 // (Round 5 measured two interleaved orders - an XCD running every class of one M tile, or of a chunk of 4 / 8 / 16 M tiles, back to
 // back so that the classes share their dy rows in its L2: 10 - 17 % slower for single tiles, level for chunks.  The launch is not
 // bound by re-reading dy; profiles/r05_s2_ab.txt.  Removed again.)
+// Round 5: the classes of one launch differ in their taps and in the parity offset of their destination pixels, nothing else; the kernel
+// takes ONE argument block and a small per-class table.  (As an array of four full blocks indexed by the run-time class, every field
+// read was a scalar load at a computed address - 326 in the 128-wide kernel, 190 of them inside loops - where the single-problem kernel
+// reads its arguments once at immediate offsets.)
 struct IgemmMulti {
-    IgemmArgs a[4];
+    IgemmArgs a;                                 // class 0's block; T, the packed tap tables and (dy0, dx0) are per class below
+    int T[4];
+    unsigned long long tap_dy[4], tap_dx[4], tap_slot[4];
+    int dy0[4], dx0[4];
     int prefix[5];
     int n;
 };
@@ -230,7 +237,11 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
     for (int c = 1; c < 4; ++c)
         if (c < q.n && (int)blockIdx.x >= q.prefix[c]) cls = c;
     cls = __builtin_amdgcn_readfirstlane(cls);
-    igemm_dma_body<BN, false, 0>(q.a[cls], (int)blockIdx.x - q.prefix[cls], q.prefix[cls + 1] - q.prefix[cls]);
+    IgemmArgs p = q.a;                           // (fields are read where they are used: no copy is made)
+    p.T = q.T[cls];
+    p.tap_dy = q.tap_dy[cls]; p.tap_dx = q.tap_dx[cls]; p.tap_slot = q.tap_slot[cls];
+    p.dy0 = q.dy0[cls]; p.dx0 = q.dx0[cls];
+    igemm_dma_body<BN, false, 0>(p, (int)blockIdx.x - q.prefix[cls], q.prefix[cls + 1] - q.prefix[cls]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -778,9 +789,17 @@ int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
         if (int rc = check_extents(cls[i])) return rc;
         prepare(cls[i], kernel_opts);
         wide = wide && cls[i].N > 64 && (long)ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, 128) > 256;
+        // one argument block for all classes: everything but the taps and the destination parity must agree
+        const IgemmArgs &x = cls[i], &y = cls[0];
+        EP24_REQUIRE(x.src == y.src && x.ld_src == y.ld_src && x.B == y.B && x.SH == y.SH && x.SW == y.SW && x.GH == y.GH && x.GW == y.GW && x.sy == y.sy &&
+                     x.sx == y.sx && x.wt == y.wt && x.WT == y.WT && x.K == y.K && x.N == y.N && x.dst == y.dst && x.ld_dst == y.ld_dst && x.DH == y.DH &&
+                     x.DW == y.DW && x.dsy == y.dsy && x.dsx == y.dsx && x.dbs == y.dbs && x.dp0 == y.dp0 && x.accumulate == y.accumulate && x.M == y.M &&
+                     !x.bias && !x.stats && !x.bnr_z && !x.epi_infer, EP24_E_ARG, "conv_igemm_multi: the classes of one launch share everything but their taps and parity");
     }
+    q.a = cls[0];
     for (int i = 0; i < n; ++i) {
-        q.a[i] = cls[i];
+        q.T[i] = cls[i].T; q.tap_dy[i] = cls[i].tap_dy; q.tap_dx[i] = cls[i].tap_dx; q.tap_slot[i] = cls[i].tap_slot;
+        q.dy0[i] = cls[i].dy0; q.dx0[i] = cls[i].dx0;
         q.prefix[i + 1] = q.prefix[i] + ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, wide ? 128 : 64);
     }
     const unsigned blocks = (unsigned)q.prefix[n];
