@@ -182,6 +182,10 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const bf16* dy, long ld_dy, c
                 vdy[k] = *reinterpret_cast<const bf16x8*>(dy + mm * ld_dy + cg * 8);
                 vz[k] = *reinterpret_cast<const bf16x8*>(z + mm * ld_z + cg * 8);
             }
+            // ... and they STAY in front of the constants: left to itself the scheduler requested the eight constant vectors first, waited
+            // for all of them (their scale / shift arithmetic), and only then issued these eight loads - a second serial round trip in
+            // every block of every reduce launch (round 5, from the ISA)
+            __builtin_amdgcn_sched_barrier(0);
             float sc[8], sh[8], iv[8], mi[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
