@@ -24,8 +24,9 @@ class PlanOptions:
     capture_side: bool = False         # cross-stream edges inside captured graphs (experimental; faulted on ROCm 7.2)
     fold_bn_eval: bool = True          # eval mode: BatchNorm folded into the conv (one launch per unit)
     conv_kernel_opts: int = 0          # bit 0: 3x3 stride-1 layers through the generic tiled kernel, bit 1: 8-byte epilogue stores
-    wgrad_group_steps: int = 90        # 64-pixel steps a workgroup of a grouped weight-gradient launch keeps at least (swept again at the end of round 5,
-                                       # when the lane had become co-critical: 60 / 75 / 90 / 100 / 120 / 160 / 250 -> 19.94 / 19.55 / 19.41 / 19.44 / 19.44 / 19.58 / 19.77 ms)
+    wgrad_group_steps: int = 100       # 64-pixel steps a workgroup of a grouped weight-gradient launch keeps at least (swept again at the end of round 5,
+                                       # when the lane had become co-critical: 60 / 75 / 90 / 100 / 120 / 160 / 250 -> 19.94 / 19.55 / 19.41 / 19.44 / 19.44 / 19.58 / 19.77 ms
+                                       # for the headline network; 90 costs the VGG backbone 7 % (484 against 521 - 523 images/s at 100 / 120): 100)
     group_wgrad: bool = True           # weight gradients of a backward segment's layers as grouped launches per tile class (round 5)
     fuse_bn_reduce: bool = False       # a 3x3 stride-1 input gradient that is the only consumer of the unit below takes that unit's
                                        # BatchNorm-backward sums in its epilogue (no reduce launch for it).  Measured slower in the step
