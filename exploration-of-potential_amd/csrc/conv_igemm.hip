@@ -273,20 +273,29 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
 //   1 / 2  A = y = silu(bn(z)) (2: + residual row), z = p.src = the producing unit's raw output; y is stored to p.xf_out as
 //          bn_act_fwd would have stored it (same expressions, same rounding: the rows the MFMAs read are the stored bf16 values)
 //   3      A = dz = bn_act_bwd_apply(dy = p.src, z = p.xf_aux); dz is stored to p.xf_out for the weight gradient
+//   4      the rows as they are, in the 16-row block structure of the other forms (the BNR input gradients: their epilogue's extra
+//          rows and sums do not fit beside 32-row blocks - 430 - 600 bytes of scratch in the loop)
 // Per-channel constants are folded from the fixed-point sums by every workgroup into LDS behind the weight tile (as the BatchNorm
 // kernels' prologues do); block 0 also does those kernels' block-0 duties.  Host: N <= BN (one N tile: every row is made once).
-template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false, int XF = 0>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+// BNR (round 5, input-gradient forms): what the kernel stores is the dy of the unit BELOW (the previous Bottleneck's conv2, whose output
+// this 1x1 conv read; with a shortcut the stored value is old + new, i.e. the complete gradient), so the two sums of that unit's
+// BatchNorm backward - sum(du), sum(du * zhat), du = dy * silu'(bn(z)) - are taken from the rows while they leave, with the reduce
+// kernel's expressions on the ROUNDED values it would have read; its launch (dy and z read once more, one dependent launch) goes.
+// The sums' fp32 order differs from the reduce kernel's (per-lane partial sums, then the statistics fold): same values to fp32 rounding.
+template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false, int XF = 0, bool BNR = false>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     // 4 waves x 32 rows per row group.  The transformed-A forms walk a wave's 32 rows as two blocks of 16 (XS = 2 sub-blocks: their
     // second source row and the constants need the registers - with 32 rows per block the loop spilled, and a scratch access in the
     // loop turns every counted wait into vmcnt(0)); the rows a lane owns and the order it adds them to the BatchNorm statistics are
     // the plain kernel's, so the statistics are bit-identical as well.
     constexpr int SP = BN / 64, NTW = SP * 4, MT = XF ? 1 : 2, XS = XF ? 2 : 1, RG = 128;
-    static_assert(XF == 0 || H == 1, "the transformed-A forms make one K pass");
+    static_assert(XF == 0 || XF == 4 || H == 1, "the transformed-A forms make one K pass");
+    static_assert(!BNR || (EPI == 0 && !GATHER && XF == 4), "the fused reduce belongs to the plain input-gradient form in 16-row blocks (with the transformed-A form it doubled that form's VALU work and spilled: measured, not kept)");
     constexpr int OOB = 0x7FFFFFF0;
     constexpr bool XAUX = XF >= 2;                                            // a second source row beside p.src
-    constexpr int XNC = XF == 3 ? 5 : 2;                                      // constants per channel: (sc, sh) / (sc, sh, k1, k2, k3)
+    constexpr int XNC = XF == 3 ? 5 : XF == 4 ? 0 : 2;                        // constants per channel: (sc, sh) / (sc, sh, k1, k2, k3) / none (XF 4: the rows as they are)
     constexpr int XKP = H * 128;                                              // channels the K steps touch
+    constexpr int XC_FLOATS = XF ? XNC * XKP : 0;                            // floats of transformed-A constants behind the weight tile
     static_assert(XF == 0 || (EPI == 0 && !GATHER), "the transformed-A forms are training forms of the plain 1x1 kernel");
     constexpr int NPAN_ = (H - 1) * 2 + (NKS + 1) / 2;                        // 64-channel weight panels in LDS (NPAN below)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,11 +330,12 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
     }
     [[maybe_unused]] const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(XAUX ? p.xf_aux : p.src), 0, XAUX ? p.xf_aux_bytes : 0u, 0x00020000);
     [[maybe_unused]] const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(XF ? p.xf_out : (bf16*)p.dst, 0, XF ? p.xf_out_bytes : 0u, 0x00020000);
+    [[maybe_unused]] const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(BNR ? p.bnr_z : p.src), 0, BNR ? p.bnr_z_bytes : 0u, 0x00020000);
     // every load is issued: a row past M (also every row of a unit past the last one) and a K step past K read zeros
     auto load = [&](bf16x8 (&A)[MT][NKS], [[maybe_unused]] bf16x8 (&X)[XAUX ? MT : 1][XAUX ? NKS : 1], long u) {
         const long g = rb + (u / (H * XS)) * bpn;
         const int h = (int)(u % H);
-        const long r0 = g * RG + wave * 32 + (XF ? (int)(u % XS) * 16 : 0);
+        const long r0 = g * RG + wave * 32 + (XF ? (int)((u / H) % XS) * 16 : 0);
         if constexpr (GATHER) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
     // HH: which K half this block is (compile time: in the two-block loop body block 0 is half 0 and block 1 half H - 1)
     auto compute = [&](bf16x8 (&A)[MT][NKS], [[maybe_unused]] bf16x8 (&X)[XAUX ? MT : 1][XAUX ? NKS : 1], long u, auto hh) {
         constexpr int h = decltype(hh)::value;
-        if constexpr (XF != 0) {
+        if constexpr (XF != 0 && XF != 4) {
             // the BatchNorm pass on the rows in flight: constants of a lane's 8 channels per K step from LDS (the 16 lanes of a
             // quarter read the same words: broadcast), rows >= M become zeros (they must add nothing to this unit's statistics)
             const float* xc = reinterpret_cast<const float*>(smem + NPAN_ * (BN * 128));
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
         }
         if constexpr (h != H - 1) return;
         const long g = rb + (u / (H * XS)) * bpn;
-        const long r0 = g * RG + wave * 32 + (XF ? (int)(u % XS) * 16 : 0);
+        const long r0 = g * RG + wave * 32 + (XF ? (int)((u / H) % XS) * 16 : 0);
         if constexpr (infer) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -487,21 +497,38 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 v2u old[4][SP];
+                [[maybe_unused]] v2u zb[BNR ? 4 : 1][BNR ? SP : 1];
                 if constexpr (ACC) {                         // the old values of this 16-row block are requested before the first is needed
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int sp = 0; sp < SP; ++sp) old[r][sp] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff(i, r, sp), 0, 0);
                 }
+                if constexpr (BNR) {                         // ... and the z rows of the unit below (a row >= M: out of range, zeros)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int sp = 0; sp < SP; ++sp) {
+                        for (int sp = 0; sp < SP; ++sp) {
+                            const long m = r0 + i * 16 + 4 * fq + r;
+                            const int c0 = n0 + sp * 64 + 4 * frow;
+                            zb[r][sp] = __builtin_amdgcn_raw_buffer_load_b64(zrsrc, (m < p.M && c0 < p.N) ? (int)((m * p.bnr_ldz + c0) * 2) : OOB, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp) {
+                    [[maybe_unused]] f32x4 kb[BNR ? 4 : 1];  // the unit below's (sc, sh, invstd, mean * invstd) of this lane's four channels
+                    if constexpr (BNR) {
+                        const float* bc = reinterpret_cast<const float*>(smem + NPAN_ * (BN * 128)) + XC_FLOATS;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) kb[q] = *reinterpret_cast<const f32x4*>(bc + q * BN + sp * 64 + 4 * frow);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
                         float v[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             v[q] = acc[i][sp * 4 + q][r];
-                            if constexpr (XF != 3) { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }     // (an input gradient has no statistics)
+                            if constexpr (XF != 3 && !BNR) { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }     // (an input gradient has no statistics)
                         }
                         if constexpr (ACC) {
                             const bf16x4 o = __builtin_bit_cast(bf16x4, old[r][sp]);
@@ -512,7 +539,18 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
 #pragma unroll
                         for (int q = 0; q < 4; ++q) w[q] = (bf16)v[q];
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, w), drsrc, voff(i, r, sp), 0, 0);
+                        if constexpr (BNR) {                 // bn_bwd_reduce_body's expressions on the rounded dy (s1: sum du, s2: sum du * zhat)
+                            const bf16x4 zz4 = __builtin_bit_cast(bf16x4, zb[r][sp]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float zz = (float)zz4[q];
+                                const float du = (float)w[q] * act_grad(fmaf(zz, kb[0][q], kb[1][q]), 1);
+                                s1[sp * 4 + q] += du;
+                                s2[sp * 4 + q] = fmaf(du, fmaf(zz, kb[2][q], -kb[3][q]), s2[sp * 4 + q]);
+                            }
+                        }
                     }
+                }
             }
         }
     };
@@ -654,6 +692,21 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
             for (int q = 0; q < 5; ++q) xc[q * XKP + c] = v_[q];
         }
     }
+    if constexpr (BNR) {
+        // the unit below's constants for this N tile's channels, four arrays of BN floats: scale, shift (as its forward made them),
+        // invstd, mean * invstd
+        float* bc = reinterpret_cast<float*>(smem + NPAN * (BN * 128)) + XC_FLOATS;
+        for (int c = tid; c < BN; c += 256) {
+            const int ch = n0 + c;
+            float k_[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ch < p.N) {
+                const float mean = p.bnr_mean[ch], inv = p.bnr_invstd[ch], g = p.bnr_gamma[ch], bt = p.bnr_beta[ch];
+                k_[0] = g * inv; k_[1] = bt - mean * k_[0]; k_[2] = inv; k_[3] = mean * inv;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q * BN + c] = k_[q];
+        }
+    }
     if constexpr (!GATHER) {
 #pragma unroll
         for (int it = 0; it < NWT; ++it) {
@@ -675,7 +728,7 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
         compute(A1, X1, u + 1, std::integral_constant<int, H - 1>{});
     }
 
-    if (p.stats) {
+    if (BNR || p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][BN]; the weight tile is no longer needed
 #pragma unroll
@@ -690,18 +743,24 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
             }
         }
         __syncthreads();
-        long long* st = p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        [[maybe_unused]] long long* st = BNR ? nullptr : p.stats + (long)(blockIdx.x % p.stats_replicas) * 2 * p.N;
+        [[maybe_unused]] const long rep = BNR ? (long)(blockIdx.x % p.bnr_reps) * p.bnr_rep_stride : 0;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v += red[(r * 2 + which) * BN + c];
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+            if (n0 + c < p.N) {
+                if constexpr (BNR)     // s1 = sum du -> the beta sum, s2 = sum du * zhat -> the gamma sum (2^-36 fixed point, as bn_act_bwd_reduce)
+                    atomicAdd((unsigned long long*)((which ? p.bnr_dgamma : p.bnr_dbeta) + rep + n0 + c), (unsigned long long)to_fix_g(v));
+                else
+                    atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+            }
         }
     }
 }
 
-template <int BN, int H, int NKS, bool GATHER = false, int XF = 0>
+template <int BN, int H, int NKS, bool GATHER = false, int XF = 0, bool BNR = false>
 void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     constexpr int RG = 128;                                    // rows per workgroup and row group, as in the kernel
     const int n_tiles = ep24_cdiv(a.N, BN);
@@ -713,14 +772,13 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
     long bpn = (EP24_STREAM_WGS / n_tiles + 7) / 8 * 8;
     if (bpn > (n_groups + 7) / 8 * 8) bpn = (n_groups + 7) / 8 * 8;
     constexpr int NPAN = (H - 1) * 2 + (NKS + 1) / 2;          // as in the kernel: all panels its K steps touch
-    size_t lds = (size_t)NPAN * BN * 128;
+    // the weight tile + the per-channel constants of the transformed-A forms + the unit below's constants of the BNR forms
+    size_t lds = (size_t)NPAN * BN * 128 + (size_t)(XF == 3 ? 5 * H * 128 : (XF == 1 || XF == 2) ? 2 * H * 128 : 0) * sizeof(float) + (size_t)(BNR ? 4 * BN : 0) * sizeof(float);
     if (lds < 4096) lds = 4096;                                // the statistics fold: [4 waves][2][BN] floats
-    if (XF) lds = (size_t)NPAN * BN * 128 + (size_t)(XF == 3 ? 5 : 2) * H * 128 * sizeof(float);      // + the per-channel constants
-    if (XF && lds < 4096) lds = 4096;
     const dim3 grid((unsigned)(bpn * n_tiles));
-    if constexpr (XF == 3) {                                   // the input gradient may be a second writer of its destination
-        if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
-        else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
+    if constexpr (XF == 3 || BNR) {                            // input gradients: possibly a second writer of their destination
+        if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true, false, XF, BNR>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, false, XF, BNR>), grid, dim3(256), lds, stream, a, (int)bpn);
     } else if constexpr (XF != 0) {
         hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, false, XF>), grid, dim3(256), lds, stream, a, (int)bpn);
     } else if constexpr (GATHER) {
@@ -738,6 +796,12 @@ template <int XF>
 void launch_stream_xf(const IgemmArgs& a, hipStream_t stream) {               // K <= 128 (xf_shape_ok)
     if (a.N > 64) { if (a.K > 64) launch_stream<128, 1, 4, false, XF>(a, stream); else launch_stream<128, 1, 2, false, XF>(a, stream); }
     else          { if (a.K > 64) launch_stream<64, 1, 4, false, XF>(a, stream); else launch_stream<64, 1, 2, false, XF>(a, stream); }
+}
+
+// the plain kernel's shapes with the fused reduce (input gradients of 1x1 stride-1 convs with K <= 256): the 16-row block form (XF 4)
+void launch_stream_bnr(const IgemmArgs& a, hipStream_t stream) {
+    if (a.N > 64) { if (a.K > 128) launch_stream<128, 2, 4, false, 4, true>(a, stream); else if (a.K > 64) launch_stream<128, 1, 4, false, 4, true>(a, stream); else launch_stream<128, 1, 2, false, 4, true>(a, stream); }
+    else          { if (a.K > 128) launch_stream<64, 2, 4, false, 4, true>(a, stream); else if (a.K > 64) launch_stream<64, 1, 4, false, 4, true>(a, stream); else launch_stream<64, 1, 2, false, 4, true>(a, stream); }
 }
 
 // Shapes the transformed-A forms take: what the plain streaming kernel takes with K <= 128 (one K pass) and N in one tile.
@@ -820,15 +884,26 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     prepare(a, kernel_opts);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     const long dst_b = ((a.M - 1) * a.ld_dst + a.N) * 2;     // the streaming kernel stores through a buffer descriptor (32-bit offsets)
-    if (a.bnr_z) {      // the fused BatchNorm-backward reduction lives in the 16-byte store path of the shared epilogue
+    const bool stream_ok = a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW &&
+                           (a.K <= 128 || (a.K <= 256 && (a.M >= 100000 || !(kernel_opts & KOPT_TILED256)))) && !out_f32 && (!a.bias || a.epi_infer) && plain_dst &&
+                           a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L;
+    if (a.bnr_z && !stream_ok) {      // the fused BatchNorm-backward reduction lives in the 16-byte store path of the shared epilogue
         EP24_REQUIRE(plain_dst && !out_f32 && !a.accumulate && !a.narrow_epi && !a.bias && !a.epi_infer && a.N % 8 == 0 && a.ld_dst % 8 == 0 &&
                      a.bnr_ldz % 8 == 0 && ((reinterpret_cast<unsigned long long>(a.dst) | reinterpret_cast<unsigned long long>(a.bnr_z)) & 15) == 0 &&
                      a.bnr_reps > 0, EP24_E_ARG, "conv_dgrad_bnr: needs a plain, first-writer bf16 destination with channel counts / strides in multiples of 8");
     }
-    if (!a.bnr_z && a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW && (a.K <= 128 || (a.K <= 256 && (a.M >= 100000 || !(kernel_opts & KOPT_TILED256)))) && !out_f32 &&
-        (!a.bias || a.epi_infer) && plain_dst && a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L) {
+    if (stream_ok) {
         if (dry) { *kernel_id = 2; return EP24_OK; }
         a.dst_bytes = (unsigned)dst_b;
+        if (a.bnr_z) {                 // the fused reduce of the unit below: the streaming kernel's own form of it (round 5)
+            const long z_b = ((a.M - 1) * a.bnr_ldz + a.N) * 2;
+            EP24_REQUIRE(!a.stats && !a.epi_infer && a.bnr_reps > 0 && a.bnr_ldz % 4 == 0 && z_b < 0x7FFF0000L && a.bnr_act == 1, EP24_E_ARG,
+                         "conv_dgrad_bnr (1x1): an input gradient of a SiLU unit, z rows 8-byte aligned, operands below 2 GiB");
+            a.bnr_z_bytes = (unsigned)z_b;
+            launch_stream_bnr(a, stream);
+            EP24_LAUNCH_CHECK("ep24_conv_igemm_stream_bnr");
+            return EP24_OK;
+        }
         // 128-wide tiles where N fills them (a 256-wide tile - one pass of the rows for N = 256 - needs 400 registers and a whole CU
         // per workgroup: 68 against 50 us on 80x80x256->256 with cold operands, tools/stream_ab.py)
         // K steps of 32 per K half: 2 for K <= 64, else 4 (a K tail is zero-filled on both operands)
@@ -1174,7 +1249,24 @@ extern "C" int ep24_conv1x1_dgrad_bnbwd_bf16(const void* dy, int64_t ld_dy, cons
     return EP24_OK;
 }
 
+
 static int kernel_for_impl(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias, int kernel_opts);
+
+// The same for a 1x1 stride-1 conv of the streaming kernel (K <= 256), which may be a SECOND writer of dx (a Bottleneck's conv1 over a
+// shortcut: what it stores, old + new, is the complete gradient of the unit below): `accumulate` as in ep24_conv_dgrad_bf16.
+extern "C" int ep24_conv1x1_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W,
+                                           int Cin, int Cout_k, const void* z, int64_t ld_z, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, int64_t rep_stride, int reps,
+                                           int act, void* stream) {
+    EP24_REQUIRE(z && mean && invstd && gamma && beta && dgamma && dbeta, EP24_E_ARG, "conv1x1_dgrad_bnr: null pointer");
+    int kid = -1;
+    if (int rc = conv_dgrad_impl(nullptr, ld_dy, nullptr, nullptr, ld_dx, accumulate, B, H, W, Cin, Cout_k, 1, 1, 0, nullptr, true, &kid)) return rc;
+    EP24_REQUIRE(kid == 2, EP24_E_UNSUPPORTED, "conv1x1_dgrad_bnr: Cin=%d Cout=%d is not a layer of the streaming kernel (Cout <= 256)", Cin, Cout_k);
+    IgemmArgs b{};
+    b.bnr_z = (const bf16*)z; b.bnr_ldz = ld_z; b.bnr_mean = mean; b.bnr_invstd = invstd; b.bnr_gamma = gamma; b.bnr_beta = beta;
+    b.bnr_dgamma = (long long*)dgamma; b.bnr_dbeta = (long long*)dbeta; b.bnr_rep_stride = rep_stride; b.bnr_reps = reps; b.bnr_act = act;
+    return conv_dgrad_impl(dy, ld_dy, wt, dx, ld_dx, accumulate, B, H, W, Cin, Cout_k, 1, 1, 0, stream, false, nullptr, &b);
+}
 
 extern "C" int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias) {
     return kernel_for_impl(dgrad, B, H, W, Cin, Cout, ksize, stride, y_f32, has_bias, 0);

@@ -38,6 +38,7 @@ struct IgemmArgs {
     // kernel read dy and z once more for them.  [reps][..] fixed-point sums, replica stride bnr_rep_stride, as bn_act_bwd_reduce.
     const bf16* bnr_z; long bnr_ldz; const float* bnr_mean; const float* bnr_invstd; const float* bnr_gamma; const float* bnr_beta;
     long long* bnr_dgamma; long long* bnr_dbeta; long bnr_rep_stride; int bnr_reps; int bnr_act;
+    unsigned bnr_z_bytes;           // extent of bnr_z for the streaming kernel's buffer loads (its BNR forms, round 5)
     // Streaming 1x1 kernel with a TRANSFORMED A operand (igemm_stream_kernel<XF>, round 5): the rows it multiplies are not stored yet.
     // It makes them from what the BatchNorm pass in front of it would have read, stores them where that pass would have, and multiplies
     // them - one dependent launch and one read of the rows less, the same values bit for bit.

@@ -1012,7 +1012,7 @@ class Engine:
         self._add_builder(build_bwd)
         return out
 
-    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False, bn_in=False):
+    def unit(self, mod, x, out=None, residual=None, stem=False, conv=None, bn=None, act=None, bn2=None, x_single=False, bn_in=False, below_in=False):
         """BaseConv: conv -> BN(batch stats) -> SiLU (+ residual) (network_blocks.py:50-51).  ``conv`` / ``bn`` / ``act``
         name the pieces of a unit that is not a BaseConv (the ResNet backbone: act 2 = ReLU, 0 = none).  ``x_single``: the
         caller states that this unit is the only consumer of ``x`` (a Bottleneck's 3x3 over its 1x1): its input gradient IS the
@@ -1102,6 +1102,7 @@ class Engine:
         bar = self._bar_slot() if one_launch else None
         if residual is None:                       # with a residual the incoming gradient is shared with the shortcut: not this unit's alone
             out.bn_info, out.bn_c0 = info, 0
+        out.bn_any = info                          # ... which a consumer that states `below_in` knows how to complete
 
         def build_bwd():
             assert out.gready(), "activation without a gradient producer"
@@ -1182,6 +1183,17 @@ class Engine:
                                                     (lambda f=below["sum_g"], o=o: f() + 8 * o), (lambda f=below["sum_b"], o=o: f() + 8 * o),
                                                     2 * ct, STATS_REPLICAS, below["act"]))
                     below["fused"] += x.C
+                elif (below_in and self.options.fuse_bn_reduce_stream and k_ == 1 and s == 1 and getattr(x, "bn_any", None) is not None and
+                      not x.bn_any["fused"] and x.bn_any["act"] == 1 and x.bn_any["cout"] == cin and x.bn_any["z"].ld % 4 == 0 and
+                      _lib.lib().fn["ep24_conv_kernel_for"](1, B, H, W, cin, seg.cout_pad, 1, 1, 0, 0) == 2):
+                    # d(x) is complete with this launch and is the dy of the unit below: its reduce pass rides on the rows being stored
+                    bl = x.bn_any
+                    zb, sv, ct = bl["z"], bl["save"], bl["cout"]
+                    self._b("conv1x1_dgrad_bnr_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin, seg.cout_pad,
+                                                        zb.ptr(), zb.ld, ptr(sv, 0), ptr(sv, ct), ptr(flat, bl["gam"].off), ptr(flat, bl["bet"].off),
+                                                        bl["sum_g"], bl["sum_b"], 2 * ct, STATS_REPLICAS, 1))
+                    bl["fused"] += cin
+                    self.n_bnr_stream = getattr(self, "n_bnr_stream", 0) + 1
                 else:
                     self._b("conv_dgrad_bf16", (dz, cout, ptr(home.wd, seg.wd_off), x.gptr(), x.gld, acc, B, H, W, cin,
                                                 seg.cout_pad, k_, s))
@@ -1235,7 +1247,7 @@ class Engine:
         self.unit(mod.conv2, x, out=cat.slice(h, h))
         for i, blk in enumerate(mod.m):
             last = i == n - 1
-            u = self.unit(blk.conv1, t, bn_in=i > 0)
+            u = self.unit(blk.conv1, t, bn_in=i > 0, below_in=i > 0)
             t = self.conv_block(blk.conv2, u, out=cat.slice(0, h) if last else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, cat, out=out)
 
@@ -1502,7 +1514,7 @@ class Engine:
 
             self._add_builder(build_copy)
         for i, blk in enumerate(mod.m):
-            u = self.unit(blk.conv1, t, bn_in=i > 0)
+            u = self.unit(blk.conv1, t, bn_in=i > 0, below_in=i > 0)
             t = self.conv_block(blk.conv2, u, out=P.slice(0, h) if i == n - 1 else None, residual=t if blk.use_add else None, x_single=True)
         return self.unit(mod.conv3, P.slice(0, 2 * h), out=out)
 

@@ -35,6 +35,8 @@ class PlanOptions:
     fuse_bn_stream: bool = True        # forward: a Bottleneck's first conv, when it is a 1x1 unit of the streaming kernel (Cin, Cout <= 128), makes its
                                        # input from the previous Bottleneck's raw output - no BatchNorm launch in front of it (round 5)
     fuse_bn_dgrad: bool = True         # backward: the input gradient of such a 1x1 unit makes dz itself - no BatchNorm-backward apply launch (round 5)
+    fuse_bn_reduce_stream: bool = True # backward: the input gradient of a Bottleneck's 1x1 conv on the streaming kernel (128 < Cout <= 256: the 40x40 level) also
+                                       # takes the BatchNorm-backward sums of the unit below - no reduce launch for that unit (round 5; sums' fp32 order differs)
     fuse_loss_decode: bool = True      # TrainStep: loss gradient and the head's decode backward in one pass (round 5; not with the L1 branch)
     # ---- captured step (ep24.train.TrainStep) ----
     parallel_forward: bool = True      # level-0 head chain on a second forward lane

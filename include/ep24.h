@@ -194,6 +194,17 @@ int ep24_bn_act_bwd_apply(const void* dy, int64_t ld_dy, const void* z, int64_t 
                           float* gamma_grad, float* beta_grad, void* dz, int64_t ld_dz, int64_t M, int C, int act,
                           int reps, void* stream);
 
+/* The input gradient of a 1x1 stride-1 conv of the streaming kernel (Cout_k <= 256) that ALSO takes the BatchNorm-backward sums of the
+ * unit below (round 5): what it stores - with `accumulate`, old + new: the complete gradient over a shortcut - is that unit's dy, so
+ * sum(du) and sum(du * zhat) are added to dgamma / dbeta ([reps][..] 2^-36 fixed point, replica stride rep_stride, zeroed by the caller)
+ * from the rounded rows on their way out, with ep24_bn_act_bwd_reduce's expressions (the fp32 order of the partial sums differs); that
+ * unit's reduce launch is not needed.  dx is bit-identical to ep24_conv_dgrad_bf16's.  z / mean / invstd / gamma / beta: the unit below
+ * (act = 1, SiLU).  EP24_E_UNSUPPORTED for a shape the streaming kernel does not take. */
+int ep24_conv1x1_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void* dx, int64_t ld_dx, int accumulate, int B, int H, int W,
+                                int Cin, int Cout_k, const void* z, int64_t ld_z, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int64_t* dgamma, int64_t* dbeta, int64_t rep_stride, int reps,
+                                int act, void* stream);
+
 /* Depthwise 3x3 convolution (groups = channels) of the DWConv blocks (yolox_24p/models/network_blocks.py:57-76: a depthwise BaseConv
  * followed by a 1x1 BaseConv; `depthwise=True` of CSPDarknet / Bottleneck / YOLOPAFPN / YOLOXHead, darknet.py:107, network_blocks.py:92,
  * yolo_pafpn.py:30, yolo_head_24p.py:45 - in no BASELINE configuration).  HBM-bound elementwise kernels (csrc/dwconv.hip): NHWC bf16

@@ -145,3 +145,51 @@ def test_xf_refuses_what_it_does_not_take():
     rc = fn["ep24_conv1x1_bnin_bf16"](ptr(t), 64, ptr(i), 1, ptr(f), ptr(f), None, None, None, None, ptr(f), ptr(t), 64, None, 0, 1e-3, 0.03, 2,
                                       ptr(t), ptr(t), 64, None, 1, 1, 1, 1, 64, 64, stream_ptr())
     assert rc != 0 and "SiLU" in lib().last_error()
+
+
+# the input gradient of a 1x1 conv of the streaming kernel with the reduce pass of the unit below in its epilogue (ep24_conv1x1_dgrad_bnr_bf16)
+# B, H, W, Cin (= channels of the unit below), Cout (K), accumulate
+BNR_CASES = [(20, 40, 40, 256, 256, 1), (20, 40, 40, 256, 256, 0), (4, 20, 20, 256, 256, 1), (2, 24, 24, 64, 192, 0), (3, 13, 17, 48, 160, 1), (20, 80, 80, 128, 128, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,acc", BNR_CASES)
+def test_dgrad_with_the_reduce_of_the_unit_below(B, H, W, Cin, Cout, acc):
+    """dx must be what ep24_conv_dgrad_bf16 stores, bit for bit (same products, same order); the two sums must be what
+    ep24_bn_act_bwd_reduce makes of that dx and the unit's z, up to the fp32 order of the partial sums (2^-36 fixed point both)."""
+    call, ptr, sp = _abi()
+    M, R = B * H * W, 8
+    dz = rnd(M, Cout, seed=21).to(DEV)
+    wt = rnd(Cin, Cout, seed=22, scale=Cout ** -0.5).to(DEV)
+    dx0 = rnd(M, Cin, seed=23).to(DEV)
+    zb = rnd(M, Cin, seed=24, scale=2.0).to(DEV)                              # the unit below: its raw conv output and BatchNorm
+    gamma, beta = (torch.rand(Cin) + 0.5).to(DEV), (torch.rand(Cin) - 0.5).to(DEV)
+    stats = _stats_of(zb.float().cpu(), R)
+    save = torch.zeros(2, Cin, device=DEV)
+    ytmp = torch.zeros(M, Cin, dtype=BF, device=DEV)
+    call("bn_act_fwd", ptr(zb), Cin, ptr(stats), R, ptr(gamma), ptr(beta), None, None, None, None, ptr(save), ptr(ytmp), Cin, None, 0, M, Cin, 1e-3, 0.03, 1, sp())
+    # the two launches
+    dx_a = dx0.clone()
+    call("conv_dgrad_bf16", ptr(dz), Cout, ptr(wt), ptr(dx_a), Cin, acc, B, H, W, Cin, Cout, 1, 1, sp())
+    sums_a = torch.zeros(R, 2, Cin, dtype=torch.int64, device=DEV)
+    call("bn_act_bwd_reduce", ptr(dx_a), Cin, ptr(zb), Cin, ptr(save), ptr(gamma), ptr(beta), ptr(sums_a), ptr(sums_a, Cin), M, Cin, 1, R, sp())
+    # the one launch
+    dx_b = dx0.clone()
+    sums_b = torch.zeros(R, 2, Cin, dtype=torch.int64, device=DEV)
+    call("conv1x1_dgrad_bnr_bf16", ptr(dz), Cout, ptr(wt), ptr(dx_b), Cin, acc, B, H, W, Cin, Cout, ptr(zb), Cin, ptr(save), ptr(save, Cin), ptr(gamma), ptr(beta),
+         ptr(sums_b), ptr(sums_b, Cin), 2 * Cin, R, 1, sp())
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b)
+    a, b = sums_a.sum(0).double() / 2 ** 36, sums_b.sum(0).double() / 2 ** 36
+    assert float(a.abs().max()) > 1.0
+    err = float((a - b).abs().max() / a.abs().max())
+    assert err < 2e-5, err
+
+
+def test_dgrad_bnr_refuses_what_the_streaming_kernel_does_not_take():
+    from ep24._lib import lib, ptr, stream_ptr
+    fn = lib().fn
+    t = torch.zeros(4096, dtype=BF, device=DEV)
+    f = torch.zeros(4096, device=DEV)
+    i = torch.zeros(4096, dtype=torch.int64, device=DEV)
+    rc = fn["ep24_conv1x1_dgrad_bnr_bf16"](ptr(t), 512, ptr(t), ptr(t), 64, 0, 1, 2, 2, 64, 512, ptr(t), 64, ptr(f), ptr(f), ptr(f), ptr(f), ptr(i), ptr(i), 128, 1, 1, stream_ptr())
+    assert rc != 0 and "streaming" in lib().last_error()
