@@ -114,7 +114,8 @@ def instrumented_step(ts):
                 e0.record()
                 rc = fn["ep24_" + name](*a, s)
                 e1.record()
-                all_rec.append((name, tuple(v for v in a[-5:] if isinstance(v, int) and abs(v) < (1 << 24)), e0, e1))
+                tail = a[6:11] if name == "conv1x1_dgrad_bnr_bf16" else a[-5:]        # (that entry's shape B, H, W, Cin, Cout sits in front of the unit below's arguments)
+                all_rec.append((name, tuple(v for v in tail if isinstance(v, int) and abs(v) < (1 << 24)), e0, e1))
                 continue
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -31,10 +31,15 @@ for line in open(sys.argv[1]):
     elif f[0].startswith("conv1x1_"):
         # a 1x1 unit together with the BatchNorm pass in front of it (round 5): forward reads z (+ shortcut, not counted), stores y and
         # the conv output; backward reads dy and z, stores dz and the input gradient
+        if len(f) < 6:          # a table written before bench.py printed this entry's shape (r05d): YOLOX-l's twelve launches are the 40x40x256 Bottlenecks
+            f = [f[0], "20", "40", "40", "256", "256"]
         B, H, W, Ci, Co = map(int, f[1:6])
         M = B * H * W
         K, N = (Ci, Co) if "bnin" in f[0] else (Co, Ci)
-        byts = 2.0 * ((2 if "bnin" in f[0] else 3) * M * K + M * N + N * K) * n
+        if "dgrad_bnr" in f[0]:        # input gradient + the reduce pass of the unit below: reads dz and that unit's z, stores dx (old dx not counted)
+            byts = 2.0 * (M * K + 2 * M * N + N * K) * n
+        else:
+            byts = 2.0 * ((2 if "bnin" in f[0] else 3) * M * K + M * N + N * K) * n
         c = conv["1x1 + BN pass"]
         c[0] += n; c[1] += ms; c[2] += byts; c[3] += 2.0 * M * N * K * n
     elif sec == 1:
