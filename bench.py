@@ -77,7 +77,8 @@ def pmc_traffic(prefix):
 
 
 # device-kernel name prefixes behind each member of the dominant family in a rocprofv3 kernel list
-REPLAY_PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_"}
+REPLAY_PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_",
+                 "conv_wreg_kernel": "conv_wreg_kernel"}
 
 
 def replayed_ms_per_step(prefix):
@@ -180,9 +181,11 @@ def instrumented_step(ts):
         assert kid >= 0, (name, _lib.lib().last_error())
         if kid == 3 and ((name.endswith("_ex") and (args[-1] & 8)) or name.startswith("conv_dgrad_bnr")):
             kid = 1                                        # kernel_opts bit 3 / the fused BatchNorm sums: the 8-wave halo-patch kernel
-        if name.endswith("_ex") and (((args[-1] & 16) and kid == 0) or (args[-1] & 64)):      # bit 4: the ring without a patch; bit 6: the narrow ring
+        if kid == 6 and not fwd and args[5]:
+            kid = 0                                        # an ACCUMULATING input gradient of such a layer stays with the tiled kernel
+        if name.endswith("_ex") and (((args[-1] & 16) and kid == 0) or (args[-1] & 64) or (args[-1] & 512)):      # bit 4: the ring without a patch; bit 6: the narrow ring; bit 9: no weights-in-registers kernel
             kid = fn["ep24_conv_kernel_for_ex"](0 if fwd else 1, B, H, W, Cin, Cout, k, s, int(bool(fwd and args[5] != 0)), int(bool(fwd and args[8] is not None)), args[-1])
-        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel", "conv_ring_kernel", "conv_ring_generic_kernel", "conv_ring_kernel")[kid]
+        return ("igemm_dma_kernel", "conv_patch_kernel", "igemm_stream_kernel", "conv_ring_kernel", "conv_ring_generic_kernel", "conv_ring_kernel", "conv_wreg_kernel")[kid]
 
     convs = [x for x in list(eng.fwd) + list(eng.bwd) if x[0].replace("side:", "").startswith("conv_")]
     for (name, fl, e0, e1, by), (_, args) in zip(rec, convs):
@@ -413,7 +416,7 @@ def main():
         # since round 4, conv_patch_kernel before and on request) and igemm_dma_kernel (everything else) - over the same 183 launches
         # that were one kernel in round 1; the line carries the
         # family and, under "members", each kernel by itself (their average launch durations are what rocprofv3 reports).
-        members = [k for k in ("conv_ring_kernel", "conv_ring_generic_kernel", "conv_patch_kernel", "igemm_dma_kernel") if k in fam]
+        members = [k for k in ("conv_ring_kernel", "conv_ring_generic_kernel", "conv_patch_kernel", "igemm_dma_kernel", "conv_wreg_kernel") if k in fam]
         dom = " + ".join(members)
         f = {key: sum(fam[k][key] for k in members) for key in ("flops", "ms", "launches", "bytes")}
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12

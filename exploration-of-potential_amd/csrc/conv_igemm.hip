@@ -26,6 +26,7 @@ constexpr int KOPT_NARROW = 64;            // bit 6: A/B option - 3x3 stride-1 l
 constexpr int KOPT_NO_DEEP = 128;          // bit 7: A/B option - no three-stage form of the tiled kernel (the 20 x 20 level runs in 64-wide two-stage tiles, as before round 4)
 constexpr int KOPT_TILED256 = 256;         // bit 8: A/B option - 1x1 stride-1 layers with 128 < K <= 256 and M < 100 000 in the tiled kernel, as before the streaming
                                            // kernel's weight tile was requested in one batch (round 5: since then it wins there too, profiles/r05_xf_ab.txt)
+constexpr int KOPT_NO_WREG = 512;         // bit 9: A/B option - 3x3 stride-1 layers with <= 64 channels in the tiled kernel instead of the weights-in-registers kernel (round 5)
 constexpr int KOPT_PATCH8 = 8;             // bit 3: 3x3 stride-1 layers through the 8-wave lockstep halo-patch kernel instead of the loader / consumer ring
 
 // ---------------------------------------------------------------------------------------------------------
@@ -828,7 +829,7 @@ int check_extents(const IgemmArgs& a) {
     return EP24_OK;
 }
 
-// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming, 3 loader / consumer ring, 4 ring without a patch, 5 narrow ring)
+// dry = true: no launch, *kernel_id receives the kernel the shape dispatches to (0 tiled, 1 halo patch, 2 streaming, 3 loader / consumer ring, 4 ring without a patch, 5 narrow ring, 6 weights in registers)
 void prepare(IgemmArgs& a, int kernel_opts) {
     a.narrow_epi = (kernel_opts & KOPT_NARROW_EPI) ? 1 : 0;
     a.src_bytes = (unsigned)((((long)a.B * a.SH * a.SW - 1) * a.ld_src + a.K) * 2);
@@ -920,6 +921,12 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
         !(kernel_opts & KOPT_TILED)) {
         int prc = EP24_OK;
         int ring = 0;
+        if (!a.epi_infer && !(kernel_opts & KOPT_NO_WREG) && launch_wreg(a, stream, dry, &prc)) {      // N, K <= 64: the weights live in registers
+            if (dry) { *kernel_id = 6; return EP24_OK; }
+            if (prc) return prc;
+            EP24_LAUNCH_CHECK("ep24_conv_wreg");
+            return EP24_OK;
+        }
         if (!(kernel_opts & KOPT_PATCH8)) {
             if (kernel_opts & KOPT_NARROW) ring = launch_ring(a, stream, dry, &prc, true, true);
             if (!ring) ring = launch_ring(a, stream, dry, &prc, (kernel_opts & KOPT_RING32) == 0, false);

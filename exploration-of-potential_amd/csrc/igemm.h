@@ -283,6 +283,9 @@ bool launch_patch(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 // m16 (the default): consumers with v_mfma_f32_16x16x32_bf16, bit-identical to the tiled kernel; false: the 32 x 32 x 16 form (A/B option).
 // narrow_ok (A/B option): the 256 x 64 tile wherever at least 128 of them exist.  Returns 0: not this kernel, 1: the 256 x 128 ring, 2: the narrow one.
 int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool m16 = true, bool narrow_ok = false);
+// conv_wreg.hip (round 5): 3x3 stride-1 layers with at most 64 channels on either side and at least 256 tiles of 256 pixels - every
+// B fragment of the layer in registers, persistent workgroups, one LDS window per tap row.  Same contract as launch_patch.
+bool launch_wreg(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 // ... and the ring without a patch, for any other gather-GEMM with bf16 output that fills the chip with 256 x 128 tiles.
 bool launch_ring_generic(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc);
 

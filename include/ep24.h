@@ -71,7 +71,10 @@ int ep24_conv_fwd_bf16(const void* x, int64_t ld_x, const void* w, void* y, int6
  * CU - the 20 x 20 level at B = 20 - run in 128-wide tiles with three LDS stages and two tiles in flight; with bit 7 they run in 64-wide
  * two-stage tiles as before; bit-identical results); bit 8: 1x1 stride-1 layers with 128 < K <= 256 and fewer than 100 000 pixels run
  * in the tiled kernel, as they did before the streaming kernel's weight tile was requested in one batch (round 5: the streaming kernel
- * is the default for every 1x1 stride-1 layer with K <= 256 now).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
+ * is the default for every 1x1 stride-1 layer with K <= 256 now); bit 9: 3x3 stride-1 layers with at most 64 channels on either side
+ * run in the tiled kernel instead of conv_wreg_kernel (round 5, csrc/conv_wreg.hip: every weight fragment of the layer in registers,
+ * persistent workgroups, one LDS window per tap row; bit-identical outputs, the batch statistics equal to fp32 summation order; the
+ * default for such layers with at least 65 536 pixels, an image at least 32 wide and a plain first-writer destination).  kernel_opts = 0 is exactly ep24_conv_fwd_bf16 / ep24_conv_dgrad_bf16, and every default kernel of a 3x3 stride-1
  * layer (ring, 8-wave halo patch, tiled) gives bit-identical results. */
 /* Round 5: bits 4, 5 and 6 (and bit 0 of the weight gradient's kernel_opts) select variants that were built, measured and lost in
  * rounds 3 - 4; they left the product library, which answers EP24_E_UNSUPPORTED for them.  `make -C csrc variants` builds
@@ -103,7 +106,8 @@ int ep24_conv_dgrad_bnr_bf16(const void* dy, int64_t ld_dy, const void* wt, void
  * library's own dispatch rule, for reports (bench.py attributes launch times to kernels with it).  Returns 0 =
  * igemm_dma_kernel (generic tiled), 1 = conv_patch_kernel (halo patch, 8 waves in lockstep), 2 = igemm_stream_kernel (1x1
  * streaming), 3 = conv_ring_kernel (halo patch as a loader / consumer ring), 4 = conv_ring_generic_kernel (the ring without a
- * patch; only with kernel_opts bit 4), 5 = conv_ring_kernel with the narrow tile (only with kernel_opts bit 6), < 0 on error.
+ * patch; only with kernel_opts bit 4), 5 = conv_ring_kernel with the narrow tile (only with kernel_opts bit 6), 6 = conv_wreg_kernel
+ * (3x3 stride-1, at most 64 channels on either side: weights in registers), < 0 on error.
  * y_f32 / has_bias as in ep24_conv_fwd_bf16 (both 0 for dgrad). */
 int ep24_conv_kernel_for(int dgrad, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int y_f32, int has_bias);
 /* ... and for the _ex entry points with the given kernel_opts. */

@@ -118,6 +118,10 @@ HOT_SHAPES = [  # B, H, Cin, Cout, k, s[, W]
     # them: 480 x 672 -> 60 x 84): rows m >= M of the last tile, the `live` guard of the statistics in the wide epilogue,
     # out-of-range patch pieces, with two patch buffers (K = 128, LDS exactly 160 KB) and with one (K = 64)
     (20, 60, 128, 128, 3, 1, 84), (12, 52, 64, 128, 3, 1, 100),
+    # the weights-in-registers kernel (round 5: 3x3 stride-1, <= 64 channels on either side, >= 256 tiles of 256 pixels; the
+    # 160 x 160 x 64 shape above takes it too): a last tile with rows past M on a non-square image, a K tail (48 channels: the
+    # window's last two chunks are zeros) with an N tail (40 channels), the narrowest image it takes (W = 32: nine image rows per tile)
+    (3, 150, 64, 64, 3, 1, 160), (5, 120, 48, 40, 3, 1, 120), (9, 230, 64, 64, 3, 1, 32),
     # the streaming 1x1 kernel's tails (its loads and stores are unconditional; what does not exist is an out-of-range buffer
     # offset): rows past M in the last block and a whole block past the end (odd unit count), an N tail, K = 64 (two K steps),
     # a K tail inside a step (K = 120), two K halves with a tail (K = 200, M large enough for the streaming form)
@@ -174,7 +178,7 @@ def test_conv_hot_shapes(shape):
         if shape[7] == 5:                                                  # ... which no layer takes by default
             assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 0) in (0, 1, 3)
     elif len(shape) > 6:
-        want = 3 if k == 3 else 2                                         # 3: the loader / consumer ring (round 4), 2: streaming
+        want = (6 if max(Cin, Cout) <= 64 else 3) if k == 3 else 2       # 3: the loader / consumer ring (round 4), 6: weights in registers (round 5), 2: streaming
         assert M % 256 != 0 and fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == want, "meant to exercise the ring / streaming kernel's tails"
 
     xd = nhwc(x).to(DEV)
@@ -188,7 +192,8 @@ def test_conv_hot_shapes(shape):
     # other layers: bit 4 sends those that fill the chip with 256 x 128 tiles to the ring without a patch (kernel id 4; an A/B option)
     # 3x3 stride-1: the default is the ring with 16x16x32 consumers; bit 5 = its 32x32x16 form (key 3), bit 3 = the 8-wave kernel
     # key 4: the narrow ring where it fits; key 5 (bits 0 + 7): the tiled kernel WITHOUT its three-stage form (the 20 x 20 level)
-    variants = ((0, 1), (2, 0), (3, 32), (1, 8), (4, 64), (5, 129)) if (k == 3 and s == 1) else ((0, 128), (2, 0), (5, 16))
+    # key 6 (bit 9): a 3x3 stride-1 layer with <= 64 channels in the kernel it ran in before the weights-in-registers kernel
+    variants = ((0, 1), (2, 0), (3, 32), (1, 8), (4, 64), (5, 129), (6, 512)) if (k == 3 and s == 1) else ((0, 128), (2, 0), (5, 16))
     if not have_variants:
         variants = tuple(v for v in variants if not (v[1] & (16 | 32 | 64)))
     for patch, ko in variants:
@@ -227,6 +232,15 @@ def test_conv_hot_shapes(shape):
                 assert torch.equal(a_, b_), other
         sa, sb = outs[0][3].sum(0).double(), outs[other][3].sum(0).double()
         assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max()), other
+    if k == 3 and s == 1 and max(Cin, Cout) <= 64 and M >= 65536:
+        # the weights-in-registers kernel is what the default ran, the tiled kernel what bit 9 ran; its statistics (a workgroup's sums
+        # over all of its tiles) are reproducible bit for bit
+        assert fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k, s, 0, 0) == 6 and fn["ep24_conv_kernel_for"](1, B, H, W, Cin, Cout, k, s, 0, 0) == 6
+        assert fn["ep24_conv_kernel_for_ex"](0, B, H, W, Cin, Cout, k, s, 0, 0, 512) == 0
+        y_again = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
+        st_again = torch.zeros(R, 2, Cout, dtype=torch.int64, device=DEV)
+        call("conv_fwd_bf16_ex", ptr(xd), Cin, ptr(wf), ptr(y_again), Cout, 0, 0, 0, None, ptr(st_again), R, B, H, W, Cin, Cout, k, s, 0, sp())
+        assert torch.equal(y_again, outs[2][0]) and torch.equal(st_again, outs[2][3])
     if 3 in outs:                                                          # ... and is bitwise reproducible run to run
         y_again = torch.zeros(B, OH, OW, Cout, dtype=BF, device=DEV)
         call("conv_fwd_bf16_ex", ptr(xd), Cin, ptr(wf), ptr(y_again), Cout, 0, 0, 0, None, None, R, B, H, W, Cin, Cout, k, s, 32, sp())

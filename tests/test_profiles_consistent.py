@@ -8,7 +8,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel",
-          "igemm_dma_kernel": "igemm_dma_"}
+          "igemm_dma_kernel": "igemm_dma_", "conv_wreg_kernel": "conv_wreg_kernel"}
 
 
 def _latest_tag():

@@ -41,7 +41,8 @@ def counter_pass(path):
 
 
 # device-kernel name prefixes behind the members of bench.py's dominant family (bench.py REPLAY_PREFIX)
-REPLAY_PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_"}
+REPLAY_PREFIX = {"conv_ring_kernel": "conv_ring_kernel", "conv_ring_generic_kernel": "conv_ring_generic_kernel", "conv_patch_kernel": "conv_patch_kernel", "igemm_dma_kernel": "igemm_dma_",
+                 "conv_wreg_kernel": "conv_wreg_kernel"}
 
 
 def restamp(d, prof, tag, head):
