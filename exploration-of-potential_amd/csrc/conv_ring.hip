@@ -48,7 +48,11 @@ __device__ unsigned g_ring_timeouts;
 
 #ifdef EP24_STAMPS
 __device__ unsigned long long g_ring_stamps[64 * 8];
+__device__ unsigned long long g_ring_estamps[64 * 8];    // the epilogue of wave 0 (a consumer) and wave 4 (a loader) of the first 32 workgroups, piece by piece
 #define STAMP() __builtin_amdgcn_s_memtime()
+#define ESTAMP(k) do { if (blockIdx.x < 32 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NCW)) est[k] = STAMP(); } while (0)
+#else
+#define ESTAMP(k) do { } while (0)
 #endif
 
 template <int N>
@@ -138,7 +142,12 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef EP24_STAMPS
+    unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ESTAMP(0);
     __syncthreads();                                         // every wave is out of the main loop: LDS is free
+    ESTAMP(1);
     if (consumer) {
         const int wm = TBN == 128 ? wave >> 1 : wave;
         const int wn = TBN == 128 ? wave & 1 : 0;
@@ -153,13 +162,32 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
             for (int q = 0; q < 4; ++q)
                 if (c0 + q < p.N) bias4[q] = p.bias[c0 + q];
         }
+        // Round 5: the stamps of this epilogue (tools/ring_estamps.py, profiles/r05_ring_epilogue.txt) put 4 850 of its 10 500 cycles
+        // HERE - ~1 050 instructions of one wave per SIMD, 256 of them the selects of `if (row < M) { s1 += v; s2 += v * v; }` (two per
+        // value) and 128 the multiplies.  Now the accumulators of rows past M are cleared up front - only the launch's last row of tiles
+        // has any (uniform branch) - so that they add zeros, and the sum of squares is one fused multiply-add per value.
+        if (!infer && m0 + RBM > p.M) {
+#pragma unroll
+            for (int i = 0; i < CMT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = m0 + wm * (CMT * 16) + i * 16 + 4 * fq + r >= p.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][q][r] = dead ? 0.f : acc[i][q][r];
+                }
+        }
+        // a lane's four staging addresses (r = 0 .. 3) do not depend on the row block: row & 7 = 4 (fq & 1) + r, a block is 2 KB further
+        // (an immediate) - written as `stg + row * 128 + swizzle(row)` inside the loop they were 190 of the loop's 600 instructions
+        int sadr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sadr[r] = (4 * fq + r) * 128 + (((frow >> 1) ^ (4 * (fq & 1) + r)) << 4) + (frow & 1) * 8;
 #pragma unroll
         for (int i = 0; i < CMT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + 4 * fq + r;
                 const long m = m0 + wm * (CMT * 16) + row;
-                const bool live = m < p.M;
+                [[maybe_unused]] const bool live = m < p.M;
                 bf16x4 w;
                 bf16x4 res4 = {0, 0, 0, 0};
                 if (infer && p.epi_res && live && c0 + 3 < p.N) res4 = *reinterpret_cast<const bf16x4*>(p.epi_res + m * p.epi_ldres + c0);
@@ -170,46 +198,50 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
                         v = act_fwd(v + bias4[q], p.epi_act);
                         if (p.epi_res) v += (float)res4[q];
                     }
-                    if (live) { s1[q] += v; s2[q] += v * v; }
+                    s1[q] += v; s2[q] = fmaf(v, v, s2[q]);       // (the eval-mode form stores no statistics)
                     w[q] = (bf16)v;
                 }
-                *reinterpret_cast<bf16x4*>(stg + row * 128 + (((frow >> 1) ^ (row & 7)) << 4) + (frow & 1) * 8) = w;
+                *reinterpret_cast<bf16x4*>(stg + sadr[r] + i * 2048) = w;
             }
         }
     }
+    ESTAMP(2);
     __syncthreads();
+    ESTAMP(3);
     ring_store_tile<TBN>(p, m0, n0, smem);
-    if (p.stats) {
-        __syncthreads();                                     // the staging areas have been read
-        float* red = reinterpret_cast<float*>(smem);         // [NCW waves][2][64]
-        if (consumer) {
+    ESTAMP(4);
+    if (p.stats && consumer) {
+        // Round 5: every consumer publishes the sums of ITS 128 x 64 piece (64 x 64: the narrow tile) - no barrier, no LDS.  The fold of
+        // the two row halves of a tile through LDS sat behind two workgroup barriers, the first of which waited for the loaders' half of
+        // the stores (1 300 + 1 600 cycles of the epilogue's 10 500).  After the two butterflies every lane of a quarter holds the sums of
+        // its four channels; lane (frow, fq) publishes channel 4 frow + fq.  (The fixed-point conversion is per 128 rows now, as in the
+        // tiled kernels, instead of per 256: equal to 2^-20 rounding.)
+        const int wn = TBN == 128 ? wave & 1 : 0;
+        float a4[4], b4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float a = s1[q], b = s2[q];
-                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-                if (fq == 0) {
-                    red[(wave * 2 + 0) * 64 + 4 * frow + q] = a;
-                    red[(wave * 2 + 1) * 64 + 4 * frow + q] = b;
-                }
-            }
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            a4[q] = a; b4[q] = b;
         }
-        __syncthreads();
+        const float av = fq == 0 ? a4[0] : fq == 1 ? a4[1] : fq == 2 ? a4[2] : a4[3];
+        const float bv = fq == 0 ? b4[0] : fq == 1 ? b4[1] : fq == 2 ? b4[2] : b4[3];
+        const int c = n0 + wn * 64 + 4 * frow + fq;
         long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
-        if (tid < 2 * TBN) {
-            const int which = tid / TBN, c = tid - which * TBN;
-            const int wcol = c >> 6;
-            float v = 0.f;
-            if constexpr (TBN == 128) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) v += red[((r * 2 + wcol) * 2 + which) * 64 + (c & 63)];
-            } else {
-#pragma unroll
-                for (int r = 0; r < NCW; ++r) v += red[(r * 2 + which) * 64 + c];
-            }
-            if (n0 + c < p.N) atomicAdd((unsigned long long*)(st + (long)which * p.N + n0 + c), (unsigned long long)to_fix(v));
+        if (c < p.N) {
+            atomicAdd((unsigned long long*)(st + c), (unsigned long long)to_fix(av));
+            atomicAdd((unsigned long long*)(st + (long)p.N + c), (unsigned long long)to_fix(bv));
         }
     }
+    ESTAMP(6);
+#ifdef EP24_STAMPS
+    if (blockIdx.x < 32 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NCW)) {
+        unsigned long long* o = g_ring_estamps + (blockIdx.x * 2 + ((threadIdx.x >> 6) != 0)) * 8;
+        for (int k = 0; k < 7; ++k) o[k] = est[k];
+        o[7] = STAMP();
+    }
+#endif
 }
 
 // The staged 256 x 128 bf16 tile (four areas of [128 rows][128 B], 16-byte chunk index XOR (row & 7)) leaves as 16-byte stores, eight
@@ -220,6 +252,43 @@ __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 && p.dbs == (long)p.GH * p.GW);
     constexpr int CMT = TBN == 128 ? 8 : 4;
     constexpr int CPT = NCW * CMT * 16 * 8 / ((NCW + NLW) * 64);     // 16-byte chunks per thread: 8 (4 for the narrow tile)
+    if constexpr (TBN == 128) {
+        // Round 5: the destination of this kernel is plain and below 2 GiB (launch_ring): it leaves through buffer stores with 32-bit
+        // offsets.  Chunk k of thread t is LDS byte k * 8192 + (t >> 3) * 128 + (((t & 7) ^ ((t >> 3) & 7)) << 4) and row
+        // (k >> 2) * 128 + (k & 1) * 64 + (t >> 3), channel ((k >> 1) & 1) * 64 + (t & 7) * 8 of the tile: one address per thread, the rest
+        // immediates and one add per chunk.  (The pointer form below - still the narrow tile's - makes a 64-bit address per chunk: ~700
+        // instructions for eight stores; the stamps read 2 000 cycles for a consumer and 3 200 for a loader, the consumers then
+        // waiting for the loaders at the next barrier.)
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const auto drs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16*>(p.dst), 0, p.dst_bytes, 0x00020000);
+        const int rt = tid >> 3, ch = tid & 7;
+        const char* lsrc = smem + rt * 128 + ((ch ^ (rt & 7)) << 4);
+        const int ld2 = (int)p.ld_dst * 2;
+        const long mt = m0 + rt;
+        const int cc0 = n0 + ch * 8;
+        const int off_t = (int)((mt * p.ld_dst + cc0) * 2);
+        bf16x8 v_[CPT];
+        int off[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) v_[k] = *reinterpret_cast<const bf16x8*>(lsrc + k * 8192);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int dm = (k >> 2) * 128 + (k & 1) * 64, dc = ((k >> 1) & 1) * 64;
+            off[k] = (mt + dm < p.M && cc0 + dc < p.N) ? off_t + dm * ld2 + dc * 2 : OOB;
+        }
+        if (p.accumulate) {                                  // every old value is requested before the first is added (out of range: zeros)
+            bf16x8 o_[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) o_[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(drs, off[k], 0, 0));
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v_[k][e] = (bf16)((float)v_[k][e] + (float)o_[k][e]);
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, v_[k]), drs, off[k], 0, 0);
+        return;
+    }
     bf16* dptr[CPT];
     bf16x8 val[CPT], old[CPT];
     bool ok[CPT];
@@ -1226,7 +1295,11 @@ int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, h
                      hipGetErrorString(e));
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32, TBN, INFER>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, a, NP, halo, npb);
+    IgemmArgs b = a;
+    const long dst_b = ((a.M - 1) * a.ld_dst + a.N) * 2;     // a destination the 32-bit offsets of the epilogue's buffer stores cover (else 0: its pointer form)
+    EP24_REQUIRE(dst_b < 0x7FFF0000L, EP24_E_UNSUPPORTED, "conv_ring: a destination of %ld bytes is beyond the 32-bit offsets of its stores (launch_ring sends such a layer to the tiled kernel)", dst_b);
+    b.dst_bytes = (unsigned)dst_b;
+    hipLaunchKernelGGL((conv_ring_kernel<PPS, M32, TBN, INFER>), dim3(tiles), dim3((NCW + NLW) * 64), lds, stream, b, NP, halo, npb);
     return EP24_OK;
 }
 
@@ -1246,6 +1319,9 @@ extern "C" int ep24_conv_ring_timeouts(void) {
 extern "C" int ep24_debug_read_ring_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
 }
+extern "C" int ep24_debug_read_ring_estamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_estamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace ep24_igemm {
@@ -1262,6 +1338,7 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
         if (a.oy[t] != sgn * (t / 3 - 1) || a.ox[t] != sgn * (t % 3 - 1) || a.wslot[t] != t) return 0;
     if (a.K % 8 != 0) return 0;
     if (a.bnr_z) return 0;                                   // the fused BatchNorm-backward sums (an A/B option) stay with the 8-wave kernel
+    if (((a.M - 1) * a.ld_dst + a.N) * 2 >= 0x7FFF0000L) return 0;      // its epilogue stores with 32-bit offsets
 #ifdef EP24_AB_VARIANTS
     const bool narrow = narrow_ok;
 #else

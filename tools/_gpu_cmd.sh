@@ -1,14 +1,13 @@
-mkdir -p gpurun_out/wreg
-o=gpurun_out/wreg/configs.txt; rm -f $o
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --steps 40 --warmup 8 "$@" > gpurun_out/wreg/c.out 2> gpurun_out/wreg/c.err || { echo "$name FAILED" >> $o; tail -3 gpurun_out/wreg/c.err >> $o; return; }; python -c "import json; d=json.loads(open('gpurun_out/wreg/c.out').read().strip().splitlines()[-1]); print('%-13s %8.2f %7.3f   %s' % ('$name', d['value'], d['ms_per_step'], '$*'))" >> $o; }
-run default
-run vgg --backbone vgg
-run vgg_tiled --backbone vgg --plan conv_kernel_opts=512
-run resnet --backbone resnet
-run densenet --backbone densenet
-run config5 --batch 8 --size 1280 --gts 50 --fisheye
-run config5_tiled --batch 8 --size 1280 --gts 50 --fisheye --plan conv_kernel_opts=512
-run longrun --long-run
-run depthwise_s --depthwise --width 0.5 --depth 0.33
-run dense_s --width 0.5 --depth 0.33
-cat $o
+mkdir -p gpurun_out/ring
+L=$PWD/exploration-of-potential_amd/ep24
+EP24_LIB=$L/libep24_stamps.so timeout -k 10 200 python tools/ring_estamps.py > gpurun_out/ring/estamps3.txt 2>&1
+grep -v amdgpu.ids gpurun_out/ring/estamps3.txt
+timeout -k 10 300 python -m pytest tests/test_gpu_conv.py -x -q -k "hot_shapes or infer_unit" > gpurun_out/ring/tests.log 2>&1; tail -2 gpurun_out/ring/tests.log
+for r in 1 2 3; do
+  for lib in before ""; do
+    echo "== lib ${lib:-new}" >> gpurun_out/ring/step_ab.txt
+    EP24_LIB=$L/libep24${lib:+_$lib}.so timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/ring/b.out 2> gpurun_out/ring/b.err || { tail -5 gpurun_out/ring/b.err; exit 1; }
+    python -c "import sys,json; d=json.loads(open('gpurun_out/ring/b.out').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['members']['conv_ring_kernel']['achieved'])" >> gpurun_out/ring/step_ab.txt
+  done
+done
+cat gpurun_out/ring/step_ab.txt

@@ -15,6 +15,7 @@ SHAPES = [(20, 160, 64, 64), (4, 160, 64, 64), (20, 160, 48, 48), (20, 80, 64, 6
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in sys.argv[1].split(";")]
 NSET = max(1, int(os.environ.get("EP24_AB_SETS", "4")))
+KOS = tuple(int(v) for v in os.environ.get("EP24_AB_KOS", "512,0").split(","))      # kernel_opts compared (one value: the loaded library's default kernel alone)
 
 
 def graph_time(run, iters=24):
@@ -54,7 +55,7 @@ def main():
         for kind in ("fwd", "dgrad"):
             best = {}
             for rnd in range(3):
-                for ko in (512, 0):
+                for ko in KOS:
                     if kind == "fwd":
                         run = lambda i, ko=ko: call("conv_fwd_bf16_ex", ptr(xs[i]), Cin, ptr(ws[i]), ptr(ys[i]), Cout, 0, 0, 0, None, ptr(st), 8, B, H, W, Cin, Cout, 3, 1, ko, stream_ptr())
                     else:
@@ -62,7 +63,7 @@ def main():
                     t = graph_time(run)
                     best[ko] = min(best.get(ko, 1e9), t)
             gf = 2.0 * B * H * W * 9 * Cin * Cout / 1e9
-            print("%-6s %-18s %10.1f %10.1f   TF: %6.0f %6.0f   (default kernel id %d)" % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout), best[512], best[0], gf / best[512] / 1e3, gf / best[0] / 1e3, kid), flush=True)
+            print("%-6s %-18s " % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout)) + " ".join("%10.1f" % best[k] for k in KOS) + "   TF: " + " ".join("%6.0f" % (gf / best[k] * 1e-3) for k in KOS) + "   (default kernel id %d)" % kid, flush=True)
     print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 
