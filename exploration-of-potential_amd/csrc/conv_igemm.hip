@@ -853,6 +853,11 @@ int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
     for (int i = 0; i < n; ++i) {
         if (int rc = check_extents(cls[i])) return rc;
         prepare(cls[i], kernel_opts);
+        {   // the extent of the (strided) destination for the epilogue's buffer stores (0: its pointer form)
+            const IgemmArgs& c = cls[i];
+            const long ext = (((long)(c.B - 1) * c.dbs + c.dp0 + (long)((c.GH - 1) * c.dsy + c.dy0) * c.DW + (c.GW - 1) * c.dsx + c.dx0) * c.ld_dst + c.N) * 2;
+            cls[i].dst_bytes = (ext > 0 && ext < 0x7FFF0000L) ? (unsigned)ext : 0u;
+        }
         wide = wide && cls[i].N > 64 && (long)ep24_cdiv(cls[i].M, BM) * ep24_cdiv(cls[i].N, 128) > 256;
         // one argument block for all classes: everything but the taps and the destination parity must agree
         const IgemmArgs &x = cls[i], &y = cls[0];
@@ -862,6 +867,7 @@ int launch_multi(IgemmArgs* cls, int n, hipStream_t stream, int kernel_opts) {
                      !x.bias && !x.stats && !x.bnr_z && !x.epi_infer, EP24_E_ARG, "conv_igemm_multi: the classes of one launch share everything but their taps and parity");
     }
     q.a = cls[0];
+    for (int i = 1; i < n; ++i) q.a.dst_bytes = (q.a.dst_bytes && cls[i].dst_bytes) ? std::max(q.a.dst_bytes, cls[i].dst_bytes) : 0u;     // one descriptor over every class's pixels
     for (int i = 0; i < n; ++i) {
         q.T[i] = cls[i].T; q.tap_dy[i] = cls[i].tap_dy; q.tap_dx[i] = cls[i].tap_dx; q.tap_slot[i] = cls[i].tap_slot;
         q.dy0[i] = cls[i].dy0; q.dx0[i] = cls[i].dx0;
@@ -885,6 +891,9 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
     prepare(a, kernel_opts);
     const bool plain_dst = a.dsy == 1 && a.dsx == 1 && a.dy0 == 0 && a.dx0 == 0 && a.DW == a.GW && a.dp0 == 0 && a.dbs == (long)a.GH * a.GW;
     const long dst_b = ((a.M - 1) * a.ld_dst + a.N) * 2;     // the streaming kernel stores through a buffer descriptor (32-bit offsets)
+    // ... and so do the 16-byte store paths of the tiled / ring epilogues where the destination's extent allows (0: their pointer form)
+    const long dst_ext = plain_dst ? dst_b : (((long)(a.B - 1) * a.dbs + a.dp0 + (long)((a.GH - 1) * a.dsy + a.dy0) * a.DW + (a.GW - 1) * a.dsx + a.dx0) * a.ld_dst + a.N) * 2;
+    a.dst_bytes = (!out_f32 && dst_ext > 0 && dst_ext < 0x7FFF0000L) ? (unsigned)dst_ext : 0u;
     const bool stream_ok = a.T == 1 && a.sy == 1 && a.sx == 1 && a.oy[0] == 0 && a.ox[0] == 0 && a.GH == a.SH && a.GW == a.SW &&
                            (a.K <= 128 || (a.K <= 256 && (a.M >= 100000 || !(kernel_opts & KOPT_TILED256)))) && !out_f32 && (!a.bias || a.epi_infer) && plain_dst &&
                            a.ld_dst % 4 == 0 && a.N % 4 == 0 && dst_b < 0x7FFF0000L;

@@ -119,7 +119,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = acc[i][q][r] + bias4[q];
-                    if (live) { s1[q] += v; s2[q] += v * v; }
+                    const float vs = live ? v : 0.f;             // (one select per value; `if (live) { s1 += v; s2 += v * v; }` was two, and a multiply)
+                    s1[q] += vs; s2[q] = fmaf(vs, vs, s2[q]);
                     w[q] = (bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(stg + row * 128 + (((frow >> 1) ^ (row & 7)) << 4) + (frow & 1) * 8) = w;
@@ -138,6 +139,36 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
                 bsg[j] = 0.f; bsb[j] = 0.f;
             }
         }
+        // Round 5: a destination whose extent fits 32-bit offsets (dst_bytes != 0: every layer of the step) leaves through buffer stores -
+        // an offset per chunk instead of a 64-bit pointer, rows past M / columns past N as out-of-range offsets instead of a branch round
+        // the store (profiles/r05_ring_epilogue.txt: the ring's epilogue spent 2 000 - 3 200 cycles on eight such stores)
+        if (!bnr && p.dst_bytes != 0u) {
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            const auto drs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16*>(p.dst), 0, p.dst_bytes, 0x00020000);
+            const int rt = lane >> 3;
+            const char* lsrc = stg + rt * 128 + ((ch ^ (rt & 7)) << 4);
+            const long mw = m0 + wm * (MT * 16) + rt;
+#pragma unroll
+            for (int k = 0; k < MT * 2; ++k) {
+                const long m = mw + k * 8;
+                long dpix = m;
+                if (!fast_dst) {
+                    const int mm = m < p.M ? (int)m : 0;
+                    const int n = fdiv(mm, p.d_plane);
+                    const int rem = mm - n * (p.GH * p.GW);
+                    const int gy = fdiv(rem, p.d_gw), gx = rem - gy * p.GW;
+                    dpix = (long)n * p.dbs + p.dp0 + (long)(gy * p.dsy + p.dy0) * p.DW + gx * p.dsx + p.dx0;
+                }
+                const int off = (m < p.M && cc < p.N) ? (int)((dpix * p.ld_dst + cc) * 2) : OOB;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(lsrc + k * 1024);
+                if (p.accumulate) {                        // (out of range: zeros)
+                    const bf16x8 o = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, v), drs, off, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < MT * 2; ++k) {
             const int row = k * 8 + (lane >> 3);
@@ -249,7 +280,28 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             }
         }
     }
-    if (p.stats) {
+    if (p.stats && wide) {
+        // Round 5 (the 16-byte store path; as the ring's epilogue): every wave publishes the sums of its own MT*16 x 64 piece - no fold
+        // through LDS, no barriers.  After the two butterflies every lane of a quarter holds the sums of its four channels; lane
+        // (frow, fq) publishes channel 4 frow + fq.  (The fixed-point conversion is per wave piece now instead of per tile: equal to
+        // 2^-20 rounding; the integer sums stay order-independent.)
+        float a4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = s1[q], b = s2[q];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            a4[q] = a; b4[q] = b;
+        }
+        const float av = fq == 0 ? a4[0] : fq == 1 ? a4[1] : fq == 2 ? a4[2] : a4[3];
+        const float bv = fq == 0 ? b4[0] : fq == 1 ? b4[1] : fq == 2 ? b4[2] : b4[3];
+        const int c = n0 + wn * 64 + 4 * frow + fq;
+        long long* st = p.stats + (long)(tile_m % p.stats_replicas) * 2 * p.N;
+        if (c < p.N) {
+            atomicAdd((unsigned long long*)(st + c), (unsigned long long)to_fix(av));
+            atomicAdd((unsigned long long*)(st + (long)p.N + c), (unsigned long long)to_fix(bv));
+        }
+    } else if (p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [NWV waves][2][64]
 #pragma unroll

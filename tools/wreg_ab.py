@@ -42,28 +42,31 @@ def graph_time(run, iters=24):
 def main():
     fn = _lib.lib().fn
     print("%-6s %-18s %10s %10s   (us per launch: tiled kernel, weights-in-registers kernel; TFLOP/s)" % ("kind", "B,H,Cin,Cout", "tiled", "wreg"))
-    for B, H, Cin, Cout in SHAPES:
+    for shp in SHAPES:
+        B, H, Cin, Cout = shp[:4]
+        k_, s_ = (shp[4], shp[5]) if len(shp) > 5 else (3, 1)     # "B,H,Cin,Cout[,k,s]"
         W = H
+        OH = (H + 2 * ((k_ - 1) // 2) - k_) // s_ + 1
         xs = [torch.randn(B * H * W, Cin, device=DEV).to(torch.bfloat16) for _ in range(NSET)]
-        ws = [(torch.randn(Cout, 9, Cin, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(NSET)]
-        wds = [(torch.randn(Cin, 9, Cout, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(NSET)]
-        ys = [torch.zeros(B * H * W, Cout, device=DEV, dtype=torch.bfloat16) for _ in range(NSET)]
-        dys = [torch.randn(B * H * W, Cout, device=DEV).to(torch.bfloat16) for _ in range(NSET)]
+        ws = [(torch.randn(Cout, k_ * k_, Cin, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(NSET)]
+        wds = [(torch.randn(Cin, k_ * k_, Cout, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(NSET)]
+        ys = [torch.zeros(B * OH * OH, Cout, device=DEV, dtype=torch.bfloat16) for _ in range(NSET)]
+        dys = [torch.randn(B * OH * OH, Cout, device=DEV).to(torch.bfloat16) for _ in range(NSET)]
         dxs = [torch.zeros(B * H * W, Cin, device=DEV, dtype=torch.bfloat16) for _ in range(NSET)]
         st = torch.zeros(8, 2, Cout, dtype=torch.int64, device=DEV)
-        kid = fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, 3, 1, 0, 0)
+        kid = fn["ep24_conv_kernel_for"](0, B, H, W, Cin, Cout, k_, s_, 0, 0)
         for kind in ("fwd", "dgrad"):
             best = {}
             for rnd in range(3):
                 for ko in KOS:
                     if kind == "fwd":
-                        run = lambda i, ko=ko: call("conv_fwd_bf16_ex", ptr(xs[i]), Cin, ptr(ws[i]), ptr(ys[i]), Cout, 0, 0, 0, None, ptr(st), 8, B, H, W, Cin, Cout, 3, 1, ko, stream_ptr())
+                        run = lambda i, ko=ko: call("conv_fwd_bf16_ex", ptr(xs[i]), Cin, ptr(ws[i]), ptr(ys[i]), Cout, 0, 0, 0, None, ptr(st), 8, B, H, W, Cin, Cout, k_, s_, ko, stream_ptr())
                     else:
-                        run = lambda i, ko=ko: call("conv_dgrad_bf16_ex", ptr(dys[i]), Cout, ptr(wds[i]), ptr(dxs[i]), Cin, 0, B, H, W, Cin, Cout, 3, 1, ko, stream_ptr())
+                        run = lambda i, ko=ko: call("conv_dgrad_bf16_ex", ptr(dys[i]), Cout, ptr(wds[i]), ptr(dxs[i]), Cin, 0, B, H, W, Cin, Cout, k_, s_, ko, stream_ptr())
                     t = graph_time(run)
                     best[ko] = min(best.get(ko, 1e9), t)
-            gf = 2.0 * B * H * W * 9 * Cin * Cout / 1e9
-            print("%-6s %-18s " % (kind, "%d,%d,%d,%d" % (B, H, Cin, Cout)) + " ".join("%10.1f" % best[k] for k in KOS) + "   TF: " + " ".join("%6.0f" % (gf / best[k] * 1e-3) for k in KOS) + "   (default kernel id %d)" % kid, flush=True)
+            gf = 2.0 * B * OH * OH * k_ * k_ * Cin * Cout / 1e9
+            print("%-6s %-22s " % (kind, ",".join(str(v) for v in shp)) + " ".join("%10.1f" % best[k] for k in KOS) + "   TF: " + " ".join("%6.0f" % (gf / best[k] * 1e-3) for k in KOS) + "   (default kernel id %d)" % kid, flush=True)
     print("ring timeouts:", fn["ep24_conv_ring_timeouts"]())
 
 
