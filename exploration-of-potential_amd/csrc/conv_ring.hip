@@ -129,6 +129,8 @@ __device__ __forceinline__ void spin_until(const lds_u32* f, unsigned need, lds_
 
 template <int TBN>
 __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int n0, char* smem);
+template <int HALF, bool ALL>
+__device__ __forceinline__ void ring_store_half(const IgemmArgs& p, long m0, int n0, char* smem);
 
 // Epilogue with all eight waves (16-byte store path only).  The stamps of the first form - the four consumers alone, each staging and
 // storing its 128 x 64 piece - read 10.5 k cycles per tile, a quarter of a 36-step kernel: the tail is store-ISSUE bound (MI355X_MICROARCH
@@ -181,8 +183,9 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
         int sadr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sadr[r] = (4 * fq + r) * 128 + (((frow >> 1) ^ (4 * (fq & 1) + r)) << 4) + (frow & 1) * 8;
+        auto stage = [&](auto lo_c, auto hi_c) {
 #pragma unroll
-        for (int i = 0; i < CMT; ++i) {
+        for (int i = decltype(lo_c)::value; i < decltype(hi_c)::value; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + 4 * fq + r;
@@ -204,12 +207,36 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
                 *reinterpret_cast<bf16x4*>(stg + sadr[r] + i * 2048) = w;
             }
         }
+        };
+        if constexpr (TBN == 128 && !INFER) {
+            // two halves: while the consumers stage the second 64 rows of their pieces, the loaders - idle during the staging until
+            // now: 3 000 cycles - store the first
+            stage(std::integral_constant<int, 0>{}, std::integral_constant<int, CMT / 2>{});
+            ESTAMP(2);
+            __syncthreads();
+            ESTAMP(3);
+            stage(std::integral_constant<int, CMT / 2>{}, std::integral_constant<int, CMT>{});
+        } else {
+            stage(std::integral_constant<int, 0>{}, std::integral_constant<int, CMT>{});
+        }
     }
-    ESTAMP(2);
-    __syncthreads();
-    ESTAMP(3);
-    ring_store_tile<TBN>(p, m0, n0, smem);
-    ESTAMP(4);
+    if constexpr (TBN == 128 && !INFER) {
+        if (!consumer) {
+            ESTAMP(2);
+            __syncthreads();
+            ESTAMP(3);
+            ring_store_half<0, false>(p, m0, n0, smem);
+        }
+        ESTAMP(4);
+        __syncthreads();
+        ring_store_half<1, true>(p, m0, n0, smem);
+    } else {
+        ESTAMP(2);
+        __syncthreads();
+        ESTAMP(3);
+        ring_store_tile<TBN>(p, m0, n0, smem);
+        ESTAMP(4);
+    }
     if (p.stats && consumer) {
         // Round 5: every consumer publishes the sums of ITS 128 x 64 piece (64 x 64: the narrow tile) - no barrier, no LDS.  The fold of
         // the two row halves of a tile through LDS sat behind two workgroup barriers, the first of which waited for the loaders' half of
@@ -321,6 +348,43 @@ __device__ __forceinline__ void ring_store_tile(const IgemmArgs& p, long m0, int
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
         if (ok[k]) *reinterpret_cast<bf16x8*>(dptr[k]) = val[k];
+}
+
+// Half of the staged 256 x 128 tile - rows HALF * 64 .. + 63 of each of the four 128-row areas - as 16-byte buffer stores: by all eight
+// waves (ALL: 4 chunks per thread) or by the four loader waves alone (8 chunks per thread).  Chunk c = k * T + t of the half is area
+// c >> 9, row (c >> 3) & 63 of the half, 16-byte chunk c & 7; a thread's row & 7 and chunk do not depend on k.
+template <int HALF, bool ALL>
+__device__ __forceinline__ void ring_store_half(const IgemmArgs& p, long m0, int n0, char* smem) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    constexpr int T = ALL ? (NCW + NLW) * 64 : NLW * 64, NK = 4 * 64 * 8 / T;
+    const int t = ALL ? (int)threadIdx.x : (int)threadIdx.x - NCW * 64;
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16*>(p.dst), 0, p.dst_bytes, 0x00020000);
+    const int rt = t >> 3, ch = t & 7;
+    const char* lsrc = smem + HALF * 8192 + rt * 128 + ((ch ^ (rt & 7)) << 4);
+    const int ld2 = (int)p.ld_dst * 2;
+    const long mt = m0 + HALF * 64 + rt;
+    const int cc0 = n0 + ch * 8;
+    const int off_t = (int)((mt * p.ld_dst + cc0) * 2);
+    bf16x8 v_[NK];
+    int off[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int area = ALL ? k : k >> 1, rr = ALL ? 0 : (k & 1) * 32;          // (compile-time after unrolling)
+        v_[k] = *reinterpret_cast<const bf16x8*>(lsrc + area * 16384 + rr * 128);
+        const int dm = (area >> 1) * 128 + rr, dc = (area & 1) * 64;
+        off[k] = (mt + dm < p.M && cc0 + dc < p.N) ? off_t + dm * ld2 + dc * 2 : OOB;
+    }
+    if (p.accumulate) {                                      // every old value is requested before the first is added (out of range: zeros)
+        bf16x8 o_[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) o_[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(drs, off[k], 0, 0));
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v_[k][e] = (bf16)((float)v_[k][e] + (float)o_[k][e]);
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, v_[k]), drs, off[k], 0, 0);
 }
 
 // Epilogue of the 32 x 32 x 16 consumers.  A consumer holds D[channel][pixel] tiles: lane = pixel (lane & 31), register quad qd of a
