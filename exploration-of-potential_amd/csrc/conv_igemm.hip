@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
 // BatchNorm backward - sum(du), sum(du * zhat), du = dy * silu'(bn(z)) - are taken from the rows while they leave, with the reduce
 // kernel's expressions on the ROUNDED values it would have read; its launch (dy and z read once more, one dependent launch) goes.
 // The sums' fp32 order differs from the reduce kernel's (per-lane partial sums, then the statistics fold): same values to fp32 rounding.
-template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false, int XF = 0, bool BNR = false>      // EPI: 0 training (statistics), 2 inference (bias, act, residual)
+template <int BN, int H, int EPI, int NKS, bool ACC, bool GATHER = false, int XF = 0, bool BNR = false>      // EPI: 0 training (statistics), 1 training without statistics (input gradients), 2 inference (bias, act, residual)
 __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(const IgemmArgs p, int bpn) {
     // 4 waves x 32 rows per row group.  The transformed-A forms walk a wave's 32 rows as two blocks of 16 (XS = 2 sub-blocks: their
     // second source row and the constants need the registers - with 32 rows per block the loop spilled, and a scratch access in the
@@ -529,7 +529,10 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             v[q] = acc[i][sp * 4 + q][r];
-                            if constexpr (XF != 3 && !BNR) { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] += v[q] * v[q]; }     // (an input gradient has no statistics)
+                            // (an input gradient has no statistics: its launches take the form without them - EPI 1, round 5: the two sums
+                            // were 384 of the ~600 vector instructions of a loop iteration beside 128 MFMAs, in a kernel bound by its
+                            // issue slots; the sum of squares is one fused multiply-add)
+                            if constexpr (EPI == 0 && XF != 3 && !BNR) { s1[sp * 4 + q] += v[q]; s2[sp * 4 + q] = fmaf(v[q], v[q], s2[sp * 4 + q]); }
                         }
                         if constexpr (ACC) {
                             const bf16x4 o = __builtin_bit_cast(bf16x4, old[r][sp]);
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256, XF == 3 ? 3 : 2) void igemm_stream_kernel(cons
         compute(A1, X1, u + 1, std::integral_constant<int, H - 1>{});
     }
 
-    if (BNR || p.stats) {
+    if ((EPI == 0 || BNR) && (BNR || p.stats)) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][BN]; the weight tile is no longer needed
 #pragma unroll
@@ -787,7 +790,8 @@ void launch_stream(const IgemmArgs& a, hipStream_t stream) {
         else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false, true>), grid, dim3(256), lds, stream, a, (int)bpn);
     } else {
         if (a.epi_infer) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 2, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
-        else if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else if (a.accumulate) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 1, NKS, true>), grid, dim3(256), lds, stream, a, (int)bpn);
+        else if (!a.stats) hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 1, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
         else hipLaunchKernelGGL((igemm_stream_kernel<BN, H, 0, NKS, false>), grid, dim3(256), lds, stream, a, (int)bpn);
     }
 }

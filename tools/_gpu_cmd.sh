@@ -1,7 +1,11 @@
-mkdir -p gpurun_out/final
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/final/full_tests.log 2>&1; rc=$?
-tail -3 gpurun_out/final/full_tests.log
-[ $rc = 0 ] || exit $rc
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
-bash tools/collect_profiles.sh r05g 6518934 > gpurun_out/collect_r05g.log 2>&1; tail -2 gpurun_out/collect_r05g.log
-python -c "import json; d=json.load(open('gpurun_out/prof_r05g/bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['achieved'])"
+mkdir -p gpurun_out/stream
+L=$PWD/exploration-of-potential_amd/ep24
+timeout -k 10 600 python -m pytest tests/test_gpu_conv.py tests/test_gpu_xf.py -x -q > gpurun_out/stream/tests.log 2>&1; rc=$?; tail -2 gpurun_out/stream/tests.log; [ $rc = 0 ] || exit $rc
+for r in 1 2 3; do
+  for lib in before ""; do
+    echo "== lib ${lib:-new}" >> gpurun_out/stream/step_ab.txt
+    EP24_LIB=$L/libep24${lib:+_$lib}.so timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/stream/b.out 2> gpurun_out/stream/b.err || { tail -5 gpurun_out/stream/b.err; exit 1; }
+    python -c "import sys,json; d=json.loads(open('gpurun_out/stream/b.out').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['families']['igemm_stream_kernel'])" >> gpurun_out/stream/step_ab.txt
+  done
+done
+paste - - < gpurun_out/stream/step_ab.txt
