@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p) {
 #ifndef EP24_DEEP_STAGES
 #define EP24_DEEP_STAGES 3
 #endif
+template <int EPI>                                                                      // 0: with the batch statistics, 1: without (an input gradient)
 __global__ __launch_bounds__(256) void igemm_dma_deep_kernel(const IgemmArgs p) {       // 128-wide tiles, three stages, bf16 training form
-    igemm_dma_body<128, false, 0, EP24_DEEP_STAGES>(p, (int)blockIdx.x, (int)gridDim.x);
+    igemm_dma_body<128, false, EPI, EP24_DEEP_STAGES>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to four gather-GEMMs in ONE launch: the parity classes of a stride-2 input gradient (same M, N and K; 1, 2, 2 and 4 taps) used
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void igemm_dma_multi_kernel(const IgemmMulti q
     p.T = q.T[cls];
     p.tap_dy = q.tap_dy[cls]; p.tap_dx = q.tap_dx[cls]; p.tap_slot = q.tap_slot[cls];
     p.dy0 = q.dy0[cls]; p.dx0 = q.dx0[cls];
-    igemm_dma_body<BN, false, 0>(p, (int)blockIdx.x - q.prefix[cls], q.prefix[cls + 1] - q.prefix[cls]);
+    igemm_dma_body<BN, false, 1>(p, (int)blockIdx.x - q.prefix[cls], q.prefix[cls + 1] - q.prefix[cls]);      // (input gradients: no statistics)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -816,6 +817,7 @@ template <int BN, bool F32>
 void launch_variant(const IgemmArgs& a, unsigned tiles, hipStream_t stream) {
     constexpr size_t lds = 2 * (BM * 128 + BN * 128);
     if (a.epi_infer && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 2>), dim3(tiles), dim3(256), lds, stream, a);
+    else if (!a.stats && !F32) hipLaunchKernelGGL((igemm_dma_kernel<BN, false, 1>), dim3(tiles), dim3(256), lds, stream, a);      // no batch statistics asked for: the form without the sums
     else hipLaunchKernelGGL((igemm_dma_kernel<BN, F32>), dim3(tiles), dim3(256), lds, stream, a);
 }
 
@@ -981,12 +983,14 @@ int launch(IgemmArgs a, bool out_f32, hipStream_t stream, int kernel_opts = 0, b
         EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv: hipGetDevice failed");
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
-            const hipError_t e = hipFuncSetAttribute((const void*)igemm_dma_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)igemm_dma_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_dma_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", dev, hipGetErrorString(e));
             done.fetch_or(bit, std::memory_order_release);
         }
         const unsigned t128 = (unsigned)ep24_cdiv(a.M, BM) * (unsigned)ep24_cdiv(a.N, 128);
-        hipLaunchKernelGGL(igemm_dma_deep_kernel, dim3(t128), dim3(256), EP24_DEEP_STAGES * (BM * 128 + 128 * 128), stream, a);
+        if (a.stats) hipLaunchKernelGGL(igemm_dma_deep_kernel<0>, dim3(t128), dim3(256), EP24_DEEP_STAGES * (BM * 128 + 128 * 128), stream, a);
+        else hipLaunchKernelGGL(igemm_dma_deep_kernel<1>, dim3(t128), dim3(256), EP24_DEEP_STAGES * (BM * 128 + 128 * 128), stream, a);
         EP24_LAUNCH_CHECK("ep24_conv_igemm_deep");
         return EP24_OK;
     }

@@ -139,8 +139,9 @@ __device__ __forceinline__ void ring_store_half(const IgemmArgs& p, long m0, int
 // rounded FROM (fp32, as the tiled kernels); after a barrier every wave stores 8 chunks per lane, 8 lanes per 128-byte row segment.
 // Same values, same statistics and the same order of the fixed-point sums as igemm_epilogue: bit-identical outputs.
 // TBN = 64 (the narrow tile, 256 x 64): the four consumers hold 64 x 64 pieces stacked over the rows, CMT = 4.
-template <int TBN, int CMT, bool INFER = false>
+template <int TBN, int CMT, int EMODE = 0>                  // EMODE: 0 training (statistics), 1 inference (bias, act, residual), 2 training without statistics (input gradients)
 __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[CMT][NT], const bool consumer, long m0, int n0, int tile_m, char* smem) {
+    constexpr bool INFER = EMODE == 1, STATS = EMODE == 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -168,7 +169,7 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
         // HERE - ~1 050 instructions of one wave per SIMD, 256 of them the selects of `if (row < M) { s1 += v; s2 += v * v; }` (two per
         // value) and 128 the multiplies.  Now the accumulators of rows past M are cleared up front - only the launch's last row of tiles
         // has any (uniform branch) - so that they add zeros, and the sum of squares is one fused multiply-add per value.
-        if (!infer && m0 + RBM > p.M) {
+        if (STATS && m0 + RBM > p.M) {
 #pragma unroll
             for (int i = 0; i < CMT; ++i)
 #pragma unroll
@@ -201,7 +202,8 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
                         v = act_fwd(v + bias4[q], p.epi_act);
                         if (p.epi_res) v += (float)res4[q];
                     }
-                    s1[q] += v; s2[q] = fmaf(v, v, s2[q]);       // (the eval-mode form stores no statistics)
+                    // (an input gradient has no statistics - EMODE 2: the sums are 256 of the loop's ~500 instructions; the eval-mode form stores none either)
+                    if constexpr (STATS) { s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
                     w[q] = (bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(stg + sadr[r] + i * 2048) = w;
@@ -237,7 +239,7 @@ __device__ __forceinline__ void ring_epilogue(const IgemmArgs& p, f32x4 (&acc)[C
         ring_store_tile<TBN>(p, m0, n0, smem);
         ESTAMP(4);
     }
-    if (p.stats && consumer) {
+    if (STATS && p.stats && consumer) {
         // Round 5: every consumer publishes the sums of ITS 128 x 64 piece (64 x 64: the narrow tile) - no barrier, no LDS.  The fold of
         // the two row halves of a tile through LDS sat behind two workgroup barriers, the first of which waited for the loaders' half of
         // the stores (1 300 + 1 600 cycles of the epilogue's 10 500).  After the two butterflies every lane of a quarter holds the sums of
@@ -469,7 +471,7 @@ __device__ __forceinline__ void ring_epilogue32(const IgemmArgs& p, f32x16_ (&ac
 // level at B = 20: 128 tiles) or whose N is 64.  Consumers are stacked over the rows (64 x 64 each, 4 x 4 accumulator tiles): a step is
 // 8 groups of 4 MFMAs and 16 fragment reads, LDS read bandwidth and MFMA issue in balance (512 cycles each), so the loaders run TWO
 // steps ahead here (the next step's DMAs are issued before the wait for this step's: one step per round trip would bound the loop).
-template <int PPS, bool M32, int TBN = RBN, bool INFER = false>
+template <int PPS, bool M32, int TBN = RBN, int INFER = 0>        // INFER: the epilogue's EMODE (0 training, 1 inference, 2 training without statistics)
 __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_kernel(const IgemmArgs p, const int NP, const int halo, const int npb) {
     static_assert(TBN == 128 || (TBN == 64 && !M32), "tile widths: 128, or 64 with the 16 x 16 consumers");
     constexpr int CMT = TBN == 128 ? MT : 4;                 // accumulator row tiles per consumer
@@ -1346,7 +1348,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void conv_ring_generic_kernel(con
 }
 #endif   // EP24_AB_VARIANTS
 
-template <int PPS, bool M32, int TBN = RBN, bool INFER = false>
+template <int PPS, bool M32, int TBN = RBN, int INFER = 0>        // INFER: the epilogue's EMODE (0 training, 1 inference, 2 training without statistics)
 int launch_ring_pps(const IgemmArgs& a, int NP, int halo, int npb, size_t lds, hipStream_t stream) {
     const unsigned tiles = (unsigned)ep24_cdiv(a.M, RBM) * (unsigned)ep24_cdiv(a.N, TBN);
     static std::atomic<unsigned long long> done{0};          // per-device attribute, set once (conv_patch.hip has the reasons)
@@ -1448,9 +1450,14 @@ int launch_ring(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc, bool 
                 : pps == 2 ? launch_ring_pps<2, false, RBN, true>(a, np, halo, npb, lds, stream)
                            : launch_ring_pps<3, false, RBN, true>(a, np, halo, npb, lds, stream);
         else
-            *rc = pps <= 1 ? launch_ring_pps<1, false>(a, np, halo, npb, lds, stream)
-                : pps == 2 ? launch_ring_pps<2, false>(a, np, halo, npb, lds, stream)
-                           : launch_ring_pps<3, false>(a, np, halo, npb, lds, stream);
+            if (a.stats)
+                *rc = pps <= 1 ? launch_ring_pps<1, false>(a, np, halo, npb, lds, stream)
+                    : pps == 2 ? launch_ring_pps<2, false>(a, np, halo, npb, lds, stream)
+                               : launch_ring_pps<3, false>(a, np, halo, npb, lds, stream);
+            else                                                 // an input gradient: the form without the BatchNorm sums
+                *rc = pps <= 1 ? launch_ring_pps<1, false, RBN, 2>(a, np, halo, npb, lds, stream)
+                    : pps == 2 ? launch_ring_pps<2, false, RBN, 2>(a, np, halo, npb, lds, stream)
+                               : launch_ring_pps<3, false, RBN, 2>(a, np, halo, npb, lds, stream);
     }
     return narrow ? 2 : 1;
 }

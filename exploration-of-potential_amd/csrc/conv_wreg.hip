@@ -62,6 +62,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+template <bool STATS>                                   // false: an input gradient - no batch statistics (their sums were a fifth of the epilogue)
 __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const IgemmArgs p, const FastDiv d_wp, const FastDiv d_h, const int n_tiles, const int per_xcd, const int sgn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,8 +244,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const IgemmArgs p, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][qq][r];
-                    const float vs = live ? v : 0.f;
-                    s1[qq * 4 + r] += vs; s2[qq * 4 + r] = fmaf(vs, vs, s2[qq * 4 + r]);
+                    if constexpr (STATS) {
+                        const float vs = live ? v : 0.f;
+                        s1[qq * 4 + r] += vs; s2[qq * 4 + r] = fmaf(vs, vs, s2[qq * 4 + r]);
+                    }
                     o[qq * 4 + r] = (bf16)v;
                 }
             const int so = (live && cok) ? m * ((int)p.ld_dst * 2) + cbyte : OOB;      // every store is issued (counted waits)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const IgemmArgs p, c
         if (more) cmp_setup(next);
     }
 
-    if (p.stats) {
+    if (STATS && p.stats) {
         // a lane's sums are over its pixels (frow, the four blocks, every tile): fold the 16 pixel lanes, then the four pixel-block
         // waves of a channel half through LDS, in a fixed order
         float* red = reinterpret_cast<float*>(smem + RED_OFF);
@@ -341,7 +344,8 @@ bool launch_wreg(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
         EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "conv_wreg: hipGetDevice failed");
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
-            const hipError_t e = hipFuncSetAttribute((const void*)conv_wreg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WREG_LDS);
+            hipError_t e = hipFuncSetAttribute((const void*)conv_wreg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WREG_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_wreg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WREG_LDS);
             EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "conv_wreg: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) failed on device %d: %s", WREG_LDS, dev, hipGetErrorString(e));
             done.fetch_or(bit, std::memory_order_release);
         }
@@ -349,7 +353,8 @@ bool launch_wreg(const IgemmArgs& a, hipStream_t stream, bool dry, int* rc) {
         b.dst_bytes = (unsigned)dst_b;
         const int n_tiles = (int)((a.M + TM - 1) / TM);
         const int per_xcd = (n_tiles + 7) / 8;
-        hipLaunchKernelGGL(conv_wreg_kernel, dim3(256), dim3(NW * 64), WREG_LDS, stream, b, make_fastdiv((unsigned)(a.GW + 2)), make_fastdiv((unsigned)a.GH), n_tiles, per_xcd, sgn);
+        if (a.stats) hipLaunchKernelGGL(conv_wreg_kernel<true>, dim3(256), dim3(NW * 64), WREG_LDS, stream, b, make_fastdiv((unsigned)(a.GW + 2)), make_fastdiv((unsigned)a.GH), n_tiles, per_xcd, sgn);
+        else hipLaunchKernelGGL(conv_wreg_kernel<false>, dim3(256), dim3(NW * 64), WREG_LDS, stream, b, make_fastdiv((unsigned)(a.GW + 2)), make_fastdiv((unsigned)a.GH), n_tiles, per_xcd, sgn);
         return EP24_OK;
     }();
     return true;

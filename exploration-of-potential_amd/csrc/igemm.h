@@ -70,7 +70,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // channels of a pixel (8-byte packed bf16 stores).  Does: bias, BN batch statistics (2^-20 fixed-point int64 atomics, one
 // per channel per workgroup), bf16 / fp32 stores with optional accumulate, and for MODE 2 the inference form
 // y = act(acc + bias) + residual.
-template <int BN, bool OUT_F32, int MT, int MODE = 0, int NWV = 4, bool BNR = true>      // BNR false: no fused BatchNorm-backward sums in this instantiation
+template <int BN, bool OUT_F32, int MT, int MODE = 0, int NWV = 4, bool BNR = true>      // BNR false: no fused BatchNorm-backward sums in this instantiation; MODE 1: training without the batch statistics (an input gradient has none: round 5)
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[MT][4], long m0, int n0, int tile_m, char* smem) {
     constexpr int WN = BN / 64, WM = NWV / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,19 +85,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr bool infer = MODE == 2 && !OUT_F32;
+    constexpr bool STATS = MODE != 1;
     const bool fast_dst = (p.dsy == 1 && p.dsx == 1 && p.dy0 == 0 && p.dx0 == 0 && p.DW == p.GW && p.dp0 == 0 &&
                            p.dbs == (long)p.GH * p.GW);
     // Wide-store path (bf16 output, no fused extras, 16-byte aligned rows): the wave's 64 x 64 tile is staged through LDS
     // (free after the main loop) and leaves as 16-byte stores, 8 lanes per 128-byte row segment.  The direct form below
     // stores 8 bytes per lane, 16 instructions per lane: measured with in-kernel stamps, that store tail was 10.7 k cycles
     // per 256 x 128 tile (store-issue bound, ~7 B/clk/CU) - as long as five K steps of the main loop.
-    const bool wide = MODE == 0 && !OUT_F32 && !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 &&
+    const bool wide = (MODE == 0 || MODE == 1) && !OUT_F32 && !p.narrow_epi && (p.N & 7) == 0 && (p.ld_dst & 7) == 0 &&
                       (reinterpret_cast<unsigned long long>(p.dst) & 15) == 0;
     if (wide) {
         // fused BatchNorm-backward sums: the z rows of this wave's part of the tile are requested NOW, all of them (clamped indices, no
         // conditional load), so they arrive while the accumulators go through LDS - fetched inside the store loop they were eight
         // serial round trips per workgroup (+24 us per launch: more than the reduce kernel they replace)
-        const bool bnr = BNR && MODE == 0 && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
+        const bool bnr = BNR && (MODE == 0 || MODE == 1) && p.bnr_z != nullptr;      // uniform over the launch (the host admits it only with this store path)
         bf16x8 zr[MT * 2];
         if (bnr) {
             const int zc = n0 + wn * 64 + (lane & 7) * 8;
@@ -119,8 +120,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = acc[i][q][r] + bias4[q];
-                    const float vs = live ? v : 0.f;             // (one select per value; `if (live) { s1 += v; s2 += v * v; }` was two, and a multiply)
-                    s1[q] += vs; s2[q] = fmaf(vs, vs, s2[q]);
+                    if constexpr (STATS) {
+                        const float vs = live ? v : 0.f;         // (one select per value; `if (live) { s1 += v; s2 += v * v; }` was two, and a multiply)
+                        s1[q] += vs; s2[q] = fmaf(vs, vs, s2[q]);
+                    }
                     w[q] = (bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(stg + row * 128 + (((frow >> 1) ^ (row & 7)) << 4) + (frow & 1) * 8) = w;
@@ -280,7 +283,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             }
         }
     }
-    if (p.stats && wide) {
+    if (STATS && p.stats && wide) {
         // Round 5 (the 16-byte store path; as the ring's epilogue): every wave publishes the sums of its own MT*16 x 64 piece - no fold
         // through LDS, no barriers.  After the two butterflies every lane of a quarter holds the sums of its four channels; lane
         // (frow, fq) publishes channel 4 frow + fq.  (The fixed-point conversion is per wave piece now instead of per tile: equal to
@@ -301,7 +304,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x4 (&acc)[
             atomicAdd((unsigned long long*)(st + c), (unsigned long long)to_fix(av));
             atomicAdd((unsigned long long*)(st + (long)p.N + c), (unsigned long long)to_fix(bv));
         }
-    } else if (p.stats) {
+    } else if (STATS && p.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [NWV waves][2][64]
 #pragma unroll
