@@ -1,11 +1,11 @@
-mkdir -p gpurun_out/num
+mkdir -p gpurun_out/s32
 L=$PWD/exploration-of-potential_amd/ep24
-for cfg in "1.0 1.0 640 4" "0.25 0.33 128 2"; do
-  EP24_LIB=$L/libep24_r05g.so timeout -k 10 300 python tools/numeric_ab.py run gpurun_out/num/a.pt $cfg 2>&1 | grep -v amdgpu
-  EP24_LIB=$L/libep24_r05g.so timeout -k 10 300 python tools/numeric_ab.py run gpurun_out/num/a2.pt $cfg 2>&1 | grep -v amdgpu
-  EP24_LIB=$L/libep24.so timeout -k 10 300 python tools/numeric_ab.py run gpurun_out/num/b.pt $cfg 2>&1 | grep -v amdgpu
-  echo "== $cfg: r05g library twice (reproducibility), then r05g against HEAD"
-  python tools/numeric_ab.py cmp gpurun_out/num/a.pt gpurun_out/num/a2.pt
-  python tools/numeric_ab.py cmp gpurun_out/num/b.pt gpurun_out/num/a.pt
+timeout -k 10 600 python -m pytest tests/test_gpu_conv.py tests/test_gpu_xf.py tests/test_gpu_engine.py -x -q > gpurun_out/s32/tests.log 2>&1; rc=$?; tail -2 gpurun_out/s32/tests.log; [ $rc = 0 ] || exit $rc
+for r in 1 2 3; do
+  for lib in before ""; do
+    echo "== lib ${lib:-new}" >> gpurun_out/s32/step_ab.txt
+    EP24_LIB=$L/libep24${lib:+_$lib}.so timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/s32/b.out 2> gpurun_out/s32/b.err || { tail -5 gpurun_out/s32/b.err; exit 1; }
+    python -c "import sys,json; d=json.loads(open('gpurun_out/s32/b.out').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['families']['igemm_stream_kernel']['ms_per_step'])" >> gpurun_out/s32/step_ab.txt
+  done
 done
-rm -f gpurun_out/num/*.pt
+paste - - < gpurun_out/s32/step_ab.txt
