@@ -38,6 +38,10 @@ struct WgradArgs {
 template <int TW> __device__ __forceinline__ int rkey(int row);
 template <> __device__ __forceinline__ int rkey<128>(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 template <> __device__ __forceinline__ int rkey<64>(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+// 384-B rows (192 channels = the stem's 12 tap slots x 16): a row starts 32 banks after the one above it, so the 8 rows of a
+// half-wave's transposed read sit at slot (block ^ key) ^ 4 * (row & 1) of the 8 32-byte slots of a bank row - distinct with the
+// 64-channel key; the key stays below 4, so a permuted block stays inside its group of four of the 12 blocks
+template <> __device__ __forceinline__ int rkey<192>(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 // byte offset of 16-B chunk c of row r in a [64][TW] bf16 tile
 template <int TW> __device__ __forceinline__ int wr_off(int r, int c) {
     return r * (TW * 2) + ((((c >> 1) ^ rkey<TW>(r)) << 1 | (c & 1)) << 4);
@@ -122,7 +126,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock)
     // two divisions and 64-bit multiplies each, kept the VALU busier than the MFMAs: 90 -> 62 us per 3x3 256-ch layer.)
     int* xtab = reinterpret_cast<int*>(smem + 2 * STAGE);          // [2][64] byte offsets, XOOB = padding / past the end (VTAP: [2][64][4])
     constexpr int XOOB = 0x7FFF0000;
-    constexpr int XT = VTAP ? 256 : 64;                             // table entries per step
+    constexpr int XT = VTAP ? 64 * (TCI / 16) : 64;                 // table entries per step (VTAP: a row has TCI / 16 tap slots)
+    constexpr int NT = VTAP ? TCI / 64 : 1;                         // entries a thread produces per step (VTAP: tap slots tid % 4 + 4 k of its row)
     int x_row[XI], x_colb[XI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
@@ -130,7 +135,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock)
         const int r = U / XCH, pc = U % XCH;
         const int c = ((((pc >> 1) ^ rkey<TCI>(r)) << 1) | (pc & 1));
         if constexpr (VTAP) {                                       // chunk c = tap c / 2 of the tile, half c & 1 of the pixel
-            x_row[j] = r * 4 + (c >> 1);
+            x_row[j] = r * (TCI / 16) + (c >> 1);
             x_colb[j] = (c & 1) * 16;
         } else {
             x_row[j] = r;
@@ -152,10 +157,27 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock)
         t_off = n * p.c_n + oh * p.c_oh + ow * p.c_ow + ((pkh - ppad) * p.W + (pkw - ppad)) * p.c_pix;
     }
     const int lo_y = ppad - pkh, lo_x = ppad - pkw, wrap_x = p.OW * p.stride, wrap_y = p.OH * p.stride;
+    // VTAP with more than one tap slot per thread: slot k is tap vt + 4 k, t_off is the first one's and td[k] what the k-th adds
+    int lo_yk[NT], lo_xk[NT], td[NT];
+    if constexpr (VTAP) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int v = vt + 4 * k, h = (v * 11) >> 5, w = v - 3 * h;
+            lo_yk[k] = 1 - h; lo_xk[k] = 1 - w;
+            td[k] = v < 9 ? ((h - pkh) * p.W + (w - pkw)) * p.c_pix : -1;
+        }
+    }
     auto produce = [&](int slot) {
-        const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W && (!VTAP || vt < 9);
-        if constexpr (VTAP) xtab[slot * XT + tid] = ok ? t_off : XOOB;
-        else if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
+        if constexpr (VTAP) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_yk[k]) < (unsigned)p.H && (unsigned)(t_xs - lo_xk[k]) < (unsigned)p.W && td[k] != -1;
+                xtab[slot * XT + t_row * (TCI / 16) + (tid & 3) + 4 * k] = ok ? t_off + td[k] : XOOB;
+            }
+        } else {
+            const bool ok = t_p < p_end_i && (unsigned)(t_ys - lo_y) < (unsigned)p.H && (unsigned)(t_xs - lo_x) < (unsigned)p.W;
+            if (lane < 16) xtab[slot * 64 + t_row] = ok ? t_off : XOOB;
+        }
         t_p += 64; t_ys += p.s_dys; t_xs += p.s_dxs; t_off += p.s_doff;
         if (t_xs >= wrap_x) { t_xs -= wrap_x; t_ys += p.stride; t_off += p.c_oh - p.OW * p.c_ow; }
         if (t_ys >= wrap_y) { t_ys -= wrap_y; t_off += p.c_n - p.OH * p.c_oh; }
@@ -261,11 +283,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock)
     // slab form with whole 4-channel groups: 16-byte stores, a wave covers 8 rows x 128 B (64 x 64 tile) or 4 rows x 256 B per
     // instruction - a quarter of the store instructions of the 4-byte form below (the store tail is issue bound)
     if constexpr (VTAP) {                                    // column c of tile g = (tap 4 g + c / 16, channel c % 16) -> dW column tap * 12 + channel
-        const int c = lane, vtap = (ci0 >> 6) * 4 + (c >> 4), cc = c & 15;
         for (int row = wave; row < TCO; row += 4) {
             const int co = co0 + row;
             if (co >= p.cout_valid) break;
-            if (vtap < 9 && cc < 12) p.slab[(long)by * p.slab_stride + (long)co * p.ld_dw + vtap * 12 + cc] = tile[row * TCI + c];
+#pragma unroll
+            for (int c = lane; c < TCI; c += 64) {
+                const int vtap = (ci0 >> 6) * 4 + (c >> 4), cc = c & 15;
+                if (vtap < 9 && cc < 12) p.slab[(long)by * p.slab_stride + (long)co * p.ld_dw + vtap * 12 + cc] = tile[row * TCI + c];
+            }
         }
         return;
     }
@@ -684,6 +709,34 @@ void launch_wgrad(WgradArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((wgrad_kernel<TCO, TCI, VTAP>), grid, dim3(256), 2 * 64 * (TCO + TCI) * 2 + (VTAP ? 2048 : 512), stream, a);
 }
 
+// The stem as ONE 64 x 192 tile (round 5): all 12 tap slots of a pixel against one read of its dY row - the three 64 x 64 tiles read
+// every dY row three times (672 against 416 bytes per pixel through L2).  64 KB of stages + a 6-KB offset table: two workgroups per
+// CU, 512 pixel splits.
+constexpr int STEM_TCI = 192, STEM_LDS = 2 * 64 * (64 + STEM_TCI) * 2 + 2 * 64 * (STEM_TCI / 16) * 4;
+long stem_splits(const WgradArgs& a) {
+    const long steps = (a.M + 63) / 64;
+    long splits = 512;
+    if (splits > steps / 8) splits = steps / 8;
+    return splits < 1 ? 1 : splits;
+}
+int launch_stem(WgradArgs& a, hipStream_t stream) {
+    a.tiles_ci = 1; a.tiles_co = 1; a.tiles = 1;
+    const long steps = (a.M + 63) / 64, splits = stem_splits(a);
+    a.chunk = ((steps + splits - 1) / splits) * 64;
+    a.xcd_remap = 1;
+    static std::atomic<unsigned long long> done{0};          // more than 64 KB of dynamic LDS: the attribute, once per device
+    int dev = 0;
+    EP24_REQUIRE(hipGetDevice(&dev) == hipSuccess, EP24_E_LAUNCH, "stem_conv_wgrad: hipGetDevice failed");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<64, STEM_TCI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS);
+        EP24_REQUIRE(e == hipSuccess, EP24_E_LAUNCH, "stem_conv_wgrad: hipFuncSetAttribute failed on device %d: %s", dev, hipGetErrorString(e));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((wgrad_kernel<64, STEM_TCI, true>), dim3((unsigned)splits), dim3(256), STEM_LDS, stream, a);
+    return EP24_OK;
+}
+
 int fill_args(WgradArgs& a, const void* x, int64_t ld_x, const void* dy, int64_t ld_dy, float* dw, int64_t ld_dw, int cout_valid,
               int cin_valid, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
     EP24_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ld_x % 8 == 0 && ld_dy % 8 == 0, EP24_E_ARG,
@@ -940,7 +993,7 @@ int wgrad_ring_timeouts() {
 // Weight gradient of the Focus stem straight from the space-to-depth image (VTAP above): slab[s][Cout][108], column tap * 12 + channel
 static int stem_wgrad_args(WgradArgs& a, const void* f16, const void* dy, int64_t ld_dy, int B, int FH, int FW, int Cout) {
     EP24_REQUIRE(Cout % 8 == 0 && Cout > 0 && Cout <= 64, EP24_E_UNSUPPORTED, "stem_conv_wgrad: Cout=%d (a multiple of 8, at most 64)", Cout);
-    // three virtual channel tiles of 64 = 12 tap slots x 16 channels; 1x1 addressing over the 32-byte pixels
+    // one virtual channel tile of 192 = 12 tap slots x 16 channels; 1x1 addressing over the 32-byte pixels
     if (int rc = fill_args(a, f16, 16, dy, ld_dy, nullptr, 108, Cout, 108, B, FH, FW, 192, Cout, 1, 1)) return rc;
     a.x_bytes = (unsigned)((long)B * FH * FW * 32);
     return EP24_OK;
@@ -949,7 +1002,7 @@ static int stem_wgrad_args(WgradArgs& a, const void* f16, const void* dy, int64_
 extern "C" int ep24_stem_conv_wgrad_splits(int B, int FH, int FW, int Cout) {
     WgradArgs a{};
     if (int rc = stem_wgrad_args(a, nullptr, nullptr, (Cout + 7) / 8 * 8, B, FH, FW, Cout)) return rc;
-    return (int)wgrad_splits<64, 64>(a);
+    return (int)stem_splits(a);
 }
 
 extern "C" int ep24_stem_conv_wgrad_slab_bf16(const void* f16, const void* dy, int64_t ld_dy, float* slab, int64_t slab_floats, int B,
@@ -959,9 +1012,9 @@ extern "C" int ep24_stem_conv_wgrad_slab_bf16(const void* f16, const void* dy, i
     if (int rc = stem_wgrad_args(a, f16, dy, ld_dy, B, FH, FW, Cout)) return rc;
     a.slab = slab;
     a.slab_stride = (long)Cout * 108;
-    const long need = wgrad_splits<64, 64>(a) * a.slab_stride;
+    const long need = stem_splits(a) * a.slab_stride;
     EP24_REQUIRE(need <= slab_floats, EP24_E_ARG, "stem_conv_wgrad_slab: slab holds %ld floats, %ld needed", (long)slab_floats, need);
-    launch_wgrad<64, 64, true>(a, (hipStream_t)stream);
+    if (int rc = launch_stem(a, (hipStream_t)stream)) return rc;
     EP24_LAUNCH_CHECK("ep24_stem_conv_wgrad_slab");
     return EP24_OK;
 }
