@@ -1,20 +1,16 @@
-# final-tree record: the other configurations and the entry point's default mode beside bench.py, one box
-set -e
-R=$PWD; O=$R/gpurun_out/s35; mkdir -p $O
-cfg() { n=$1; shift; timeout -k 10 240 python bench.py --no-cpu-baseline --steps 40 --warmup 8 "$@" > $O/c_$n.json 2> $O/c_$n.err || { tail -5 $O/c_$n.err; exit 1; }
-  python -c "import json,sys; d=json.loads([l for l in open('$O/c_$n.json') if l.startswith('{')][-1]); print('%-14s %8.2f %7.3f   %s' % ('$n', d['value'], d['ms_per_step'], ' '.join(sys.argv[1:])))" "$@" | tee -a $O/configs.txt; }
-cfg default
-cfg vgg --backbone vgg
-cfg resnet --backbone resnet
-cfg densenet --backbone densenet
-cfg config5 --batch 8 --size 1280 --gts 50 --fisheye
-cfg longrun --long-run
-cd $R/exploration-of-potential_amd/yolox_24p
-timeout -k 10 300 python3 train_24p.py -f load_train/yolox_24p_l_train.py -b 20 -l 0.01 --synthetic --steps 250 --synthetic-len 6000 --log-interval 50 --output-dir $O/run --throughput-json $O/tp_raw_u8.json > $O/raw_u8.log 2>&1 || { tail -5 $O/raw_u8.log; exit 1; }
-rm -rf $O/run
-cd $R
-python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_sustained.json 2> $O/bench.err
-python3 -c "
-import json
-t=json.load(open('$O/tp_raw_u8.json')); b=json.loads([l for l in open('$O/bench_sustained.json') if l.startswith('{')][0])
-print('trainer', t['images_per_s'], 'bench', b['value'], 'ratio', round(t['images_per_s']/b['value'],4))"
+mkdir -p gpurun_out/s36
+L=$PWD/exploration-of-potential_amd/ep24
+timeout -k 10 500 python -m pytest tests/test_gpu_loss.py tests/test_gpu_engine.py tests/test_gpu_fp32.py tests/test_gpu_hazard.py tests/test_gpu_fullsize.py -x -q > gpurun_out/s36/tests.log 2>&1; rc=$?; tail -2 gpurun_out/s36/tests.log; [ $rc = 0 ] || exit $rc
+for lib in before ""; do
+  echo "== lib ${lib:-new}"
+  EP24_LIB=$L/libep24${lib:+_$lib}.so timeout -k 10 200 python tools/loss_time.py > gpurun_out/s36/loss_time_${lib:-new}.txt 2>&1 || { tail -5 gpurun_out/s36/loss_time_${lib:-new}.txt; exit 1; }
+  grep -i "dynamic_k\|sum" gpurun_out/s36/loss_time_${lib:-new}.txt
+done
+for r in 1 2 3; do
+  for lib in before ""; do
+    echo "== lib ${lib:-new}" >> gpurun_out/s36/step_ab.txt
+    EP24_LIB=$L/libep24${lib:+_$lib}.so timeout -k 10 200 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > gpurun_out/s36/b.out 2> gpurun_out/s36/b.err || { tail -5 gpurun_out/s36/b.err; exit 1; }
+    python -c "import sys,json; d=json.loads(open('gpurun_out/s36/b.out').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['loss'])" >> gpurun_out/s36/step_ab.txt
+  done
+done
+paste - - < gpurun_out/s36/step_ab.txt
