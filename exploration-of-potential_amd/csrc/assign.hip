@@ -324,12 +324,26 @@ __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const f
     const unsigned long long* mc = in_ctr + (long)b * A;
     float vpw[PER > 0 ? PER : 1], vco[PER > 0 ? PER : 1];
     if constexpr (PER > 0) {
+        // Every load of the row is UNCONDITIONAL and from a clamped address, so all 4 * PER of them leave in one batch.  Written as
+        // "cand ? pwr[a] : -inf" the loop compiled to a branch per element with the mask loads, a wait, and the value loads behind a
+        // second branch: 2 * PER dependent memory round trips in front of the first selection round - most of the kernel's time
+        // (round 5, session 3: the rounds themselves were rebuilt twice before the ISA was read).  A non-candidate's slot of pw / cost
+        // may hold anything; it is read and dropped.
+        unsigned long long m[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int a = threadIdx.x + 256 * j;
-            const bool cand = a < A && (mb[a] | mc[a]) != 0ull;
-            vpw[j] = cand ? pwr[a] : -INFINITY;                      // never selected
-            vco[j] = cand ? cr[a] : INFINITY;
+            const int ac = a < A ? a : A - 1;
+            m[j] = mb[ac] | mc[ac];
+            vpw[j] = pwr[ac];
+            vco[j] = cr[ac];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int a = threadIdx.x + 256 * j;
+            const bool cand = a < A && m[j] != 0ull;
+            vpw[j] = cand ? vpw[j] : -INFINITY;                      // never selected
+            vco[j] = cand ? vco[j] : INFINITY;
         }
     }
     // top-min(10,P) largest pairwise values, summed in descending order (losses.py:452-456)
@@ -338,13 +352,21 @@ __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const f
     for (int r = 0; r < 10; ++r) {
         float bv = -INFINITY; int bi = -1;
         if constexpr (PER > 0) {
+            // the element picked in the round before leaves the thread's values (a select per element, no "after the previous pick"
+            // test: 5 instead of ~20 instructions per element - a round's VALU time is A elements over the CU's four SIMDs whatever
+            // the thread count); the first strictly larger element wins, so equal values go by index as before
+            const int d = prev_i - (int)threadIdx.x;
+            int bj = -1;
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const int a = threadIdx.x + 256 * j;
-                const float v = vpw[j];
-                const bool after = v < prev_v || (v == prev_v && a > prev_i);
-                if (v > -INFINITY && after && (bi < 0 || v > bv)) { bv = v; bi = a; }
+                float v = vpw[j];
+                v = d == 256 * j ? -INFINITY : v;
+                vpw[j] = v;
+                const bool t = v > bv;
+                bv = t ? v : bv;
+                bj = t ? j : bj;
             }
+            bi = bj >= 0 ? (int)threadIdx.x + 256 * bj : -1;
         } else {
             for (int a = threadIdx.x; a < A; a += 256) {
                 if ((mb[a] | mc[a]) == 0ull) continue;
@@ -366,13 +388,18 @@ __global__ __launch_bounds__(256) void dynamic_k_kernel(const float* pw, const f
     for (int r = 0; r < k; ++r) {
         float bv = INFINITY; int bi = -1;
         if constexpr (PER > 0) {
+            const int d = prev_i - (int)threadIdx.x;
+            int bj = -1;
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const int a = threadIdx.x + 256 * j;
-                const float v = vco[j];
-                const bool after = v > prev_v || (v == prev_v && a > prev_i);
-                if (v < INFINITY && after && (bi < 0 || v < bv)) { bv = v; bi = a; }
+                float v = vco[j];
+                v = d == 256 * j ? INFINITY : v;
+                vco[j] = v;
+                const bool t = v < bv;
+                bv = t ? v : bv;
+                bj = t ? j : bj;
             }
+            bi = bj >= 0 ? (int)threadIdx.x + 256 * bj : -1;
         } else {
             for (int a = threadIdx.x; a < A; a += 256) {
                 if ((mb[a] | mc[a]) == 0ull) continue;
