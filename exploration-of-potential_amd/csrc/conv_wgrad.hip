@@ -76,10 +76,11 @@ template <int OFF_LO, int OFF_HI> __device__ __forceinline__ bf16x8 tr_pair(unsi
 // and channel tails use an out-of-range buffer offset (the DMA then writes zeros).  Two stages, one barrier per
 // 64-pixel step.
 //
-// VTAP (the Focus stem, round 3): X is the space-to-depth image [B][H][W][16] bf16 and the 64 "channels" of an X tile are four
-// taps x 16 channels of the 3x3 neighbourhood (tile g: taps 4 g .. 4 g + 3; the taps past the ninth and the channels past the
-// twelfth are zeros / dropped).  The offset table has one entry per (tile row, tap) - 256 per step, one per thread - and a DMA
-// lane picks the entry of its chunk's tap.  dW leaves as [Cout][tap * 12 + channel], the layout of the im2col form it replaces
+// VTAP (the Focus stem, round 3): X is the space-to-depth image [B][H][W][16] bf16 and the "channels" of an X tile are tap slots
+// x 16 channels of the 3x3 neighbourhood (the taps past the ninth and the channels past the twelfth are zeros / dropped).  Since
+// round 5 the stem runs as ONE tile of TCI = 192 = 12 tap slots (launch_stem below; as three 64-wide tiles g = taps 4 g .. 4 g + 3
+// every dY row was read three times).  The offset table has one entry per (tile row, tap slot) - 64 * TCI / 16 per step, TCI / 64
+// per thread - and a DMA lane picks the entry of its chunk's tap.  dW leaves as [Cout][tap * 12 + channel], the layout of the im2col form it replaces
 // (which re-read 224 bytes per pixel here: 0.40 ms at B = 20).
 template <int TCO, int TCI, bool VTAP = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int vblock) {
